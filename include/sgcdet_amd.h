@@ -1,0 +1,237 @@
+/*
+ * sgcdet_amd.h -- C ABI of the MI355X (gfx950) view-transformation library.
+ *
+ * This is the drop-in boundary for the SGCDet hot path.
+ * The reference reaches its native code through the pybind module `dfa3D._ext`
+ * (packages/3D-deformable-attention/DFA3D/dfa3D/ops/csrc/pybind.cpp:42-67); the
+ * four functions exported there map 1:1 onto the first four entry points below.
+ * The remaining entry points are the fused / restructured forms the MI355X host
+ * code calls instead of the reference's Python loops (file:line cited per
+ * function).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory
+ *     unless the name ends in `_host`;
+ *   - all tensors are dense row-major ("contiguous"), fp32 unless stated,
+ *     spatial-shape / level-start tensors are int64 exactly as the reference
+ *     passes them (value_spatial_shapes, value_level_start_index);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream); no internal synchronisation, no allocation, graph-capture safe;
+ *   - caller owns every buffer; outputs documented as "accumulated" must be
+ *     zeroed by the caller (same contract as the reference's backward,
+ *     TU/multi_scale_3ddeformable_attn_function.py:319-322);
+ *   - return 0 on success, a negative SGC_E* code otherwise; sgc_last_error()
+ *     returns a static, thread-local description of the last failure.  Launch
+ *     failures are returned, never printf-and-continue (contrast
+ *     csrc/cuda/wms_deform_attn_cuda.cu:45-48).
+ *   - index arithmetic inside kernels is 64-bit where products can pass 2^31.
+ *
+ * The CPU oracle (oracle/sgc_oracle.c, test infrastructure only) exports the
+ * same symbols with the same signatures (stream ignored, pointers = host
+ * memory), so one ctypes binding drives both.
+ *
+ * Shape letters: B batch (= cameras on the hot path), S = sum_l H_l*W_l value
+ * pixels, M heads, Cm channels per head, D depth bins, L levels, Q queries,
+ * P points per level.
+ */
+#ifndef SGCDET_AMD_H_
+#define SGCDET_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGC_OK 0
+#define SGC_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
+#define SGC_ELAUNCH (-2)  /* HIP launch / runtime error                          */
+#define SGC_EUNSUP (-3)   /* shape not supported by this build                    */
+
+#define SGC_ABI_VERSION 1
+
+typedef void *sgc_stream_t; /* hipStream_t */
+
+int sgc_abi_version(void);
+const char *sgc_last_error(void);
+/* "hip-gfx950" for the product library, "cpu-oracle" for oracle/libsgc_oracle.so */
+const char *sgc_backend(void);
+
+/* ------------------------------------------------------------------------- *
+ * 1. The four `dfa3D._ext` operators (pybind.cpp:42-67)
+ * ------------------------------------------------------------------------- */
+
+/* ms_depth_score_sample_forward (csrc/cuda/ms_depth_score_sample_cuda.cu:49-111,
+ * kernel common/cuda/ms_depth_score_sample_cuda_kernel.cuh:24-148).
+ *   dist   [B,S,M,D]        depth distributions (replicated per head, as the reference passes them)
+ *   shapes3[L,3] int64      (H,W,D) per level;  lsi [L] int64 level start index
+ *   loc3   [B,Q,M,L,P,3]    normalised (x=w, y=h, z=d) sampling locations
+ *   score  [B,Q,M,L,P,4]    OUT (fully written): depth score at the 4 bilinear corners,
+ *                           corner order [0]=(h0,w0) [1]=(h0,w1) [2]=(h1,w1) [3]=(h1,w0)
+ */
+int sgc_depth_score_forward(const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                            const float *loc3, float *score,
+                            int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream);
+
+/* wms_deform_attn_forward (csrc/cuda/wms_deform_attn_cuda.cu:213-288, kernel
+ * common/cuda/wms_deform_attn_cuda_kernel.cuh:24-80,240-303).
+ *   value  [B,S,M,Cm];  shapes2 [L,2] int64 (H,W);  loc2 [B,Q,M,L,P,2];  attn [B,Q,M,L,P];
+ *   score  [B,Q,M,L,P,4];  out [B,Q,M*Cm] OUT (fully written).
+ */
+int sgc_wms_forward(const float *value, const int64_t *shapes2, const int64_t *lsi,
+                    const float *loc2, const float *attn, const float *score, float *out,
+                    int B, int S, int M, int Cm, int L, int Q, int P, sgc_stream_t stream);
+
+/* wms_deform_attn_backward (csrc/cuda/wms_deform_attn_cuda.cu:291-370, kernels
+ * wms_deform_attn_cuda_kernel.cuh:82-159,305-531).
+ *   grad_out   [B,Q,M*Cm]
+ *   grad_value [B,S,M,Cm]      ACCUMULATED (+=, float atomics; caller zeroes)
+ *   grad_loc2  [B,Q,M,L,P,2]   written: (W * d/dw, H * d/dh)
+ *   grad_attn  [B,Q,M,L,P]     written
+ *   grad_score [B,Q,M,L,P,4]   written
+ */
+int sgc_wms_backward(const float *value, const int64_t *shapes2, const int64_t *lsi,
+                     const float *loc2, const float *attn, const float *score,
+                     const float *grad_out, float *grad_value, float *grad_loc2,
+                     float *grad_attn, float *grad_score,
+                     int B, int S, int M, int Cm, int L, int Q, int P, sgc_stream_t stream);
+
+/* ms_depth_score_sample_backward (csrc/cuda/ms_depth_score_sample_cuda.cu:137-201,
+ * kernel ms_depth_score_sample_cuda_kernel.cuh:150-327).
+ *   grad_score [B,Q,M,L,P,4]
+ *   grad_dist  [B,S,M,D]       ACCUMULATED (+=; caller zeroes)
+ *   grad_loc3  [B,Q,M,L,P,3]   written: (0, 0, D * sum_k g_k (v_d1 - v_d0)); the u,v
+ *                              gradient through the score is dropped exactly as the
+ *                              reference does (kernel.cuh:238-239).
+ */
+int sgc_depth_score_backward(const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                             const float *loc3, const float *grad_score,
+                             float *grad_dist, float *grad_loc3,
+                             int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 2. Fused 3D deformable attention (one launch instead of the reference's
+ *    two-stage MultiScale3DDeformableAttnFunction_fp32,
+ *    TU/multi_scale_3ddeformable_attn_function.py:275-351)
+ * ------------------------------------------------------------------------- */
+
+/* Forward.  dist is [B,S,dist_heads,D] with dist_heads == 1 (un-replicated; what the
+ * MI355X host passes) or == M (the reference's `.repeat(1,1,num_heads,1)` layout,
+ * TU/deformable_cross_attention.py:82,422).  attn may be NULL (= all ones, the
+ * Grid_Sample_3D_Feature case, TU/deformable_cross_attention.py:85).
+ * score_or_null: optional [B,Q,M,L,P,4] OUT to materialise the depth scores.      */
+int sgc_dfa3d_forward(const float *value, const float *dist, const int64_t *shapes3,
+                      const int64_t *lsi, const float *loc3, const float *attn,
+                      float *out, float *score_or_null,
+                      int B, int S, int M, int Cm, int D, int dist_heads,
+                      int L, int Q, int P, sgc_stream_t stream);
+
+/* Backward of the fused op == backward() of MultiScale3DDeformableAttnFunction_fp32
+ * (TU/multi_scale_3ddeformable_attn_function.py:303-351):
+ *   grad_value [B,S,M,Cm] ACCUMULATED;  grad_dist [B,S,dist_heads,D] ACCUMULATED (for
+ *   dist_heads == 1 this is already the sum over heads that autograd of `.repeat`
+ *   would produce);  grad_loc3 [B,Q,M,L,P,3] written (uv from the weighted gather,
+ *   z from the depth score);  grad_attn_or_null [B,Q,M,L,P] written.               */
+int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *shapes3,
+                       const int64_t *lsi, const float *loc3, const float *attn,
+                       const float *grad_out, float *grad_value, float *grad_dist,
+                       float *grad_loc3, float *grad_attn_or_null,
+                       int B, int S, int M, int Cm, int D, int dist_heads,
+                       int L, int Q, int P, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 3. Voxel -> pixel projection and per-camera compaction
+ *    (replaces VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223, and
+ *     the per-camera nonzero / rebatch loops, TU/deformable_cross_attention.py:759-773)
+ * ------------------------------------------------------------------------- */
+
+/* ref3d [Nq,3] voxel reference points (DenseHead.ref_3d rows of the selected voxels,
+ * WITHOUT origin), origin[3], proj [N,3,4] = (K' @ E_i[:3]) -- all device fp32.
+ * ref_cam [N,Nq,3] OUT = (u/img_w, v/img_h, (z-d_near)/(d_far-d_near));
+ * mask [N,Nq] uint8 OUT = z>eps & eps<u<1-eps & eps<v<1-eps  (eps = 1e-5).
+ * Arithmetic order is fixed and documented in DESIGN.md (no FMA contraction).      */
+int sgc_project_points(const float *ref3d, const float *origin, const float *proj,
+                       float *ref_cam, uint8_t *mask,
+                       int N, int Nq, float img_w, float img_h, float d_near, float d_far,
+                       sgc_stream_t stream);
+
+/* Compaction of mask[N,Nq] into the (camera, query) pair list, camera-major, query
+ * ascending inside a camera == concatenation of the reference's `indexes[i]`.
+ *   cam_count [N] int32 OUT, cam_offset [N+1] int32 OUT (exclusive scan),
+ *   pair_cam / pair_q [cap] int32 OUT (first n_pairs entries valid),
+ *   slot [N,Nq] int32 OUT: pair index of (cam,q) or -1,
+ *   vox_count [Nq] int32 OUT: #cameras seeing q, valid_index [Nq] int32 OUT: ascending
+ *   q with count>0 (reference `valid_index`, TU/deformable_cross_attention.py:822),
+ *   totals [4] int32 OUT: {n_pairs, n_valid, max_len, 0}.
+ * workspace: >= (N*Nq + Nq + 2*N + 64) int32.                                      */
+int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
+                      int32_t *cam_count, int32_t *cam_offset,
+                      int32_t *pair_cam, int32_t *pair_q, int32_t *slot,
+                      int32_t *vox_count, int32_t *valid_index, int32_t *totals,
+                      int32_t *workspace, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 4. Pair-list forms of the gather (no padded `max_len` rebatch, no dense slots)
+ * ------------------------------------------------------------------------- */
+
+/* Geometry-aware sample == Grid_Sample_3D_Feature (TU/deformable_cross_attention.py:67-116)
+ * evaluated only on visible pairs:  feat [N,S,C], dist [N,S,D], one level (H,W);
+ * out[p,:] = depth-weighted bilinear sample of camera pair_cam[p] at ref_cam[pair_cam[p], pair_q[p]].
+ *   ref_cam [N,Nq,3];  out [n_pairs,C] fully written.  n_pairs is read from
+ *   totals[0] on the device when n_pairs_or_neg < 0 (then `cap` bounds the grid).   */
+int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
+                              const int32_t *pair_cam, const int32_t *pair_q,
+                              const int32_t *totals, float *out,
+                              int N, int Nq, int H, int W, int C, int D,
+                              int n_pairs_or_neg, int cap, sgc_stream_t stream);
+
+/* Context-aware deformable gather == the DFA3D call of MSDeformableAttention3D_DFA3D
+ * (TU/deformable_cross_attention.py:423-489) with the softmax over the L*P points and
+ * the `ref + offset / (W,H,D)` location arithmetic fused in (one level, L = 1):
+ *   value [N,S,M,Cm] (value_proj output), dist [N,S,D],
+ *   raw [n_pairs, M*P*4]: per pair the three Linear outputs laid out as
+ *       [ M*P*2 uv offsets (m,p,xy) | M*P depth offsets (m,p) | M*P attention logits (m,p) ],
+ *   out [n_pairs, M*Cm] fully written.                                             */
+int sgc_pairs_deform_gather(const float *value, const float *dist, const float *ref_cam,
+                            const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
+                            const int32_t *totals, float *out,
+                            int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                            int n_pairs_or_neg, int cap, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 5. Inter-view aggregation (TU/deformable_cross_attention.py:815-837)
+ * ------------------------------------------------------------------------- */
+
+/* Masked mean over the cameras that see a voxel (:819-826):
+ *   feat [n_pairs,C], slot [N,Nq], valid_index [n_valid] -> mean [n_valid,C].      */
+int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
+                  float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream);
+
+/* Softmax over views of nn.MultiheadAttention with query length 1 (:829-833):
+ *   q [n_valid,C] (already in-projected, NOT yet scaled), kv [n_pairs,2C] (k | v
+ *   in-projected per visible pair), heads -> ctx [n_valid,C] (before out_proj).
+ *   Invisible cameras are the reference's key_padding_mask = -inf entries.          */
+int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
+                    const int32_t *valid_index, float *ctx,
+                    int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 6. Volume glue
+ * ------------------------------------------------------------------------- */
+
+/* rows [n,C] scattered to vol[idx[i],:] (DenseHead.forward scatter, DenseHead.py:80-81,
+ * and `output[:,valid_index,:] = slots_mean`, TU/deformable_cross_attention.py:835-836).
+ * idx2_or_null composes two index maps: dst row = idx2[idx[i]].                     */
+int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
+                     float *vol, int n, int C, sgc_stream_t stream);
+
+/* NCHW -> NHWC crop-and-transpose of the FPN / depth maps
+ * (TU/transformer.py:151-170 flatten+permute, AdaptiveSparseHead.py:53-59 crop):
+ *   src [N,C,Hs,Ws] -> dst [N,H*W,C] taking rows < H, cols < W.                     */
+int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
+                          int H, int W, sgc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGCDET_AMD_H_ */

@@ -1,0 +1,622 @@
+/*
+ * sgc_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the arithmetic of the reference's two CUDA kernel
+ * families (the only native code on the SGCDet hot path) and of the torch glue
+ * the MI355X library replaces with its own kernels.  It exports the symbols of
+ * include/sgcdet_amd.h with host pointers and `stream` ignored, so that the same
+ * ctypes binding drives the HIP library and this checker.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (sgcdet_amd/) never does.
+ *
+ * Pinning status: the reference ships NO test vectors for this path
+ * (packages/3D-deformable-attention/unittest_DFA3D.py:71-72 only checks NaN and
+ * needs CUDA) and its kernels cannot be built here (CUDA sources, no nvcc).
+ * "parity unpinned" by the reference's own tests; this file is pinned instead by
+ * (1) the independent closed form  grid_sample(value (x) dist)  evaluated with
+ * torch on the CPU (tests/test_oracle_identity.py) and (2) golden vectors made
+ * by running the reference's Python glue in the build container with this
+ * oracle injected as `dfa3D._ext` (tests/golden/make_golden.py).
+ *
+ * Reference files restated (paths relative to /root/reference; CS = packages/
+ * 3D-deformable-attention/DFA3D/dfa3D/ops/csrc):
+ *   depth score fwd  CS/common/cuda/ms_depth_score_sample_cuda_kernel.cuh:24-148
+ *   depth score bwd  CS/common/cuda/ms_depth_score_sample_cuda_kernel.cuh:150-327
+ *   weighted attn fwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:24-80,240-303
+ *   weighted attn bwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:82-159,305-419
+ *
+ * All arithmetic is fp32 in the reference's operation order; compile with
+ * -ffp-contract=off so gcc does not fuse multiply-adds the reference's nvcc
+ * build may or may not have fused (differences are <= 1 ulp per term either way).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../include/sgcdet_amd.h"
+
+static __thread char g_err[256] = "";
+
+static int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+int sgc_abi_version(void) { return SGC_ABI_VERSION; }
+const char *sgc_last_error(void) { return g_err; }
+const char *sgc_backend(void) { return "cpu-oracle"; }
+
+/* ---- shared helpers ------------------------------------------------------ */
+
+/* depth scores of one sample: ms_depth_score_sample_cuda_kernel.cuh:129-141 (gate)
+ * and :24-93 (im2col_trilinear).  dist_px(h,w) -> pointer to the D-vector of the
+ * pixel for this (batch, head).  s[] must be zero on entry (output is pre-zeroed
+ * in the reference, cuda.cu:83-85, and the helper does `+=`).                     */
+static void depth_score_sample(const float *dist_b, int64_t pix_stride, int head_off,
+                               int H, int W, int D, float x, float y, float z, float s[4]) {
+  const float h_im = y * H - 0.5f;
+  const float w_im = x * W - 0.5f;
+  const float d_im = z * D - 0.5f;
+  s[0] = s[1] = s[2] = s[3] = 0.f;
+  if (!(h_im > -1 && w_im > -1 && d_im > -1 && h_im < H && w_im < W && d_im < D)) return;
+  const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), d0 = (int)floorf(d_im);
+  const int h1 = h0 + 1, w1 = w0 + 1, d1 = d0 + 1;
+  const float ld = d_im - d0, hd = 1 - ld;
+  const int hs[4] = {h0, h0, h1, h1}; /* reference corner order: (h0,w0) (h0,w1) (h1,w1) (h1,w0) */
+  const int ws[4] = {w0, w1, w1, w0};
+  for (int k = 0; k < 4; ++k) {
+    const int h = hs[k], w = ws[k];
+    if (h < 0 || h > H - 1 || w < 0 || w > W - 1) continue;
+    const float *p = dist_b + ((int64_t)h * W + w) * pix_stride + head_off;
+    const float va = (d0 >= 0) ? p[d0] : 0.f;
+    const float vb = (d1 <= D - 1) ? p[d1] : 0.f;
+    s[k] = va * hd + vb * ld;
+  }
+}
+
+/* ---- 1a. depth score forward ------------------------------------------- */
+int sgc_depth_score_forward(const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                            const float *loc3, float *score,
+                            int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!dist || !shapes3 || !lsi || !loc3 || !score) return fail(SGC_EINVAL, "null pointer");
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m; /* "sampling_index" :104 */
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
+          const float *dist_b = dist + ((int64_t)b * S + lsi[l]) * M * D;
+          for (int p = 0; p < P; ++p) {
+            const int64_t pt = (sidx * L + l) * P + p;
+            depth_score_sample(dist_b, (int64_t)M * D, m * D, H, W, Dl, loc3[pt * 3], loc3[pt * 3 + 1],
+                               loc3[pt * 3 + 2], score + pt * 4);
+          }
+        }
+      }
+  return SGC_OK;
+}
+
+/* one weighted bilinear term: wms_deform_attn_cuda_kernel.cuh:24-80.
+ * vb = value + offset of (batch, level), stride between pixels = M*Cm.             */
+static float wms_bilinear(const float *vb, int H, int W, int MC, int mc_off, float h, float w,
+                          const float s[4]) {
+  const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+  const int h1 = h0 + 1, w1 = w0 + 1;
+  const float lh = h - h0, lw = w - w0, hh = 1 - lh, hw = 1 - lw;
+  float v1 = 0, v2 = 0, v3 = 0, v4 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+  if (h0 >= 0 && w0 >= 0) { d1 = s[0]; v1 = vb[((int64_t)h0 * W + w0) * MC + mc_off]; }
+  if (h0 >= 0 && w1 <= W - 1) { d2 = s[1]; v2 = vb[((int64_t)h0 * W + w1) * MC + mc_off]; }
+  if (h1 <= H - 1 && w0 >= 0) { d3 = s[3]; v3 = vb[((int64_t)h1 * W + w0) * MC + mc_off]; }
+  if (h1 <= H - 1 && w1 <= W - 1) { d4 = s[2]; v4 = vb[((int64_t)h1 * W + w1) * MC + mc_off]; }
+  const float a1 = hh * hw * d1, a2 = hh * lw * d2, a3 = lh * hw * d3, a4 = lh * lw * d4;
+  return a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4;
+}
+
+/* ---- 1b. weighted deformable attention forward ---------------------------- */
+int sgc_wms_forward(const float *value, const int64_t *shapes2, const int64_t *lsi,
+                    const float *loc2, const float *attn, const float *score, float *out,
+                    int B, int S, int M, int Cm, int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!value || !shapes2 || !lsi || !loc2 || !attn || !score || !out)
+    return fail(SGC_EINVAL, "null pointer");
+  const int MC = M * Cm;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m;
+        for (int c = 0; c < Cm; ++c) {
+          float col = 0.f; /* :270 */
+          for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes2[l * 2], W = (int)shapes2[l * 2 + 1];
+            const float *vb = value + ((int64_t)b * S + lsi[l]) * MC;
+            for (int p = 0; p < P; ++p) {
+              const int64_t pt = (sidx * L + l) * P + p;
+              const float h_im = loc2[pt * 2 + 1] * H - 0.5f; /* :286-287 */
+              const float w_im = loc2[pt * 2] * W - 0.5f;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+                col += wms_bilinear(vb, H, W, MC, m * Cm + c, h_im, w_im, score + pt * 4) * attn[pt];
+            }
+          }
+          out[sidx * Cm + c] = col;
+        }
+      }
+  return SGC_OK;
+}
+
+/* ---- 1c. weighted deformable attention backward --------------------------- */
+int sgc_wms_backward(const float *value, const int64_t *shapes2, const int64_t *lsi,
+                     const float *loc2, const float *attn, const float *score,
+                     const float *grad_out, float *grad_value, float *grad_loc2,
+                     float *grad_attn, float *grad_score,
+                     int B, int S, int M, int Cm, int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!value || !shapes2 || !lsi || !loc2 || !attn || !score || !grad_out || !grad_value ||
+      !grad_loc2 || !grad_attn || !grad_score)
+    return fail(SGC_EINVAL, "null pointer");
+  const int MC = M * Cm;
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m;
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes2[l * 2], W = (int)shapes2[l * 2 + 1];
+          const float *vb = value + ((int64_t)b * S + lsi[l]) * MC;
+          float *gvb = grad_value + ((int64_t)b * S + lsi[l]) * MC;
+          for (int p = 0; p < P; ++p) {
+            const int64_t pt = (sidx * L + l) * P + p;
+            const float *s = score + pt * 4;
+            const float aw = attn[pt];
+            const float h_im = loc2[pt * 2 + 1] * H - 0.5f;
+            const float w_im = loc2[pt * 2] * W - 0.5f;
+            /* per-(b,q,m,l,p) sums over the Cm channel threads, taken sequentially in
+             * c like the tid==0 loop of reduce_v1 (:378-398) */
+            float gw = 0, gh = 0, ga = 0, gs[4] = {0, 0, 0, 0};
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+              const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+              const float lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+              const float a1 = hh * hw * s[0], a2 = hh * lw * s[1], a3 = lh * hw * s[3],
+                          a4 = lh * lw * s[2]; /* :106 */
+              for (int c = 0; c < Cm; ++c) {
+                const int off = m * Cm + c;
+                const float top = grad_out[sidx * Cm + c];
+                const float tgv = top * aw; /* :107 */
+                float ghw = 0, gww = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                if (h0 >= 0 && w0 >= 0) { /* :112-120 */
+                  const int64_t o = ((int64_t)h0 * W + w0) * MC + off;
+                  v1 = vb[o];
+                  ghw -= s[0] * hw * v1; gww -= s[0] * hh * v1;
+                  gvb[o] += a1 * tgv;
+                  gs[0] += v1 * hh * hw * tgv;
+                }
+                if (h0 >= 0 && w1 <= W - 1) { /* :123-131 */
+                  const int64_t o = ((int64_t)h0 * W + w1) * MC + off;
+                  v2 = vb[o];
+                  ghw -= s[1] * lw * v2; gww += s[1] * hh * v2;
+                  gvb[o] += a2 * tgv;
+                  gs[1] += v2 * hh * lw * tgv;
+                }
+                if (h1 <= H - 1 && w0 >= 0) { /* :134-142 */
+                  const int64_t o = ((int64_t)h1 * W + w0) * MC + off;
+                  v3 = vb[o];
+                  ghw += s[3] * hw * v3; gww -= s[3] * lh * v3;
+                  gvb[o] += a3 * tgv;
+                  gs[3] += v3 * lh * hw * tgv;
+                }
+                if (h1 <= H - 1 && w1 <= W - 1) { /* :145-153 */
+                  const int64_t o = ((int64_t)h1 * W + w1) * MC + off;
+                  v4 = vb[o];
+                  ghw += s[2] * lw * v4; gww += s[2] * lh * v4;
+                  gvb[o] += a4 * tgv;
+                  gs[2] += v4 * lh * lw * tgv;
+                }
+                const float val = a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4;
+                ga += top * val;      /* :156 */
+                gw += W * gww * tgv;  /* :157 */
+                gh += H * ghw * tgv;  /* :158 */
+              }
+            }
+            grad_loc2[pt * 2] = gw;
+            grad_loc2[pt * 2 + 1] = gh;
+            grad_attn[pt] = ga;
+            memcpy(grad_score + pt * 4, gs, sizeof gs);
+          }
+        }
+      }
+  return SGC_OK;
+}
+
+/* gradient of one sample's 4 depth scores w.r.t. dist and z:
+ * ms_depth_score_sample_cuda_kernel.cuh:150-241 (one case per corner).            */
+static float depth_score_sample_bwd(const float *dist_b, float *gdist_b, int64_t pix_stride,
+                                    int head_off, int H, int W, int D, float x, float y, float z,
+                                    const float g[4]) {
+  const float h_im = y * H - 0.5f, w_im = x * W - 0.5f, d_im = z * D - 0.5f;
+  if (!(h_im > -1 && w_im > -1 && d_im > -1 && h_im < H && w_im < W && d_im < D)) return 0.f;
+  const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), d0 = (int)floorf(d_im);
+  const int h1 = h0 + 1, w1 = w0 + 1, d1 = d0 + 1;
+  const float ld = d_im - d0, hd = 1 - ld;
+  const int hs[4] = {h0, h0, h1, h1};
+  const int ws[4] = {w0, w1, w1, w0};
+  float gz = 0.f; /* reduced over the 4 corner threads, :304-314 */
+  for (int k = 0; k < 4; ++k) {
+    const int h = hs[k], w = ws[k];
+    float va = 0, vb = 0;
+    if (h >= 0 && h <= H - 1 && w >= 0 && w <= W - 1) {
+      const int64_t o = ((int64_t)h * W + w) * pix_stride + head_off;
+      if (d0 >= 0) { va = dist_b[o + d0]; gdist_b[o + d0] += hd * g[k]; }
+      if (d1 <= D - 1) { vb = dist_b[o + d1]; gdist_b[o + d1] += ld * g[k]; }
+    }
+    gz += D * (g[k] * (vb - va)); /* :193,240 */
+  }
+  return gz;
+}
+
+/* ---- 1d. depth score backward -------------------------------------------- */
+int sgc_depth_score_backward(const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                             const float *loc3, const float *grad_score,
+                             float *grad_dist, float *grad_loc3,
+                             int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!dist || !shapes3 || !lsi || !loc3 || !grad_score || !grad_dist || !grad_loc3)
+    return fail(SGC_EINVAL, "null pointer");
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m;
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
+          const int64_t boff = ((int64_t)b * S + lsi[l]) * M * D;
+          for (int p = 0; p < P; ++p) {
+            const int64_t pt = (sidx * L + l) * P + p;
+            const float gz = depth_score_sample_bwd(dist + boff, grad_dist + boff, (int64_t)M * D, m * D,
+                                                    H, W, Dl, loc3[pt * 3], loc3[pt * 3 + 1],
+                                                    loc3[pt * 3 + 2], grad_score + pt * 4);
+            grad_loc3[pt * 3] = 0.f; /* :238-239: uv gradient through the score is dropped */
+            grad_loc3[pt * 3 + 1] = 0.f;
+            grad_loc3[pt * 3 + 2] = gz;
+          }
+        }
+      }
+  return SGC_OK;
+}
+
+/* ---- 2. fused forms -------------------------------------------------------- */
+int sgc_dfa3d_forward(const float *value, const float *dist, const int64_t *shapes3,
+                      const int64_t *lsi, const float *loc3, const float *attn,
+                      float *out, float *score_or_null,
+                      int B, int S, int M, int Cm, int D, int dist_heads,
+                      int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !out) return fail(SGC_EINVAL, "null pointer");
+  if (dist_heads != 1 && dist_heads != M) return fail(SGC_EINVAL, "dist_heads must be 1 or M");
+  const int MC = M * Cm;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m;
+        float *o = out + sidx * Cm;
+        for (int c = 0; c < Cm; ++c) o[c] = 0.f;
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
+          const float *vb = value + ((int64_t)b * S + lsi[l]) * MC;
+          const float *db = dist + ((int64_t)b * S + lsi[l]) * dist_heads * D;
+          for (int p = 0; p < P; ++p) {
+            const int64_t pt = (sidx * L + l) * P + p;
+            float s[4];
+            const float x = loc3[pt * 3], y = loc3[pt * 3 + 1], z = loc3[pt * 3 + 2];
+            depth_score_sample(db, (int64_t)dist_heads * D, (dist_heads == 1 ? 0 : m) * D, H, W, Dl, x, y, z, s);
+            if (score_or_null) memcpy(score_or_null + pt * 4, s, sizeof s);
+            const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+            const float aw = attn ? attn[pt] : 1.0f;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+              for (int c = 0; c < Cm; ++c)
+                o[c] += wms_bilinear(vb, H, W, MC, m * Cm + c, h_im, w_im, s) * aw;
+          }
+        }
+      }
+  return SGC_OK;
+}
+
+int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *shapes3,
+                       const int64_t *lsi, const float *loc3, const float *attn,
+                       const float *grad_out, float *grad_value, float *grad_dist,
+                       float *grad_loc3, float *grad_attn_or_null,
+                       int B, int S, int M, int Cm, int D, int dist_heads,
+                       int L, int Q, int P, sgc_stream_t stream) {
+  (void)stream;
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !grad_out || !grad_value || !grad_dist || !grad_loc3)
+    return fail(SGC_EINVAL, "null pointer");
+  if (dist_heads != 1 && dist_heads != M) return fail(SGC_EINVAL, "dist_heads must be 1 or M");
+  const int MC = M * Cm;
+  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < Q; ++q)
+      for (int m = 0; m < M; ++m) {
+        const int64_t sidx = ((int64_t)b * Q + q) * M + m;
+        for (int l = 0; l < L; ++l) {
+          const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
+          const int64_t voff = ((int64_t)b * S + lsi[l]) * MC;
+          const int64_t doff = ((int64_t)b * S + lsi[l]) * dist_heads * D;
+          const int hoff = (dist_heads == 1 ? 0 : m) * D;
+          for (int p = 0; p < P; ++p) {
+            const int64_t pt = (sidx * L + l) * P + p;
+            const float x = loc3[pt * 3], y = loc3[pt * 3 + 1], z = loc3[pt * 3 + 2];
+            float s[4];
+            depth_score_sample(dist + doff, (int64_t)dist_heads * D, hoff, H, W, Dl, x, y, z, s);
+            const float aw = attn ? attn[pt] : 1.0f;
+            const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+            float gw = 0, gh = 0, ga = 0, gs[4] = {0, 0, 0, 0};
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+              const float *vb = value + voff;
+              float *gvb = grad_value + voff;
+              const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+              const float lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+              const float a1 = hh * hw * s[0], a2 = hh * lw * s[1], a3 = lh * hw * s[3], a4 = lh * lw * s[2];
+              for (int c = 0; c < Cm; ++c) {
+                const int off = m * Cm + c;
+                const float top = grad_out[sidx * Cm + c], tgv = top * aw;
+                float ghw = 0, gww = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                if (h0 >= 0 && w0 >= 0) {
+                  const int64_t o = ((int64_t)h0 * W + w0) * MC + off; v1 = vb[o];
+                  ghw -= s[0] * hw * v1; gww -= s[0] * hh * v1; gvb[o] += a1 * tgv; gs[0] += v1 * hh * hw * tgv;
+                }
+                if (h0 >= 0 && w1 <= W - 1) {
+                  const int64_t o = ((int64_t)h0 * W + w1) * MC + off; v2 = vb[o];
+                  ghw -= s[1] * lw * v2; gww += s[1] * hh * v2; gvb[o] += a2 * tgv; gs[1] += v2 * hh * lw * tgv;
+                }
+                if (h1 <= H - 1 && w0 >= 0) {
+                  const int64_t o = ((int64_t)h1 * W + w0) * MC + off; v3 = vb[o];
+                  ghw += s[3] * hw * v3; gww -= s[3] * lh * v3; gvb[o] += a3 * tgv; gs[3] += v3 * lh * hw * tgv;
+                }
+                if (h1 <= H - 1 && w1 <= W - 1) {
+                  const int64_t o = ((int64_t)h1 * W + w1) * MC + off; v4 = vb[o];
+                  ghw += s[2] * lw * v4; gww += s[2] * lh * v4; gvb[o] += a4 * tgv; gs[2] += v4 * lh * lw * tgv;
+                }
+                ga += top * (a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4);
+                gw += W * gww * tgv;
+                gh += H * ghw * tgv;
+              }
+            }
+            const float gz = depth_score_sample_bwd(dist + doff, grad_dist + doff, (int64_t)dist_heads * D,
+                                                    hoff, H, W, Dl, x, y, z, gs);
+            grad_loc3[pt * 3] = gw;      /* python merge, multi_scale_3ddeformable_attn_function.py:349 */
+            grad_loc3[pt * 3 + 1] = gh;
+            grad_loc3[pt * 3 + 2] = gz;
+            if (grad_attn_or_null) grad_attn_or_null[pt] = ga;
+          }
+        }
+      }
+  return SGC_OK;
+}
+
+/* ---- 3. projection + compaction ------------------------------------------ */
+/* VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223.  Fixed order:
+ *   p = ref + origin;  cam_r = ((P_r0*x + P_r1*y) + P_r2*z) + P_r3  (no FMA);
+ *   den = max(cam_z, eps);  u = (cam_x/den) * (1/img_w);  v = (cam_y/den) * (1/img_h);
+ *   zn = (cam_z - d_near) * (1/(d_far - d_near))
+ * (torch's GPU `tensor / python_scalar` multiplies by the fp32 reciprocal).         */
+int sgc_project_points(const float *ref3d, const float *origin, const float *proj,
+                       float *ref_cam, uint8_t *mask,
+                       int N, int Nq, float img_w, float img_h, float d_near, float d_far,
+                       sgc_stream_t stream) {
+  (void)stream;
+  if (!ref3d || !origin || !proj || !ref_cam || !mask) return fail(SGC_EINVAL, "null pointer");
+  const float eps = 1e-5f;
+  const float rw = 1.0f / img_w, rh = 1.0f / img_h, rd = 1.0f / (d_far - d_near);
+  const float hi = 1.0f - eps;
+  for (int n = 0; n < N; ++n) {
+    const float *Pm = proj + (int64_t)n * 12;
+    for (int q = 0; q < Nq; ++q) {
+      const float x = ref3d[q * 3] + origin[0], y = ref3d[q * 3 + 1] + origin[1], z = ref3d[q * 3 + 2] + origin[2];
+      float cam[3];
+      for (int r = 0; r < 3; ++r) cam[r] = ((Pm[r * 4] * x + Pm[r * 4 + 1] * y) + Pm[r * 4 + 2] * z) + Pm[r * 4 + 3];
+      const float den = fmaxf(cam[2], eps);
+      const float u = (cam[0] / den) * rw, v = (cam[1] / den) * rh;
+      const float zn = (cam[2] - d_near) * rd;
+      float *o = ref_cam + ((int64_t)n * Nq + q) * 3;
+      o[0] = u; o[1] = v; o[2] = zn;
+      mask[(int64_t)n * Nq + q] = (uint8_t)(cam[2] > eps && u > eps && u < hi && v > eps && v < hi);
+    }
+  }
+  return SGC_OK;
+}
+
+int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
+                      int32_t *cam_count, int32_t *cam_offset,
+                      int32_t *pair_cam, int32_t *pair_q, int32_t *slot,
+                      int32_t *vox_count, int32_t *valid_index, int32_t *totals,
+                      int32_t *workspace, sgc_stream_t stream) {
+  (void)stream; (void)workspace;
+  if (!mask || !cam_count || !cam_offset || !pair_cam || !pair_q || !slot || !vox_count || !valid_index || !totals)
+    return fail(SGC_EINVAL, "null pointer");
+  int32_t np = 0, max_len = 0;
+  for (int q = 0; q < Nq; ++q) vox_count[q] = 0;
+  for (int n = 0; n < N; ++n) { /* indexes[i] = nonzero(mask_i), TU/deformable_cross_attention.py:759-762 */
+    cam_offset[n] = np;
+    int32_t c = 0;
+    for (int q = 0; q < Nq; ++q) {
+      if (mask[(int64_t)n * Nq + q]) {
+        pair_cam[np] = n; pair_q[np] = q; slot[(int64_t)n * Nq + q] = np;
+        ++np; ++c; ++vox_count[q];
+      } else {
+        slot[(int64_t)n * Nq + q] = -1;
+      }
+    }
+    cam_count[n] = c;
+    if (c > max_len) max_len = c;
+  }
+  cam_offset[N] = np;
+  int32_t nv = 0; /* valid_index = count.nonzero(), :822 */
+  for (int q = 0; q < Nq; ++q)
+    if (vox_count[q] > 0) valid_index[nv++] = q;
+  totals[0] = np; totals[1] = nv; totals[2] = max_len; totals[3] = 0;
+  return SGC_OK;
+}
+
+/* ---- 4. pair-list gathers ---------------------------------------------------- */
+int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
+                              const int32_t *pair_cam, const int32_t *pair_q,
+                              const int32_t *totals, float *out,
+                              int N, int Nq, int H, int W, int C, int D,
+                              int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  (void)stream; (void)N;
+  if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
+  int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);
+  if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
+  const int64_t S = (int64_t)H * W;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < np; ++i) {
+    const int n = pair_cam[i], q = pair_q[i];
+    const float *r = ref_cam + ((int64_t)n * Nq + q) * 3;
+    float s[4];
+    depth_score_sample(dist + n * S * D, D, 0, H, W, D, r[0], r[1], r[2], s);
+    const float h_im = r[1] * H - 0.5f, w_im = r[0] * W - 0.5f;
+    float *o = out + (int64_t)i * C;
+    const int in = (h_im > -1 && w_im > -1 && h_im < H && w_im < W);
+    for (int c = 0; c < C; ++c) {
+      float col = 0.f;
+      if (in) col += wms_bilinear(feat + n * S * C, H, W, C, c, h_im, w_im, s) * 1.0f;
+      o[c] = col;
+    }
+  }
+  return SGC_OK;
+}
+
+int sgc_pairs_deform_gather(const float *value, const float *dist, const float *ref_cam,
+                            const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
+                            const int32_t *totals, float *out,
+                            int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                            int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  (void)stream; (void)N;
+  if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
+  if (P > 64) return fail(SGC_EUNSUP, "P > 64");
+  int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);
+  if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
+  const int64_t S = (int64_t)H * W;
+  const int MC = M * Cm, MP = M * P;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < np; ++i) {
+    const int n = pair_cam[i], q = pair_q[i];
+    const float *r = ref_cam + ((int64_t)n * Nq + q) * 3;
+    const float *rw = raw + (int64_t)i * MP * 4;
+    for (int m = 0; m < M; ++m) {
+      /* softmax over the L*P logits of this head (TU/deformable_cross_attention.py:428-431) */
+      const float *lg = rw + MP * 3 + m * P;
+      float mx = lg[0];
+      for (int p = 1; p < P; ++p) mx = fmaxf(mx, lg[p]);
+      float e[64], sum = 0.f;
+      for (int p = 0; p < P; ++p) { e[p] = expf(lg[p] - mx); sum += e[p]; }
+      float *o = out + (int64_t)i * MC + m * Cm;
+      for (int c = 0; c < Cm; ++c) o[c] = 0.f;
+      for (int p = 0; p < P; ++p) {
+        /* loc = ref + offset / (W, H, D), :445-455 */
+        const float x = r[0] + rw[(m * P + p) * 2] / (float)W;
+        const float y = r[1] + rw[(m * P + p) * 2 + 1] / (float)H;
+        const float z = r[2] + rw[MP * 2 + m * P + p] / (float)D;
+        const float aw = e[p] / sum;
+        float s[4];
+        depth_score_sample(dist + n * S * D, D, 0, H, W, D, x, y, z, s);
+        const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+        if (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+          for (int c = 0; c < Cm; ++c)
+            o[c] += wms_bilinear(value + n * S * MC, H, W, MC, m * Cm + c, h_im, w_im, s) * aw;
+      }
+    }
+  }
+  return SGC_OK;
+}
+
+/* ---- 5. inter-view aggregation ---------------------------------------------- */
+int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
+                  float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream) {
+  (void)stream;
+  if (!feat || !slot || !valid_index || !mean) return fail(SGC_EINVAL, "null pointer");
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_valid; ++i) {
+    const int q = valid_index[i];
+    float *o = mean + (int64_t)i * C;
+    for (int c = 0; c < C; ++c) o[c] = 0.f;
+    int cnt = 0;
+    for (int n = 0; n < N; ++n) { /* (valid_slots * valid_mask).sum(dim=0), :826 */
+      const int32_t p = slot[(int64_t)n * Nq + q];
+      if (p < 0) continue;
+      ++cnt;
+      for (int c = 0; c < C; ++c) o[c] += feat[(int64_t)p * C + c];
+    }
+    for (int c = 0; c < C; ++c) o[c] /= (float)cnt;
+  }
+  return SGC_OK;
+}
+
+int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
+                    const int32_t *valid_index, float *ctx,
+                    int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+  (void)stream;
+  if (!q || !kv || !slot || !valid_index || !ctx) return fail(SGC_EINVAL, "null pointer");
+  if (C % heads) return fail(SGC_EINVAL, "C % heads != 0");
+  const int hd = C / heads;
+  const float scale = sqrtf(1.0f / (float)hd); /* torch MHA: q * sqrt(1/head_dim) */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_valid; ++i) {
+    const int vq = valid_index[i];
+    for (int h = 0; h < heads; ++h) {
+      const float *qh = q + (int64_t)i * C + h * hd;
+      float mx = -INFINITY;
+      for (int n = 0; n < N; ++n) {
+        const int32_t p = slot[(int64_t)n * Nq + vq];
+        if (p < 0) continue;
+        const float *k = kv + (int64_t)p * 2 * C + h * hd;
+        float d = 0.f;
+        for (int c = 0; c < hd; ++c) d += (qh[c] * scale) * k[c];
+        if (d > mx) mx = d;
+      }
+      float sum = 0.f;
+      float *o = ctx + (int64_t)i * C + h * hd;
+      for (int c = 0; c < hd; ++c) o[c] = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const int32_t p = slot[(int64_t)n * Nq + vq];
+        if (p < 0) continue;
+        const float *k = kv + (int64_t)p * 2 * C + h * hd;
+        const float *v = k + C;
+        float d = 0.f;
+        for (int c = 0; c < hd; ++c) d += (qh[c] * scale) * k[c];
+        const float e = expf(d - mx);
+        sum += e;
+        for (int c = 0; c < hd; ++c) o[c] += e * v[c];
+      }
+      for (int c = 0; c < hd; ++c) o[c] /= sum;
+    }
+  }
+  return SGC_OK;
+}
+
+/* ---- 6. volume glue ------------------------------------------------------------ */
+int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
+                     float *vol, int n, int C, sgc_stream_t stream) {
+  (void)stream;
+  if (!rows || !idx || !vol) return fail(SGC_EINVAL, "null pointer");
+  for (int i = 0; i < n; ++i) {
+    int64_t d = idx[i];
+    if (idx2_or_null) d = idx2_or_null[d];
+    memcpy(vol + d * C, rows + (int64_t)i * C, sizeof(float) * C);
+  }
+  return SGC_OK;
+}
+
+int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
+                          int H, int W, sgc_stream_t stream) {
+  (void)stream;
+  if (!src || !dst) return fail(SGC_EINVAL, "null pointer");
+  if (H > Hs || W > Ws) return fail(SGC_EINVAL, "crop larger than source");
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w)
+          dst[(((int64_t)n * H + h) * W + w) * C + c] = src[(((int64_t)n * C + c) * Hs + h) * Ws + w];
+  return SGC_OK;
+}

@@ -1,0 +1,85 @@
+"""ctypes description of the C ABI declared in ``include/sgcdet_amd.h``.
+
+One table drives every binding of that header: the product library
+(``sgcdet_amd/csrc/libsgcdet_amd.so``, HIP/gfx950) and -- from the test side
+only -- the CPU oracle that exports the same symbols.  Nothing here touches
+torch; pointers are plain integers (``tensor.data_ptr()``).
+"""
+import ctypes as C
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> argtypes (restype is int for all but the three introspection calls)
+SIGNATURES = {
+    "sgc_depth_score_forward": [_p, _p, _p, _p, _p] + [_i] * 7 + [_p],
+    "sgc_wms_forward": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p],
+    "sgc_wms_backward": [_p] * 11 + [_i] * 7 + [_p],
+    "sgc_depth_score_backward": [_p] * 7 + [_i] * 7 + [_p],
+    "sgc_dfa3d_forward": [_p] * 8 + [_i] * 9 + [_p],
+    "sgc_dfa3d_backward": [_p] * 11 + [_i] * 9 + [_p],
+    "sgc_project_points": [_p] * 5 + [_i, _i, _f, _f, _f, _f, _p],
+    "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
+    "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 8 + [_p],
+    "sgc_pairs_deform_gather": [_p] * 8 + [_i] * 10 + [_p],
+    "sgc_view_mean": [_p] * 4 + [_i] * 4 + [_p],
+    "sgc_view_attend": [_p] * 5 + [_i] * 5 + [_p],
+    "sgc_scatter_rows": [_p] * 4 + [_i, _i, _p],
+    "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
+}
+
+INTROSPECTION = {
+    "sgc_abi_version": (C.c_int, []),
+    "sgc_last_error": (C.c_char_p, []),
+    "sgc_backend": (C.c_char_p, []),
+}
+
+ABI_VERSION = 1
+
+
+class SgcError(RuntimeError):
+    """Raised when an entry point returns a negative status."""
+
+
+class Library:
+    """A loaded shared object exporting the sgcdet_amd C ABI."""
+
+    def __init__(self, path):
+        self.path = str(path)
+        self._dll = C.CDLL(self.path)
+        missing = []
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        for name, (res, argtypes) in INTROSPECTION.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = res
+        if missing:
+            raise ImportError(f"{self.path} does not export: {', '.join(missing)}")
+        if self._dll.sgc_abi_version() != ABI_VERSION:
+            raise ImportError(
+                f"{self.path}: ABI version {self._dll.sgc_abi_version()} != {ABI_VERSION}")
+
+    @property
+    def backend(self):
+        return self._dll.sgc_backend().decode()
+
+    def last_error(self):
+        return self._dll.sgc_last_error().decode()
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise SgcError(f"{name} failed with status {rc}: {self.last_error()}")
+        return rc

@@ -1,0 +1,272 @@
+"""Tensor-level front end of the C ABI (``include/sgcdet_amd.h``).
+
+``TensorOps`` checks what the reference's C++ entry points check (same device,
+contiguous, dtypes -- csrc/cuda/wms_deform_attn_cuda.cu:220-238,
+csrc/common/pytorch_device_registry.hpp:111-126 -> ``RuntimeError``), allocates
+the outputs the reference allocates (``at::zeros``), and forwards raw pointers
+plus the current HIP stream to the shared library.  torch is only plumbing here:
+device memory and the stream handle.
+
+The same class fronts the CPU oracle in the tests (device_type ``"cpu"``); the
+product instantiates it exactly once, for ``"cuda"``, in ``sgcdet_amd.ext``.
+"""
+import torch
+
+
+def _stream_ptr(device_type):
+    if device_type == "cuda":
+        return torch.cuda.current_stream().cuda_stream
+    return None
+
+
+class TensorOps:
+    def __init__(self, library, device_type):
+        self.lib = library
+        self.device_type = device_type
+
+    # ---- argument checks ------------------------------------------------
+    def _check(self, **tensors):
+        dev = None
+        for name, t in tensors.items():
+            if t is None:
+                continue
+            if not isinstance(t, torch.Tensor):
+                raise RuntimeError(f"{name} must be a tensor")
+            if t.device.type != self.device_type:
+                raise RuntimeError(
+                    f"{name} must be a {self.device_type} tensor for the "
+                    f"'{self.lib.backend}' backend (got {t.device})")
+            if not t.is_contiguous():
+                raise RuntimeError(f"{name} tensor has to be contiguous")
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
+        return dev
+
+    @staticmethod
+    def _f32(**tensors):
+        for name, t in tensors.items():
+            if t is not None and t.dtype != torch.float32:
+                raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+
+    @staticmethod
+    def _i64(**tensors):
+        for name, t in tensors.items():
+            if t.dtype != torch.int64:
+                raise RuntimeError(f"{name} must be int64 (got {t.dtype})")
+
+    @staticmethod
+    def _i32(**tensors):
+        for name, t in tensors.items():
+            if t is not None and t.dtype != torch.int32:
+                raise RuntimeError(f"{name} must be int32 (got {t.dtype})")
+
+    def _call(self, name, *args):
+        ptrs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+        if self.device_type == "cuda":
+            dev = next(a.device for a in args if isinstance(a, torch.Tensor))
+            with torch.cuda.device(dev):
+                return self.lib.call(name, *ptrs, _stream_ptr("cuda"))
+        return self.lib.call(name, *ptrs, None)
+
+    # ---- 1. the four dfa3D._ext operators ----------------------------------
+    def depth_score_forward(self, dist, shapes3, lsi, loc3):
+        self._check(value=dist, value_spatial_shapes=shapes3, value_level_start_index=lsi,
+                    sampling_locations=loc3)
+        self._f32(value=dist, sampling_locations=loc3)
+        self._i64(value_spatial_shapes=shapes3, value_level_start_index=lsi)
+        B, S, M, D = dist.shape
+        _, Q, M2, L, P, three = loc3.shape
+        if M2 != M or three != 3 or shapes3.shape != (L, 3) or loc3.shape[0] != B:
+            raise RuntimeError("ms_depth_score_sample_forward: inconsistent shapes")
+        score = torch.empty((B, Q, M, L, P, 4), dtype=dist.dtype, device=dist.device)
+        self._call("sgc_depth_score_forward", dist, shapes3, lsi, loc3, score, B, S, M, D, L, Q, P)
+        return score
+
+    def wms_forward(self, value, shapes2, lsi, loc2, attn, score):
+        self._check(value=value, value_spatial_shapes=shapes2, value_level_start_index=lsi,
+                    sampling_locations=loc2, attention_weights=attn, depth_scores=score)
+        self._f32(value=value, sampling_locations=loc2, attention_weights=attn, depth_scores=score)
+        self._i64(value_spatial_shapes=shapes2, value_level_start_index=lsi)
+        B, S, M, Cm = value.shape
+        _, Q, _, L, P, two = loc2.shape
+        if two != 2 or shapes2.shape != (L, 2) or attn.shape != (B, Q, M, L, P) \
+                or score.shape != (B, Q, M, L, P, 4):
+            raise RuntimeError("wms_deform_attn_forward: inconsistent shapes")
+        out = torch.empty((B, Q, M * Cm), dtype=value.dtype, device=value.device)
+        self._call("sgc_wms_forward", value, shapes2, lsi, loc2, attn, score, out, B, S, M, Cm, L, Q, P)
+        return out
+
+    def wms_backward(self, value, shapes2, lsi, loc2, attn, score, grad_out,
+                     grad_value, grad_loc2, grad_attn, grad_score):
+        self._check(value=value, value_spatial_shapes=shapes2, value_level_start_index=lsi,
+                    sampling_locations=loc2, attention_weights=attn, depth_scores=score,
+                    grad_output=grad_out, grad_value=grad_value, grad_sampling_loc=grad_loc2,
+                    grad_attn_weight=grad_attn, grad_depth_score=grad_score)
+        self._f32(value=value, sampling_locations=loc2, attention_weights=attn, depth_scores=score,
+                  grad_output=grad_out, grad_value=grad_value, grad_sampling_loc=grad_loc2,
+                  grad_attn_weight=grad_attn, grad_depth_score=grad_score)
+        self._i64(value_spatial_shapes=shapes2, value_level_start_index=lsi)
+        B, S, M, Cm = value.shape
+        _, Q, _, L, P, _ = loc2.shape
+        self._call("sgc_wms_backward", value, shapes2, lsi, loc2, attn, score, grad_out, grad_value,
+                   grad_loc2, grad_attn, grad_score, B, S, M, Cm, L, Q, P)
+
+    def depth_score_backward(self, dist, shapes3, lsi, loc3, grad_score, grad_dist, grad_loc3):
+        self._check(value=dist, value_spatial_shapes=shapes3, value_level_start_index=lsi,
+                    sampling_locations=loc3, grad_output=grad_score, grad_value=grad_dist,
+                    grad_sampling_loc=grad_loc3)
+        self._f32(value=dist, sampling_locations=loc3, grad_output=grad_score, grad_value=grad_dist,
+                  grad_sampling_loc=grad_loc3)
+        self._i64(value_spatial_shapes=shapes3, value_level_start_index=lsi)
+        B, S, M, D = dist.shape
+        _, Q, _, L, P, _ = loc3.shape
+        self._call("sgc_depth_score_backward", dist, shapes3, lsi, loc3, grad_score, grad_dist,
+                   grad_loc3, B, S, M, D, L, Q, P)
+
+    # ---- 2. fused forms ---------------------------------------------------
+    def dfa3d_forward(self, value, dist, shapes3, lsi, loc3, attn=None, want_score=False):
+        self._check(value=value, value_dpt_dist=dist, value_spatial_shapes=shapes3,
+                    value_level_start_index=lsi, sampling_locations=loc3, attention_weights=attn)
+        self._f32(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn)
+        self._i64(value_spatial_shapes=shapes3, value_level_start_index=lsi)
+        B, S, M, Cm = value.shape
+        dist_heads, D = dist.shape[2], dist.shape[3]
+        _, Q, _, L, P, _ = loc3.shape
+        if dist.shape[:2] != (B, S) or dist_heads not in (1, M) or loc3.shape[2] != M:
+            raise RuntimeError("dfa3d_forward: inconsistent shapes")
+        out = torch.empty((B, Q, M * Cm), dtype=value.dtype, device=value.device)
+        score = torch.empty((B, Q, M, L, P, 4), dtype=value.dtype, device=value.device) if want_score else None
+        self._call("sgc_dfa3d_forward", value, dist, shapes3, lsi, loc3, attn, out, score,
+                   B, S, M, Cm, D, dist_heads, L, Q, P)
+        return out, score
+
+    def dfa3d_backward(self, value, dist, shapes3, lsi, loc3, attn, grad_out, want_grad_attn=True):
+        self._check(value=value, value_dpt_dist=dist, value_spatial_shapes=shapes3,
+                    value_level_start_index=lsi, sampling_locations=loc3, attention_weights=attn,
+                    grad_output=grad_out)
+        self._f32(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn,
+                  grad_output=grad_out)
+        B, S, M, Cm = value.shape
+        dist_heads, D = dist.shape[2], dist.shape[3]
+        _, Q, _, L, P, _ = loc3.shape
+        grad_value = torch.zeros_like(value)
+        grad_dist = torch.zeros_like(dist)
+        grad_loc3 = torch.empty_like(loc3)
+        grad_attn = torch.empty((B, Q, M, L, P), dtype=value.dtype, device=value.device) \
+            if want_grad_attn else None
+        self._call("sgc_dfa3d_backward", value, dist, shapes3, lsi, loc3, attn, grad_out, grad_value,
+                   grad_dist, grad_loc3, grad_attn, B, S, M, Cm, D, dist_heads, L, Q, P)
+        return grad_value, grad_dist, grad_loc3, grad_attn
+
+    # ---- 3. projection + compaction ---------------------------------------
+    def project_points(self, ref3d, origin, proj, img_w, img_h, d_near, d_far):
+        self._check(ref3d=ref3d, origin=origin, proj=proj)
+        self._f32(ref3d=ref3d, origin=origin, proj=proj)
+        N, Nq = proj.shape[0], ref3d.shape[0]
+        if proj.shape[1:] != (3, 4) or ref3d.shape[1] != 3 or origin.numel() != 3:
+            raise RuntimeError("project_points: inconsistent shapes")
+        ref_cam = torch.empty((N, Nq, 3), dtype=torch.float32, device=ref3d.device)
+        mask = torch.empty((N, Nq), dtype=torch.uint8, device=ref3d.device)
+        self._call("sgc_project_points", ref3d, origin, proj, ref_cam, mask, N, Nq,
+                   float(img_w), float(img_h), float(d_near), float(d_far))
+        return ref_cam, mask
+
+    def compact_pairs(self, mask, cap=None):
+        """Returns a dict of int32 tensors; ``totals`` stays on the device."""
+        self._check(mask=mask)
+        if mask.dtype != torch.uint8:
+            raise RuntimeError("mask must be uint8")
+        N, Nq = mask.shape
+        cap = N * Nq if cap is None else cap
+        dev = mask.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        out = dict(
+            cam_count=torch.empty(N, **i32), cam_offset=torch.empty(N + 1, **i32),
+            pair_cam=torch.empty(cap, **i32), pair_q=torch.empty(cap, **i32),
+            slot=torch.empty((N, Nq), **i32), vox_count=torch.empty(Nq, **i32),
+            valid_index=torch.empty(Nq, **i32), totals=torch.empty(4, **i32))
+        ws = torch.empty(N * Nq + Nq + 2 * N + 64, **i32)
+        self._call("sgc_compact_pairs", mask, N, Nq, out["cam_count"], out["cam_offset"],
+                   out["pair_cam"], out["pair_q"], out["slot"], out["vox_count"],
+                   out["valid_index"], out["totals"], ws)
+        return out
+
+    # ---- 4. pair-list gathers ------------------------------------------------
+    def pairs_geometry_sample(self, feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=None):
+        self._check(feat=feat, dist=dist, ref_cam=ref_cam, pair_cam=pair_cam, pair_q=pair_q, totals=totals)
+        self._f32(feat=feat, dist=dist, ref_cam=ref_cam)
+        self._i32(pair_cam=pair_cam, pair_q=pair_q, totals=totals)
+        N, S, Cc = feat.shape
+        D = dist.shape[-1]
+        Nq = ref_cam.shape[1]
+        if S != H * W or dist.shape[:2] != (N, S) or ref_cam.shape != (N, Nq, 3):
+            raise RuntimeError("pairs_geometry_sample: inconsistent shapes")
+        cap = pair_cam.numel()
+        rows = n_pairs if n_pairs >= 0 else cap
+        out = torch.empty((rows, Cc), dtype=torch.float32, device=feat.device)
+        self._call("sgc_pairs_geometry_sample", feat, dist, ref_cam, pair_cam, pair_q, totals, out,
+                   N, Nq, H, W, Cc, D, n_pairs, cap)
+        return out
+
+    def pairs_deform_gather(self, value, dist, ref_cam, raw, pair_cam, pair_q, n_pairs, H, W, M, P,
+                            totals=None):
+        self._check(value=value, dist=dist, ref_cam=ref_cam, raw=raw, pair_cam=pair_cam,
+                    pair_q=pair_q, totals=totals)
+        self._f32(value=value, dist=dist, ref_cam=ref_cam, raw=raw)
+        self._i32(pair_cam=pair_cam, pair_q=pair_q, totals=totals)
+        N, S, Cc = value.shape[0], value.shape[1], value.shape[-1] * (value.shape[2] if value.dim() == 4 else 1)
+        Cm = Cc // M
+        D = dist.shape[-1]
+        Nq = ref_cam.shape[1]
+        cap = pair_cam.numel()
+        rows = n_pairs if n_pairs >= 0 else cap
+        if S != H * W or raw.shape[-1] != M * P * 4 or raw.shape[0] < rows:
+            raise RuntimeError("pairs_deform_gather: inconsistent shapes")
+        out = torch.empty((rows, Cc), dtype=torch.float32, device=value.device)
+        self._call("sgc_pairs_deform_gather", value, dist, ref_cam, raw, pair_cam, pair_q, totals, out,
+                   N, Nq, H, W, M, Cm, D, P, n_pairs, cap)
+        return out
+
+    # ---- 5. inter-view aggregation ------------------------------------------
+    def view_mean(self, feat, slot, valid_index, n_valid):
+        self._check(feat=feat, slot=slot, valid_index=valid_index)
+        self._f32(feat=feat)
+        self._i32(slot=slot, valid_index=valid_index)
+        N, Nq = slot.shape
+        Cc = feat.shape[1]
+        mean = torch.empty((n_valid, Cc), dtype=torch.float32, device=feat.device)
+        self._call("sgc_view_mean", feat, slot, valid_index, mean, N, Nq, Cc, n_valid)
+        return mean
+
+    def view_attend(self, q, kv, slot, valid_index, heads):
+        self._check(q=q, kv=kv, slot=slot, valid_index=valid_index)
+        self._f32(q=q, kv=kv)
+        self._i32(slot=slot, valid_index=valid_index)
+        N, Nq = slot.shape
+        n_valid, Cc = q.shape
+        if kv.shape[1] != 2 * Cc:
+            raise RuntimeError("view_attend: kv must be [n_pairs, 2C]")
+        ctx = torch.empty_like(q)
+        self._call("sgc_view_attend", q, kv, slot, valid_index, ctx, N, Nq, Cc, heads, n_valid)
+        return ctx
+
+    # ---- 6. volume glue --------------------------------------------------------
+    def scatter_rows(self, rows, idx, vol, idx2=None):
+        self._check(rows=rows, idx=idx, vol=vol, idx2=idx2)
+        self._f32(rows=rows, vol=vol)
+        self._i32(idx=idx, idx2=idx2)
+        n, Cc = rows.shape
+        if vol.shape[-1] != Cc:
+            raise RuntimeError("scatter_rows: channel mismatch")
+        self._call("sgc_scatter_rows", rows, idx, idx2, vol, n, Cc)
+        return vol
+
+    def nchw_to_nhwc_crop(self, src, H, W):
+        self._check(src=src)
+        self._f32(src=src)
+        N, Cc, Hs, Ws = src.shape
+        dst = torch.empty((N, H * W, Cc), dtype=torch.float32, device=src.device)
+        self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W)
+        return dst
