@@ -1,0 +1,88 @@
+// Shared helpers of the gfx950 library (include/sgcdet_amd.h).  CDNA4 only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sgcdet_amd.h"
+
+namespace sgc {
+
+constexpr int kWave = 64;
+constexpr int kXcd = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
+
+int set_error(int code, const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SGC_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return SGC_OK;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware, bijective block -> tile map: the blocks that share an XCD (equal
+// blockIdx % 8 under round-robin dispatch) walk one contiguous chunk of the tile
+// range, so tiles that touch the same camera's maps meet in one 4 MiB L2.  Placement
+// is a speed assumption only; any dispatch order gives the same results.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
+  const int x = bid % kXcd, j = bid / kXcd;
+  const int base = ntiles / kXcd, rem = ntiles % kXcd;
+  return x * base + (x < rem ? x : rem) + j;
+}
+
+// One trilinear sample of the DFA3D operator, reduced to what the gather needs:
+// 4 corner weights (bilinear * depth score * attention weight) and 4 pixel indices
+// (-1 = corner outside the map).  Semantics: ms_depth_score_sample_cuda_kernel.cuh:24-148
+// and wms_deform_attn_cuda_kernel.cuh:24-80,286-294 of the reference.
+struct Sample {
+  float w[4];   // order: (h0,w0) (h0,w1) (h1,w0) (h1,w1)
+  int off[4];   // pixel index inside the level (h*W + w), -1 if outside
+  float s[4];   // depth scores in the REFERENCE order (h0,w0) (h0,w1) (h1,w1) (h1,w0)
+  // pieces the backward needs
+  float lh, lw, ld;
+  int d0;
+  bool in2, in3;
+};
+
+__device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict__ dist_px0,
+                                            int64_t pix_stride, int H, int W, int D,
+                                            float x, float y, float z, float aw) {
+  const float h_im = y * (float)H - 0.5f;
+  const float w_im = x * (float)W - 0.5f;
+  const float d_im = z * (float)D - 0.5f;
+  sm.in2 = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  sm.in3 = sm.in2 && d_im > -1.f && d_im < (float)D;
+  const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);
+  const int h0 = (int)hf, w0 = (int)wf, d0 = (int)df;
+  const int h1 = h0 + 1, w1 = w0 + 1, d1 = d0 + 1;
+  sm.lh = h_im - hf;
+  sm.lw = w_im - wf;
+  sm.ld = d_im - df;
+  sm.d0 = d0;
+  const float hh = 1.f - sm.lh, hw = 1.f - sm.lw, hd = 1.f - sm.ld;
+  const bool okh0 = h0 >= 0, okh1 = h1 <= H - 1, okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+  const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+  const int px[4] = {h0 * W + w0, h0 * W + w1, h1 * W + w0, h1 * W + w1};
+  float sc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool use = sm.in2 && ok[k];
+    sm.off[k] = use ? px[k] : -1;
+    float v = 0.f;
+    if (sm.in3 && ok[k]) {
+      const float *p = dist_px0 + (int64_t)px[k] * pix_stride;
+      const float va = d0 >= 0 ? p[d0] : 0.f;
+      const float vb = d1 <= D - 1 ? p[d1] : 0.f;
+      v = va * hd + vb * sm.ld;
+    }
+    sc[k] = v;
+  }
+  sm.s[0] = sc[0]; sm.s[1] = sc[1]; sm.s[2] = sc[3]; sm.s[3] = sc[2];
+  sm.w[0] = sm.in2 ? hh * hw * sc[0] * aw : 0.f;
+  sm.w[1] = sm.in2 ? hh * sm.lw * sc[1] * aw : 0.f;
+  sm.w[2] = sm.in2 ? sm.lh * hw * sc[2] * aw : 0.f;
+  sm.w[3] = sm.in2 ? sm.lh * sm.lw * sc[3] * aw : 0.f;
+}
+
+}  // namespace sgc

@@ -1,0 +1,372 @@
+// Fused 3D deformable attention forward for gfx950 (wave64).
+//
+// Replaces the reference's two launches per call (ms_depth_score_sample_forward +
+// wms_deform_attn_forward, TU/multi_scale_3ddeformable_attn_function.py:285-299) and the
+// [B,Q,M,L,P,4] depth-score round trip through HBM by ONE kernel built in two phases
+// per tile of TP items (an item = one (camera, query)):
+//
+//   phase 1  one lane per SAMPLE (item, head, level, point): reads its location /
+//            attention weight (or the raw Linear outputs, with the softmax over the
+//            points done by wave shuffles), evaluates the depth score from the
+//            un-replicated depth map, and leaves a 32-byte descriptor in LDS:
+//            4 corner weights (bilinear x depth score x attention) + 4 pixel indices.
+//            No lane repeats another lane's scalar work (the reference re-reads the
+//            same loc/attn/4 scores in every one of its Cm channel threads).
+//   phase 2  one lane per 4 CHANNELS of a head: reads descriptors (LDS broadcast),
+//            gathers the corner rows as float4 (a wave covers M*Cm*4 B of contiguous
+//            channels-last row per corner) and accumulates in registers.
+//
+// Tiles are dealt to XCDs in contiguous chunks (common.hpp: xcd_tile) because items are
+// camera-major: neighbouring tiles hit the same camera's value map in one L2.
+#include "common.hpp"
+
+namespace sgc {
+
+enum Mode { kBatch = 0, kPairsDeform = 1, kPairsGeom = 2 };
+
+struct FwdParams {
+  // maps
+  const float *value;       // [B,S,M,Cm]
+  const float *dist;        // [B,S,dist_heads,D]
+  const int64_t *shapes3;   // [L,3] (batch mode)  -- device
+  const int64_t *lsi;       // [L]
+  // batch-mode sample source
+  const float *loc3;        // [items,M,L,P,3]
+  const float *attn;        // [items,M,L,P] or null (= 1)
+  // pairs-mode sample source
+  const float *ref_cam;     // [N,Nq,3]
+  const float *raw;         // [pairs, M*P*4]
+  const int32_t *pair_cam, *pair_q, *totals;
+  // outputs
+  float *out;               // [items, M*Cm]
+  float *score;             // optional [items,M,L,P,4]
+  int S, M, Cm, D, dist_heads, L, Q, P, Nq;
+  int H, W;                 // pairs mode (single level)
+  int n_items;              // < 0: read totals[0]
+  int TP;                   // items per tile
+};
+
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int SPI = p.M * p.L * p.P;  // samples per item
+  float4 *lds_w = reinterpret_cast<float4 *>(smem_raw);
+  int4 *lds_o = reinterpret_cast<int4 *>(smem_raw + (size_t)p.TP * SPI * sizeof(float4));
+  int *lds_b = reinterpret_cast<int *>(smem_raw + (size_t)p.TP * SPI * (sizeof(float4) + sizeof(int4)));
+
+  const int n_items = p.n_items >= 0 ? p.n_items : p.totals[0];
+  const int ntiles = (n_items + p.TP - 1) / p.TP;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int item0 = tile * p.TP;
+  const int tid = threadIdx.x;
+  const int MC = p.M * p.Cm;
+
+  // ---------------- phase 1: sample descriptors ----------------
+  const int nsamp = p.TP * SPI;
+  for (int t = tid; t < ((nsamp + kWave - 1) / kWave) * kWave; t += blockDim.x) {
+    const bool in_tile = t < nsamp;
+    const int tt = in_tile ? t : nsamp - 1;
+    const int il = tt / SPI;          // item inside the tile
+    const int r = tt - il * SPI;      // (m, l, p), p fastest
+    int item = item0 + il;
+    const bool live = in_tile && item < n_items;
+    if (item >= n_items) item = n_items - 1;
+    const int m = r / (p.L * p.P);
+    const int lp = r - m * (p.L * p.P);
+    const int l = lp / p.P;
+    const int pt = lp - l * p.P;
+
+    int b, H, W, D, lvl0;
+    float x, y, z, aw;
+    if (MODE == kBatch) {
+      b = item / p.Q;
+      H = (int)p.shapes3[l * 3]; W = (int)p.shapes3[l * 3 + 1]; D = (int)p.shapes3[l * 3 + 2];
+      lvl0 = (int)p.lsi[l];
+      const int64_t g = (int64_t)item * SPI + r;
+      x = p.loc3[g * 3]; y = p.loc3[g * 3 + 1]; z = p.loc3[g * 3 + 2];
+      aw = p.attn ? p.attn[g] : 1.f;
+    } else {
+      b = p.pair_cam[item];
+      const int q = p.pair_q[item];
+      H = p.H; W = p.W; D = p.D; lvl0 = 0;
+      const float *rc = p.ref_cam + ((int64_t)b * p.Nq + q) * 3;
+      x = rc[0]; y = rc[1]; z = rc[2];
+      aw = 1.f;
+      if (MODE == kPairsDeform) {
+        const int MP = p.M * p.P;
+        const float *rw = p.raw + (int64_t)item * MP * 4;
+        const int mp = m * p.P + pt;
+        // loc = ref + offset / (W,H,D): TU/deformable_cross_attention.py:445-455 (IEEE division)
+        x = x + rw[mp * 2] / (float)W;
+        y = y + rw[mp * 2 + 1] / (float)H;
+        z = z + rw[MP * 2 + mp] / (float)D;
+        // softmax over the P points of this head (:428-431): the P lanes are adjacent
+        const float lg = rw[MP * 3 + mp];
+        float mx = lg;
+        for (int o = 1; o < p.P; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = expf(lg - mx);
+        float sum = e;
+        for (int o = 1; o < p.P; o <<= 1) sum += __shfl_xor(sum, o);
+        aw = e / sum;
+      }
+    }
+    const int dh = p.dist_heads == 1 ? 0 : m;
+    const float *dpx = p.dist + (((int64_t)b * p.S + lvl0) * p.dist_heads + dh) * p.D;
+    Sample sm;
+    make_sample(sm, dpx, (int64_t)p.dist_heads * p.D, H, W, D, x, y, z, aw);
+    if (in_tile) {
+      lds_w[tt] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
+      lds_o[tt] = make_int4(sm.off[0] < 0 ? -1 : sm.off[0] + lvl0, sm.off[1] < 0 ? -1 : sm.off[1] + lvl0,
+                            sm.off[2] < 0 ? -1 : sm.off[2] + lvl0, sm.off[3] < 0 ? -1 : sm.off[3] + lvl0);
+      if (r == 0) lds_b[il] = b;
+      if (live && p.score)
+        reinterpret_cast<float4 *>(p.score)[(int64_t)item * SPI + r] =
+            make_float4(sm.s[0], sm.s[1], sm.s[2], sm.s[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: row gather ----------------
+  const int CV = p.Cm / VEC;   // lanes per head
+  const int LPI = p.M * CV;    // lanes per item
+  const int LP = p.L * p.P;
+  for (int idx = tid; idx < p.TP * LPI; idx += blockDim.x) {
+    const int il = idx / LPI;
+    const int item = item0 + il;
+    if (item >= n_items) break;
+    const int r = idx - il * LPI;
+    const int m = r / CV;
+    const int c0 = (r - m * CV) * VEC;
+    const float *vbase = p.value + (int64_t)lds_b[il] * p.S * MC + m * p.Cm + c0;
+    const int d0 = il * SPI + m * LP;
+    if (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < LP; ++s) {
+        const float4 w = lds_w[d0 + s];
+        const int4 o = lds_o[d0 + s];
+        const float wk[4] = {w.x, w.y, w.z, w.w};
+        const int ok[4] = {o.x, o.y, o.z, o.w};
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = ok[k] >= 0 ? *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc.x += wk[k] * v[k].x; acc.y += wk[k] * v[k].y;
+          acc.z += wk[k] * v[k].z; acc.w += wk[k] * v[k].w;
+        }
+      }
+      *reinterpret_cast<float4 *>(p.out + (int64_t)item * MC + m * p.Cm + c0) = acc;
+    } else {
+      float acc = 0.f;
+      for (int s = 0; s < LP; ++s) {
+        const float4 w = lds_w[d0 + s];
+        const int4 o = lds_o[d0 + s];
+        const float wk[4] = {w.x, w.y, w.z, w.w};
+        const int ok[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ok[k] >= 0) acc += wk[k] * vbase[(int64_t)ok[k] * MC];
+      }
+      p.out[(int64_t)item * MC + m * p.Cm + c0] = acc;
+    }
+  }
+}
+
+static int pick_tp(int SPI, int LPI) {
+  // enough samples to occupy the block in phase 1, bounded LDS (<= 32 KiB of descriptors)
+  int tp = 256 / (SPI > 0 ? SPI : 1);
+  if (tp < 1) tp = 1;
+  if (SPI <= 2 && tp > 32) tp = 32;
+  while (tp > 1 && (int64_t)tp * SPI * 32 > 32768) tp >>= 1;
+  (void)LPI;
+  return tp;
+}
+
+template <int MODE>
+static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
+  const int SPI = p.M * p.L * p.P;
+  const bool vec4 = (p.Cm % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.value) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+  p.TP = pick_tp(SPI, p.M * p.Cm / (vec4 ? 4 : 1));
+  if ((int64_t)SPI * 32 > 60000) return set_error(SGC_EUNSUP, "M*L*P = %d samples per query exceed the LDS tile", SPI);
+  const size_t smem = (size_t)p.TP * SPI * 32 + (size_t)p.TP * sizeof(int);
+  const int grid = ceil_div(grid_items, p.TP);
+  if (grid <= 0) return SGC_OK;
+  if (vec4)
+    hipLaunchKernelGGL((dfa3d_fwd_kernel<MODE, 4>), dim3(grid), dim3(256), smem, stream, p);
+  else
+    hipLaunchKernelGGL((dfa3d_fwd_kernel<MODE, 1>), dim3(grid), dim3(256), smem, stream, p);
+  return check_launch("dfa3d_fwd_kernel");
+}
+
+// ---- split operators (dfa3D._ext compatibility): one thread per sample / per output ----
+__global__ void depth_score_fwd_kernel(const float *__restrict__ dist, const int64_t *__restrict__ shapes3,
+                                       const int64_t *__restrict__ lsi, const float *__restrict__ loc3,
+                                       float *__restrict__ score, int64_t total, int S, int M, int D,
+                                       int L, int Q, int P) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int pt = (int)(g % P);
+    const int l = (int)((g / P) % L);
+    const int m = (int)((g / ((int64_t)P * L)) % M);
+    const int64_t bq = g / ((int64_t)P * L * M);
+    const int b = (int)(bq / Q);
+    (void)pt;
+    const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
+    const float *dpx = dist + (((int64_t)b * S + lsi[l]) * M + m) * D;
+    Sample sm;
+    make_sample(sm, dpx, (int64_t)M * D, H, W, Dl, loc3[g * 3], loc3[g * 3 + 1], loc3[g * 3 + 2], 1.f);
+    reinterpret_cast<float4 *>(score)[g] = make_float4(sm.s[0], sm.s[1], sm.s[2], sm.s[3]);
+  }
+}
+
+// wms forward with precomputed scores: descriptors are rebuilt from (loc2, attn, score).
+template <int VEC>
+__global__ __launch_bounds__(256) void wms_fwd_kernel(const float *__restrict__ value,
+                                                      const int64_t *__restrict__ shapes2,
+                                                      const int64_t *__restrict__ lsi,
+                                                      const float *__restrict__ loc2,
+                                                      const float *__restrict__ attn,
+                                                      const float *__restrict__ score, float *__restrict__ out,
+                                                      int64_t total, int S, int M, int Cm, int L, int Q, int P) {
+  const int CV = Cm / VEC;
+  const int MC = M * Cm;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(g % CV) * VEC;
+    const int64_t sidx = g / CV;  // (b,q,m)
+    const int m = (int)(sidx % M);
+    const int b = (int)(sidx / M / Q);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes2[l * 2], W = (int)shapes2[l * 2 + 1];
+      const float *vb = value + ((int64_t)b * S + lsi[l]) * MC + m * Cm + c0;
+      for (int pt = 0; pt < P; ++pt) {
+        const int64_t s = (sidx * L + l) * P + pt;
+        const float h_im = loc2[s * 2 + 1] * (float)H - 0.5f, w_im = loc2[s * 2] * (float)W - 0.5f;
+        if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const float4 sc = reinterpret_cast<const float4 *>(score)[s];
+        const float aw = attn[s];
+        const bool ok[4] = {h0 >= 0 && w0 >= 0, h0 >= 0 && w1 <= W - 1, h1 <= H - 1 && w0 >= 0,
+                            h1 <= H - 1 && w1 <= W - 1};
+        const int px[4] = {h0 * W + w0, h0 * W + w1, h1 * W + w0, h1 * W + w1};
+        const float wk[4] = {hh * hw * sc.x, hh * lw * sc.y, lh * hw * sc.w, lh * lw * sc.z};
+        float val[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) val[v] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!ok[k]) continue;
+          const float *src = vb + (int64_t)px[k] * MC;
+          if (VEC == 4) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(src);
+            val[0] += wk[k] * x4.x; val[1 % VEC] += wk[k] * x4.y; val[2 % VEC] += wk[k] * x4.z; val[3 % VEC] += wk[k] * x4.w;
+          } else {
+            val[0] += wk[k] * src[0];
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += val[v] * aw;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) out[sidx * Cm + c0 + v] = acc[v];
+  }
+}
+
+}  // namespace sgc
+
+using namespace sgc;
+
+extern "C" int sgc_dfa3d_forward(const float *value, const float *dist, const int64_t *shapes3,
+                                 const int64_t *lsi, const float *loc3, const float *attn,
+                                 float *out, float *score_or_null,
+                                 int B, int S, int M, int Cm, int D, int dist_heads,
+                                 int L, int Q, int P, sgc_stream_t stream) {
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !out) return set_error(SGC_EINVAL, "sgc_dfa3d_forward: null pointer");
+  if (B < 0 || S <= 0 || M <= 0 || Cm <= 0 || D <= 0 || L <= 0 || Q < 0 || P <= 0)
+    return set_error(SGC_EINVAL, "sgc_dfa3d_forward: non-positive size");
+  if (dist_heads != 1 && dist_heads != M) return set_error(SGC_EINVAL, "sgc_dfa3d_forward: dist_heads must be 1 or M");
+  if ((int64_t)B * Q >= (1ll << 31)) return set_error(SGC_EUNSUP, "sgc_dfa3d_forward: B*Q >= 2^31");
+  FwdParams p = {};
+  p.value = value; p.dist = dist; p.shapes3 = shapes3; p.lsi = lsi; p.loc3 = loc3; p.attn = attn;
+  p.out = out; p.score = score_or_null;
+  p.S = S; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = dist_heads; p.L = L; p.Q = Q; p.P = P;
+  p.n_items = B * Q;
+  return launch_fwd<kBatch>(p, p.n_items, (hipStream_t)stream);
+}
+
+extern "C" int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
+                                         const int32_t *pair_cam, const int32_t *pair_q,
+                                         const int32_t *totals, float *out,
+                                         int N, int Nq, int H, int W, int C, int D,
+                                         int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !out)
+    return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: null pointer");
+  if (n_pairs_or_neg < 0 && !totals) return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: totals required");
+  if (n_pairs_or_neg > cap) return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: n_pairs > cap");
+  if (N <= 0 || Nq <= 0 || H <= 0 || W <= 0 || C <= 0 || D <= 0) return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: bad size");
+  FwdParams p = {};
+  p.value = feat; p.dist = dist; p.ref_cam = ref_cam; p.pair_cam = pair_cam; p.pair_q = pair_q;
+  p.totals = totals; p.out = out;
+  p.S = H * W; p.M = 1; p.Cm = C; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = 1; p.Nq = Nq;
+  p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
+  return launch_fwd<kPairsGeom>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
+}
+
+extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, const float *ref_cam,
+                                       const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
+                                       const int32_t *totals, float *out,
+                                       int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                                       int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out)
+    return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: null pointer");
+  if (n_pairs_or_neg < 0 && !totals) return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: totals required");
+  if (n_pairs_or_neg > cap) return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: n_pairs > cap");
+  if (N <= 0 || Nq <= 0 || H <= 0 || W <= 0 || M <= 0 || Cm <= 0 || D <= 0 || P <= 0)
+    return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: bad size");
+  if (P > 64 || (P & (P - 1)))
+    return set_error(SGC_EUNSUP, "sgc_pairs_deform_gather: P must be a power of two <= 64 (wave-shuffle softmax)");
+  FwdParams p = {};
+  p.value = value; p.dist = dist; p.ref_cam = ref_cam; p.raw = raw; p.pair_cam = pair_cam; p.pair_q = pair_q;
+  p.totals = totals; p.out = out;
+  p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
+  p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
+  return launch_fwd<kPairsDeform>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
+}
+
+extern "C" int sgc_depth_score_forward(const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                                       const float *loc3, float *score,
+                                       int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream) {
+  if (!dist || !shapes3 || !lsi || !loc3 || !score) return set_error(SGC_EINVAL, "sgc_depth_score_forward: null pointer");
+  const int64_t total = (int64_t)B * Q * M * L * P;
+  if (total == 0) return SGC_OK;
+  const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+  hipLaunchKernelGGL(depth_score_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dist, shapes3, lsi,
+                     loc3, score, total, S, M, D, L, Q, P);
+  return check_launch("depth_score_fwd_kernel");
+}
+
+extern "C" int sgc_wms_forward(const float *value, const int64_t *shapes2, const int64_t *lsi,
+                               const float *loc2, const float *attn, const float *score, float *out,
+                               int B, int S, int M, int Cm, int L, int Q, int P, sgc_stream_t stream) {
+  if (!value || !shapes2 || !lsi || !loc2 || !attn || !score || !out)
+    return set_error(SGC_EINVAL, "sgc_wms_forward: null pointer");
+  const bool vec4 = (Cm % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0);
+  const int64_t total = (int64_t)B * Q * M * (Cm / (vec4 ? 4 : 1));
+  if (total == 0) return SGC_OK;
+  const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+  if (vec4)
+    hipLaunchKernelGGL(wms_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, value, shapes2, lsi, loc2,
+                       attn, score, out, total, S, M, Cm, L, Q, P);
+  else
+    hipLaunchKernelGGL(wms_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, value, shapes2, lsi, loc2,
+                       attn, score, out, total, S, M, Cm, L, Q, P);
+  return check_launch("wms_fwd_kernel");
+}

@@ -1,0 +1,222 @@
+// Inter-view aggregation and volume glue for gfx950.
+//
+// The reference scatters per-camera results into dense slots [N,1,Nq,C] (262 MB at
+// config 2), projects K/V for every slot including the invisible ones and masks them
+// with -inf (TU/deformable_cross_attention.py:815-833).  Here the visible (camera, query)
+// pairs stay a compact list; `slot[n,q]` (pair index or -1) is the only dense object.
+#include "common.hpp"
+
+namespace sgc {
+
+// mean over the cameras that see voxel valid_index[i]; C/4 lanes per voxel (float4 rows)
+__global__ __launch_bounds__(256) void view_mean_kernel(const float *__restrict__ feat,
+                                                        const int32_t *__restrict__ slot,
+                                                        const int32_t *__restrict__ valid_index,
+                                                        float *__restrict__ mean, int N, int Nq, int C, int n_valid) {
+  const int C4 = C >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n_valid * C4;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / C4), c4 = (int)(idx - (int64_t)i * C4);
+    const int q = valid_index[i];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int n = 0; n < N; ++n) {
+      const int p = slot[(int64_t)n * Nq + q];
+      if (p < 0) continue;
+      const float4 v = reinterpret_cast<const float4 *>(feat + (int64_t)p * C)[c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      ++cnt;
+    }
+    const float fc = (float)cnt;
+    reinterpret_cast<float4 *>(mean + (int64_t)i * C)[c4] =
+        make_float4(acc.x / fc, acc.y / fc, acc.z / fc, acc.w / fc);
+  }
+}
+
+__global__ void view_mean_scalar_kernel(const float *__restrict__ feat, const int32_t *__restrict__ slot,
+                                        const int32_t *__restrict__ valid_index, float *__restrict__ mean,
+                                        int N, int Nq, int C, int n_valid) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n_valid * C;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / C), c = (int)(idx - (int64_t)i * C);
+    const int q = valid_index[i];
+    float acc = 0.f;
+    int cnt = 0;
+    for (int n = 0; n < N; ++n) {
+      const int p = slot[(int64_t)n * Nq + q];
+      if (p < 0) continue;
+      acc += feat[(int64_t)p * C + c];
+      ++cnt;
+    }
+    mean[idx] = acc / (float)cnt;
+  }
+}
+
+// Softmax over views for query length 1 (nn.MultiheadAttention, :829-833): one group of
+// G = head_dim/VEC lanes per (voxel, head); the dot product is reduced over the group with
+// wave shuffles, the softmax over views runs online (running max / sum) in registers.
+template <int VEC>
+__global__ __launch_bounds__(256) void view_attend_kernel(const float *__restrict__ q,
+                                                          const float *__restrict__ kv,
+                                                          const int32_t *__restrict__ slot,
+                                                          const int32_t *__restrict__ valid_index,
+                                                          float *__restrict__ ctx, int N, int Nq, int C,
+                                                          int heads, int n_valid, int G, float scale) {
+  const int hd = C / heads;
+  const int64_t total = (int64_t)n_valid * heads * G;
+  const int64_t span = (((int64_t)total + 63) / 64) * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < span;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = idx < total;
+    const int64_t id = live ? idx : total - 1;
+    const int g = (int)(id % G);
+    const int h = (int)((id / G) % heads);
+    const int i = (int)(id / ((int64_t)G * heads));
+    const int vq = valid_index[i];
+    const int c0 = h * hd + g * VEC;
+    float qv[VEC], acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      qv[v] = q[(int64_t)i * C + c0 + v] * scale;  // torch: q_scaled = q * sqrt(1/head_dim)
+      acc[v] = 0.f;
+    }
+    float mx = -INFINITY, sum = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const int p = slot[(int64_t)n * Nq + vq];
+      if (p < 0) continue;  // uniform over the G lanes of a group
+      const float *kp = kv + (int64_t)p * 2 * C + c0;
+      float kx[VEC], vx[VEC];
+      if (VEC == 4) {
+        const float4 k4 = *reinterpret_cast<const float4 *>(kp);
+        const float4 v4 = *reinterpret_cast<const float4 *>(kp + C);
+        kx[0] = k4.x; kx[1 % VEC] = k4.y; kx[2 % VEC] = k4.z; kx[3 % VEC] = k4.w;
+        vx[0] = v4.x; vx[1 % VEC] = v4.y; vx[2 % VEC] = v4.z; vx[3 % VEC] = v4.w;
+      } else {
+        kx[0] = kp[0]; vx[0] = kp[C];
+      }
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d += qv[v] * kx[v];
+      for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+      const float nm = fmaxf(mx, d);
+      const float corr = expf(mx - nm);  // exp(-inf) = 0 on the first visible view
+      const float e = expf(d - nm);
+      sum = sum * corr + e;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = acc[v] * corr + e * vx[v];
+      mx = nm;
+    }
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ctx[(int64_t)i * C + c0 + v] = acc[v] / sum;
+    }
+  }
+}
+
+__global__ void scatter_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ idx,
+                                    const int32_t *__restrict__ idx2, float *__restrict__ vol, int n, int C, int VEC) {
+  const int CV = C / VEC;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)n * CV;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / CV), c = (int)(t - (int64_t)i * CV);
+    int64_t d = idx[i];
+    if (idx2) d = idx2[d];
+    if (VEC == 4)
+      reinterpret_cast<float4 *>(vol + d * C)[c] = reinterpret_cast<const float4 *>(rows + (int64_t)i * C)[c];
+    else
+      vol[d * C + c] = rows[(int64_t)i * C + c];
+  }
+}
+
+// [N,C,Hs,Ws] -> [N,H*W,C] crop + transpose through a padded 32x33 LDS tile:
+// reads coalesced along w, writes coalesced along c.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int C, int Hs, int Ws, int H, int W) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32;  // pixel tile over the cropped H*W
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int HW = H * W;
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, px = p0 + tx;
+    float v = 0.f;
+    if (c < C && px < HW) {
+      const int h = px / W, w = px - h * W;
+      v = src[(((int64_t)n * C + c) * Hs + h) * Ws + w];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int px = p0 + j, c = c0 + tx;
+    if (c < C && px < HW) dst[((int64_t)n * HW + px) * C + c] = tile[tx][j];
+  }
+}
+
+}  // namespace sgc
+
+using namespace sgc;
+
+static int grid_for(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
+                             float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream) {
+  if (!feat || !slot || !valid_index || !mean) return set_error(SGC_EINVAL, "sgc_view_mean: null pointer");
+  if (n_valid <= 0) return SGC_OK;
+  if (C % 4 == 0 && !((uintptr_t)feat & 15) && !((uintptr_t)mean & 15))
+    hipLaunchKernelGGL(view_mean_kernel, dim3(grid_for((int64_t)n_valid * (C / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid);
+  else
+    hipLaunchKernelGGL(view_mean_scalar_kernel, dim3(grid_for((int64_t)n_valid * C, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid);
+  return check_launch("view_mean_kernel");
+}
+
+extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
+                               const int32_t *valid_index, float *ctx,
+                               int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+  if (!q || !kv || !slot || !valid_index || !ctx) return set_error(SGC_EINVAL, "sgc_view_attend: null pointer");
+  if (heads <= 0 || C % heads) return set_error(SGC_EINVAL, "sgc_view_attend: C %% heads != 0");
+  if (n_valid <= 0) return SGC_OK;
+  const int hd = C / heads;
+  const float scale = sqrtf(1.0f / (float)hd);
+  // lanes per (voxel, head): head_dim/4 when that is a power of two <= 64, else one lane per channel
+  int vec = 4, G = hd / 4;
+  if (hd % 4 || (G & (G - 1)) || G > 64 || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15)) { vec = 1; G = hd; }
+  if ((G & (G - 1)) || G > 64) return set_error(SGC_EUNSUP, "sgc_view_attend: head_dim %d not supported", hd);
+  const int64_t work = (int64_t)n_valid * heads * G;
+  if (vec == 4)
+    hipLaunchKernelGGL(view_attend_kernel<4>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale);
+  else
+    hipLaunchKernelGGL(view_attend_kernel<1>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale);
+  return check_launch("view_attend_kernel");
+}
+
+extern "C" int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
+                                float *vol, int n, int C, sgc_stream_t stream) {
+  if (!rows || !idx || !vol) return set_error(SGC_EINVAL, "sgc_scatter_rows: null pointer");
+  if (n <= 0) return SGC_OK;
+  const int vec = (C % 4 == 0 && !((uintptr_t)rows & 15) && !((uintptr_t)vol & 15)) ? 4 : 1;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((int64_t)n * (C / vec), 256)), dim3(256), 0,
+                     (hipStream_t)stream, rows, idx, idx2_or_null, vol, n, C, vec);
+  return check_launch("scatter_rows_kernel");
+}
+
+extern "C" int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
+                                     int H, int W, sgc_stream_t stream) {
+  if (!src || !dst) return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: null pointer");
+  if (H > Hs || W > Ws || N <= 0 || C <= 0 || H <= 0 || W <= 0)
+    return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: bad sizes");
+  if (N > 65535) return set_error(SGC_EUNSUP, "sgc_nchw_to_nhwc_crop: N > 65535");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, Hs, Ws, H, W);
+  return check_launch("nchw_to_nhwc_kernel");
+}
