@@ -1,0 +1,170 @@
+"""FCOS3D-style voxel heads: forward convolutions and box decoding.
+
+Reference: mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py -- ``ImVoxelHeadV2``
+(:42-88, :237-317), ``ScanNetImVoxelHeadV2`` (:346-359, :437-464), ``SunRgbdImVoxelHeadV2``
+(:467-483, :563-613); ``get_points`` from mmdet3d_plugin/models/detectors/utils.py:5-14.
+Parameter names (``centerness_conv``, ``reg_conv``, ``cls_conv``, ``scales.i.scale``) are
+the reference's.  Target assignment and losses (:95-235, :361-435, :485-561) are the
+"next" row f-3 of SURVEY.md section 8 and are not part of this path yet.
+
+NMS: the reference calls mmdet3d's ``aligned_3d_nms`` (ScanNet) / ``box3d_multiclass_nms``
+with mmcv's ``nms_rotated`` (ARKit); those are row f-4.  ``_nms`` here returns the
+score-thresholded candidates unless an ``nms_fn`` is injected.
+"""
+import torch
+from torch import nn
+
+from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
+
+
+@torch.no_grad()
+def get_points(n_voxels, voxel_size, origin):
+    """Voxel CORNER coordinates [3,nx,ny,nz] = idx*size + origin - n/2*size (utils.py:5-14)."""
+    grid = torch.stack(torch.meshgrid([torch.arange(n_voxels[0]), torch.arange(n_voxels[1]),
+                                       torch.arange(n_voxels[2])], indexing="ij"))
+    new_origin = origin - n_voxels / 2.0 * voxel_size
+    return grid * voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
+
+
+def rotation_3d_in_axis_z(points, angles):
+    """points [N,K,3] rotated about z by angles [N] (mmdet3d rotation_3d_in_axis, axis=2,
+    counter-clockwise for positive angles in the depth/lidar convention)."""
+    cos, sin = torch.cos(angles), torch.sin(angles)
+    zeros, ones = torch.zeros_like(cos), torch.ones_like(cos)
+    rot_t = torch.stack([torch.stack([cos, sin, zeros]), torch.stack([-sin, cos, zeros]),
+                         torch.stack([zeros, zeros, ones])])            # [3,3,N]
+    return torch.einsum("aij,jka->aik", points, rot_t)
+
+
+class ImVoxelHeadV2(nn.Module):
+    def __init__(self, n_classes, n_channels, n_reg_outs, n_scales, limit, centerness_topk=-1,
+                 loss_centerness=None, loss_bbox=None, loss_cls=None, train_cfg=None, test_cfg=None,
+                 nms_fn=None):
+        super().__init__()
+        self.n_classes = n_classes
+        self.n_scales = n_scales
+        self.limit = limit
+        self.centerness_topk = centerness_topk
+        self.loss_cfgs = dict(loss_centerness=loss_centerness, loss_bbox=loss_bbox, loss_cls=loss_cls)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.nms_fn = nms_fn
+        self.voxel_size = None                    # set by the detector (SGCDet.py:36)
+        self.centerness_conv = nn.Conv3d(n_channels, 1, 3, padding=1, bias=False)
+        self.reg_conv = nn.Conv3d(n_channels, n_reg_outs, 3, padding=1, bias=False)
+        self.cls_conv = nn.Conv3d(n_channels, n_classes, 3, padding=1)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in range(n_scales)])
+
+    def init_weights(self):
+        normal_init(self.centerness_conv, std=0.01)
+        normal_init(self.reg_conv, std=0.01)
+        normal_init(self.cls_conv, std=0.01, bias=bias_init_with_prob(0.01))
+
+    def forward(self, x):
+        return multi_apply(self.forward_single, x, self.scales)
+
+    @torch.no_grad()
+    def get_points(self, featmap_sizes, origin, device):
+        out = []
+        for i, size in enumerate(featmap_sizes):
+            pts = get_points(n_voxels=torch.tensor(size), voxel_size=torch.tensor(self.voxel_size) * (2 ** i),
+                             origin=torch.tensor(origin))
+            out.append(pts.reshape(3, -1).transpose(0, 1).to(device))
+        return out
+
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, valid, img_metas):
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(img_metas)
+        valids = [nn.Upsample(size=x.shape[-3:], mode="trilinear")(valid).round().bool() for x in centernesses]
+        results = []
+        for b in range(len(img_metas)):
+            results.append(self._get_bboxes_single(
+                [x[b].detach() for x in centernesses], [x[b].detach() for x in bbox_preds],
+                [x[b].detach() for x in cls_scores], [x[b].detach() for x in valids], img_metas[b]))
+        return results
+
+    def decode_candidates(self, centernesses, bbox_preds, cls_scores, valids, img_meta):
+        """Per-level sigmoid scores x centerness x valid, top ``nms_pre`` per level, box decode
+        (imvoxel_head_v2.py:286-315).  Returns (boxes [K, 6|7], scores [K, n_classes])."""
+        sizes = [f.size()[-3:] for f in centernesses]
+        mlvl_points = self.get_points(sizes, img_meta["lidar2img"]["origin"], centernesses[0].device)
+        n_reg = bbox_preds[0].shape[0]
+        nms_pre = self.test_cfg["nms_pre"] if self.test_cfg is not None else -1
+        boxes, scores_out = [], []
+        for ctr, reg, cls, valid, pts in zip(centernesses, bbox_preds, cls_scores, valids, mlvl_points):
+            ctr = ctr.permute(1, 2, 3, 0).reshape(-1).sigmoid()
+            reg = reg.permute(1, 2, 3, 0).reshape(-1, n_reg)
+            scores = cls.permute(1, 2, 3, 0).reshape(-1, self.n_classes).sigmoid()
+            valid = valid.permute(1, 2, 3, 0).reshape(-1)
+            scores = scores * ctr[:, None] * valid[:, None]
+            max_scores, _ = scores.max(dim=1)
+            if len(scores) > nms_pre > 0:
+                _, ids = max_scores.topk(nms_pre)
+                reg, scores, pts = reg[ids], scores[ids], pts[ids]
+            boxes.append(self._bbox_pred_to_bbox(pts, reg))
+            scores_out.append(scores)
+        return torch.cat(boxes), torch.cat(scores_out)
+
+    def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, valids, img_meta):
+        boxes, scores = self.decode_candidates(centernesses, bbox_preds, cls_scores, valids, img_meta)
+        return self._nms(boxes, scores, img_meta)
+
+    def forward_single(self, x, scale):
+        raise NotImplementedError
+
+    def _bbox_pred_to_bbox(self, points, bbox_pred):
+        raise NotImplementedError
+
+    def _nms(self, bboxes, scores, img_meta):
+        raise NotImplementedError
+
+
+@HEADS.register_module()
+class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
+    def forward_single(self, x, scale):
+        return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
+
+    def _bbox_pred_to_bbox(self, points, bbox_pred):
+        """point -/+ distances -> (x0,y0,z0,x1,y1,z1), :456-464."""
+        lo = points - bbox_pred[:, [0, 2, 4]]
+        hi = points + bbox_pred[:, [1, 3, 5]]
+        return torch.cat([lo, hi], -1)
+
+    def _nms(self, bboxes, scores, img_meta):
+        scores, labels = scores.max(dim=1)
+        keep = scores > self.test_cfg["score_thr"]
+        bboxes, scores, labels = bboxes[keep], scores[keep], labels[keep]
+        if self.nms_fn is not None:
+            ids = self.nms_fn(bboxes, scores, labels, self.test_cfg["iou_thr"])
+            bboxes, scores, labels = bboxes[ids], scores[ids], labels[ids]
+        centers = (bboxes[:, :3] + bboxes[:, 3:6]) / 2.0
+        bboxes = torch.cat([centers, bboxes[:, 3:6] - bboxes[:, :3]], dim=1)
+        box_type = img_meta.get("box_type_3d") if isinstance(img_meta, dict) else None
+        if box_type is not None:
+            bboxes = box_type(bboxes, origin=(0.5, 0.5, 0.5), box_dim=6, with_yaw=False)
+        return bboxes, scores, labels
+
+
+@HEADS.register_module()
+class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
+    def forward_single(self, x, scale):
+        reg = self.reg_conv(x)
+        return self.centerness_conv(x), torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1), self.cls_conv(x)
+
+    @staticmethod
+    def _bbox_pred_to_bbox(points, bbox_pred):
+        """(dx-,dx+,dy-,dy+,dz-,dz+,alpha) -> (cx,cy,cz,w,l,h,alpha), :595-613."""
+        if bbox_pred.shape[0] == 0:
+            return bbox_pred
+        shift = torch.stack(((bbox_pred[:, 1] - bbox_pred[:, 0]) / 2, (bbox_pred[:, 3] - bbox_pred[:, 2]) / 2,
+                             (bbox_pred[:, 5] - bbox_pred[:, 4]) / 2), dim=-1).view(-1, 1, 3)
+        shift = rotation_3d_in_axis_z(shift, bbox_pred[:, 6])[:, 0, :]
+        size = torch.stack((bbox_pred[:, 0] + bbox_pred[:, 1], bbox_pred[:, 2] + bbox_pred[:, 3],
+                            bbox_pred[:, 4] + bbox_pred[:, 5]), dim=-1)
+        return torch.cat((points + shift, size, bbox_pred[:, 6:7]), dim=-1)
+
+    def _nms(self, bboxes, scores, img_meta):
+        if self.nms_fn is not None:
+            return self.nms_fn(bboxes, scores, self.test_cfg, img_meta)
+        max_scores, labels = scores.max(dim=1)
+        keep = max_scores > self.test_cfg["score_thr"]
+        return bboxes[keep], max_scores[keep], labels[keep]

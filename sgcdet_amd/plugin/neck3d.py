@@ -1,0 +1,80 @@
+"""``FastIndoorImVoxelNeck``: dense 3D residual U-Net over the voxel volume.
+
+Reference: mmdet3d_plugin/models/necks/imvoxelnet.py:8-67 (neck), :146-173 (BasicBlock3dV2).
+State-dict keys are the reference's: ``down_layer_{i}.{b}.{conv1,norm1,conv2,norm2,
+downsample.0,downsample.1}``, ``up_block_{i}.{0,1,3,4}``, ``out_block_{i}.{0,1}``.
+
+"Sparse" in SGCDet means sparse QUERIES; the volume entering the neck is dense (every voxel
+carries the upsampled coarse feature, AdaptiveSparseHead.py:77-82), so the convolutions
+stay dense -- a submanifold-sparse convolution would change the results (SURVEY.md
+section 0, fact 3).
+"""
+import torch
+from torch import nn
+
+from ..mmcv_lite import NECKS
+
+
+class BasicBlock3dV2(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = nn.Conv3d(in_channels, out_channels, 3, stride, 1, bias=False)
+        self.norm1 = nn.BatchNorm3d(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, 3, 1, 1, bias=False)
+        self.norm2 = nn.BatchNorm3d(out_channels)
+        if stride != 1:
+            self.downsample = nn.Sequential(nn.Conv3d(in_channels, out_channels, 1, stride, bias=False),
+                                            nn.BatchNorm3d(out_channels))
+
+    def forward(self, x):
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.norm2(self.conv2(out))
+        skip = self.downsample(x) if self.stride != 1 else x
+        return self.relu(out + skip)
+
+
+def _conv_bn_relu(cin, cout):
+    return nn.Sequential(nn.Conv3d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+@NECKS.register_module()
+class FastIndoorImVoxelNeck(nn.Module):
+    def __init__(self, in_channels, n_blocks, out_channels):
+        super().__init__()
+        self.n_scales = len(n_blocks)
+        width = in_channels
+        for i, nb in enumerate(n_blocks):
+            stride = 1 if i == 0 else 2
+            blocks = []
+            for b in range(nb):
+                if b == 0 and stride != 1:
+                    blocks.append(BasicBlock3dV2(width, width * 2, stride))
+                    width *= 2
+                else:
+                    blocks.append(BasicBlock3dV2(width, width))
+            setattr(self, f"down_layer_{i}", nn.Sequential(*blocks))
+            if i > 0:
+                setattr(self, f"up_block_{i}", nn.Sequential(
+                    nn.ConvTranspose3d(width, width // 2, 2, 2, bias=False), nn.BatchNorm3d(width // 2),
+                    nn.ReLU(inplace=True),
+                    nn.Conv3d(width // 2, width // 2, 3, 1, 1, bias=False), nn.BatchNorm3d(width // 2),
+                    nn.ReLU(inplace=True)))
+            setattr(self, f"out_block_{i}", _conv_bn_relu(width, out_channels))
+
+    def forward(self, x):
+        """[1,C,nx,ny,nz] -> [out@1x, out@1/2, out@1/4], finest first (imvoxelnet.py:22-34)."""
+        skips = []
+        for i in range(self.n_scales):
+            x = getattr(self, f"down_layer_{i}")(x)
+            skips.append(x)
+        outs = []
+        for i in reversed(range(self.n_scales)):
+            if i < self.n_scales - 1:
+                x = skips[i] + getattr(self, f"up_block_{i + 1}")(x)
+            outs.append(getattr(self, f"out_block_{i}")(x))
+        return outs[::-1]
+
+    def init_weights(self):
+        pass

@@ -1,0 +1,133 @@
+"""Coarse-to-fine sparse volume construction (``AdaptiveSparseHead`` / ``DenseHead``).
+
+Reference: mmdet3d_plugin/models/im2voxel/AdaptiveSparseHead.py:9-102 and
+mmdet3d_plugin/models/im2voxel/DenseHead.py:10-84.  Registry names, kwargs, buffers
+(``vox_coords``, ``ref_3d``) and parameter names (``base_heads.i...``,
+``occ_pred_heads.i.0``) are the reference's; call contract:
+
+    AdaptiveSparseHead(mlvl_feats, img_meta, mlvl_dpt_dists)
+        -> (volume [1,C,nx,ny,nz], valid [1,1,nx,ny,nz] int64, occ_preds [1, sum Nvox])
+
+MI355X differences: the top-k indices are sorted and handed to ``DenseHead`` directly, so
+the ``nonzero`` host sync of DenseHead.py:66 disappears (the selected set and its ascending
+order are identical); the per-level scatter into the dense volume is one HIP launch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..mmcv_lite import HEADS, build_head, build_transformer
+from .. import ext
+
+
+def topk_wo_grad(occ_preds_flatten, topk=10):
+    """Hard top-k mask, no gradient (AdaptiveSparseHead.py:9-13).  Ties follow torch.topk."""
+    _, idx = torch.topk(occ_preds_flatten, k=topk, dim=1)
+    return torch.zeros_like(occ_preds_flatten).scatter_(1, idx, 1.0)
+
+
+@HEADS.register_module()
+class DenseHead(nn.Module):
+    def __init__(self, *args, voxel_size=None, n_voxels=None, embed_dims, cross_transformer, **kwargs):
+        super().__init__()
+        self.voxel_size = torch.tensor(voxel_size)
+        self.n_voxels = torch.tensor(n_voxels)
+        self.embed_dims = embed_dims
+        self.cross_transformer = build_transformer(cross_transformer)
+        vox_coords, ref_3d = self.get_voxel_indices()
+        self.register_buffer("vox_coords", vox_coords)
+        self.register_buffer("ref_3d", ref_3d)
+
+    def get_voxel_indices(self):
+        """vox_coords [Nvox,4] = (x,y,z,flat) with flat = (x*ny + y)*nz + z; ref_3d [Nvox,3] =
+        idx * voxel_size - n_voxels/2 * voxel_size (voxel corner, no +0.5; DenseHead.py:32-48)."""
+        nx, ny, nz = (int(v) for v in self.n_voxels)
+        grid = torch.stack(torch.meshgrid(torch.arange(nx), torch.arange(ny), torch.arange(nz), indexing="ij"))
+        flat = torch.arange(nx * ny * nz)
+        vox_coords = torch.cat([grid.reshape(3, -1).t(), flat[:, None]], dim=-1)
+        new_origin = -self.n_voxels / 2.0 * self.voxel_size
+        points = grid * self.voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
+        return vox_coords, points.view(3, -1).permute(1, 0)
+
+    def forward(self, mlvl_feats, img_meta=None, proposal=None, proposal_idx=None, **kwargs):
+        """mlvl_feats: list of [1,N,C,H,W]; proposal: [Nvox] {0,1} mask or None (= all);
+        proposal_idx: optional ascending int64 indices equal to ``nonzero(proposal > 0)``.
+        Returns [1,C,nx,ny,nz]."""
+        bs = mlvl_feats[0].shape[0]
+        device = mlvl_feats[0].device
+        assert bs == 1
+        n_vox = int(self.n_voxels.prod())
+        C = self.embed_dims
+        if proposal_idx is not None:
+            unmasked_idx = proposal_idx
+        elif proposal is None:
+            unmasked_idx = torch.arange(n_vox, device=device)
+        else:
+            unmasked_idx = torch.nonzero(proposal > 0).view(-1)          # host sync, reference behaviour
+        volume_queries = torch.zeros((n_vox, C), device=device)           # content-free queries (:63)
+        seed_feats = self.cross_transformer.get_vox_features(
+            mlvl_feats, volume_queries, ref_3d=self.ref_3d, vox_coords=self.vox_coords,
+            unmasked_idx=unmasked_idx, bev_pos=None, prev_bev=None, img_meta=img_meta, **kwargs).squeeze(0)
+        if torch.is_grad_enabled() and seed_feats.requires_grad:
+            volume_out = torch.zeros((n_vox, C), device=device).index_put((unmasked_idx,), seed_feats)
+        else:
+            volume_out = torch.zeros((n_vox, C), device=device)
+            ext.ops().scatter_rows(seed_feats.contiguous(), unmasked_idx.to(torch.int32), volume_out)
+        nx, ny, nz = (int(v) for v in self.n_voxels)
+        return volume_out.view(nx, ny, nz, C).permute(3, 0, 1, 2).unsqueeze(0)
+
+
+@HEADS.register_module()
+class AdaptiveSparseHead(nn.Module):
+    def __init__(self, embed_dims=256, topk_list=None, voxel_size_list=None, n_voxels_list=None,
+                 base_head_configs=None, **kwargs):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.topk_list = list(topk_list) if topk_list is not None else []
+        self.voxel_size_list = list(voxel_size_list) if voxel_size_list is not None else []
+        self.n_voxels_list = list(n_voxels_list) if n_voxels_list is not None else []
+        self.base_heads = nn.ModuleList([build_head(cfg) for cfg in (base_head_configs or [])])
+        self.occ_pred_heads = nn.ModuleList(
+            [nn.Sequential(nn.Linear(embed_dims, 1), nn.Sigmoid()) for _ in range(len(self.base_heads) - 1)])
+        self.loss = nn.BCELoss()
+
+    def forward(self, mlvl_feats, img_meta, mlvl_dpt_dists):
+        assert mlvl_feats[0].shape[0] == 1
+        n_lvl = len(self.base_heads)
+        volume = None
+        occ_preds_list = []
+        mask = None
+        for i in range(n_lvl):
+            # level i samples FPN map n_lvl-1-i cropped to the un-padded image (:52-59)
+            ds = 4 * (2 ** (n_lvl - 1 - i))
+            h, w = img_meta["img_shape"][0] // ds, img_meta["img_shape"][1] // ds
+            k = n_lvl - 1 - i
+            feat = mlvl_feats[k][:, :, :, :h, :w]
+            dpt = mlvl_dpt_dists[k][:, :, :, :h, :w]
+            if i == 0:
+                volume = self.base_heads[0]([feat], img_meta, mlvl_dpt_dists=[dpt])
+                continue
+            up = F.interpolate(volume, scale_factor=2, mode="trilinear", align_corners=False)
+            occ = self.occ_pred_heads[i - 1](up.permute(0, 2, 3, 4, 1)).reshape(1, -1)
+            occ_preds_list.append(occ)
+            mask, idx = None, None
+            if (i - 1) < len(self.topk_list):
+                _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
+                mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
+                idx = top.squeeze(0).sort().values                       # == nonzero(mask), no host sync
+            volume = up + self.base_heads[i]([feat], img_meta, proposal=mask, proposal_idx=idx,
+                                             mlvl_dpt_dists=[dpt])
+        if not occ_preds_list:
+            _, _, vh, vw, vz = volume.shape
+            return volume, torch.ones([1, 1, vh, vw, vz], device=volume.device), None
+        occ_preds = torch.cat(occ_preds_list[::-1], dim=1)
+        valid = self.get_valid(mask).unsqueeze(0).unsqueeze(0).detach()
+        return volume, valid, occ_preds
+
+    def get_valid(self, indices_0):
+        nx, ny, nz = self.n_voxels_list[-1]
+        return indices_0.view(nx, ny, nz).bool().long()
+
+    def occ_loss(self, occ_pred, sem_occ_gt, geo_occ_gt):
+        n = occ_pred.shape[1]
+        return {"loss_occ": self.loss(occ_pred, geo_occ_gt[:, 0:n].float()).mean() * 0.5}

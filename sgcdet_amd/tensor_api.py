@@ -264,9 +264,24 @@ class TensorOps:
         return vol
 
     def nchw_to_nhwc_crop(self, src, H, W):
-        self._check(src=src)
+        """``src`` [N,C,Hs,Ws] or a top-left crop *view* of it (the reference crops with
+        ``x[..., :height, :width]``, AdaptiveSparseHead.py:58-59); returns [N, H*W, C]."""
+        if src.dim() != 4:
+            raise RuntimeError("nchw_to_nhwc_crop expects [N,C,H,W]")
+        N, Cc, h_in, w_in = src.shape
+        if H > h_in or W > w_in:
+            raise RuntimeError("nchw_to_nhwc_crop: crop larger than the map")
+        st = src.stride()
+        Ws = st[2] if st[3] == 1 and h_in > 1 else w_in
+        Hs = st[1] // Ws if Ws > 0 and st[1] % max(Ws, 1) == 0 else h_in
+        viewable = (st[3] == 1 and Ws >= w_in and Hs >= h_in and st[1] == Hs * Ws
+                    and (N == 1 or st[0] == Cc * Hs * Ws))
+        if not viewable:
+            src = src.contiguous()
+            Hs, Ws = h_in, w_in
+        if src.device.type != self.device_type:
+            raise RuntimeError(f"src must be a {self.device_type} tensor")
         self._f32(src=src)
-        N, Cc, Hs, Ws = src.shape
         dst = torch.empty((N, H * W, Cc), dtype=torch.float32, device=src.device)
         self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W)
         return dst

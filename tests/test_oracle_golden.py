@@ -1,0 +1,73 @@
+"""Pins the oracle (C kernels + oracle/ref_path.py restatement) to the golden vectors made
+by the REFERENCE's own Python modules (tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from golden_util import load, img_meta, depth_pyramid, max_err
+from oracle.ref_path import RefPath
+
+
+def test_reference_autograd_composition(oracle_ops):
+    """MultiScale3DDeformableAttnFunction_fp32 (two ext calls + python grad merge) == fused oracle."""
+    d, _ = load("op_autograd")
+    out, score = oracle_ops.dfa3d_forward(d["value"], d["dist"], d["shapes3"], d["lsi"], d["loc"], d["attn"], want_score=True)
+    assert torch.equal(out, d["out"]) and torch.equal(score, d["score"])
+    gv, gd, gl, ga = oracle_ops.dfa3d_backward(d["value"], d["dist"], d["shapes3"], d["lsi"], d["loc"], d["attn"], d["grad_out"])
+    assert max_err(gv, d["grad_value"]) < 1e-6 and max_err(gd, d["grad_dist"]) < 1e-5
+    assert max_err(gl, d["grad_loc"]) < 1e-4 and max_err(ga, d["grad_attn"]) < 1e-6
+
+
+def _voxel_cfg(d, C=32):
+    return dict(embed_dims=C, n_voxels_list=[tuple(int(v) for v in g) for g in d["grids"]],
+                voxel_size_list=[tuple(float(v) for v in s) for s in d["sizes"]],
+                topk_list=[int(v) for v in d["topk"]], dbound=(0.2, 5.0), num_heads=8, num_points=4)
+
+
+def test_point_sampling_matches_reference_torch(oracle_ops):
+    """VoxFormerEncoder_DFA3D.point_sampling run by the reference on torch-CPU vs the oracle's
+    fixed-order projection: mask identical, coordinates within fp32 rounding."""
+    d, _ = load("point_sampling")
+    meta = img_meta(d)
+    rp = RefPath({}, dict(dbound=(float(d["dbound"][0]), float(d["dbound"][1]))))
+    ref_cam, mask = rp.project(d["ref_3d"].float(), meta)
+    g_cam = d["ref_cam"][:, 0, :, 0]
+    g_mask = d["mask"][:, 0, :, 0]
+    assert torch.equal(mask, g_mask)
+    assert 0.1 < g_mask.float().mean() < 0.9
+    assert max_err(ref_cam, g_cam) < 2e-6
+
+
+def test_voxel_head_restatement_matches_reference():
+    d, sd = load("voxel_head")
+    meta = img_meta(d)
+    rp = RefPath(sd, _voxel_cfg(d))
+    feats = [d[f"feat{i}"] for i in range(4)]
+    dpts = depth_pyramid(d["dpt"])
+    lvl0, _ = rp.dense_head(0, feats[2][:, :, :, :59 // 16, :80 // 16], dpts[2][:, :, :, :59 // 16, :80 // 16], meta)
+    assert max_err(lvl0, d["level0_volume"]) < 2e-5
+    volume, valid, occ = rp.adaptive_sparse_head(feats, meta, dpts)
+    assert torch.equal(valid, d["valid"])                       # top-k voxel sets: bit-exact
+    assert max_err(occ, d["occ"]) < 1e-5
+    assert max_err(volume, d["volume"]) < 5e-5
+
+
+def test_neck_restatement_matches_reference():
+    d, sd = load("neck")
+    outs = RefPath(sd, {}).neck(d["x"])
+    for i, o in enumerate(outs):
+        assert o.shape == d[f"out{i}"].shape
+        assert max_err(o, d[f"out{i}"]) < 1e-4 * max(1.0, d[f"out{i}"].abs().max().item())
+
+
+@pytest.mark.parametrize("tag,n_cls", [("scannet", 18), ("sunrgbd", 17)])
+def test_head_restatement_matches_reference(tag, n_cls):
+    d, sd = load("head_" + tag)
+    rp = RefPath(sd, dict(head=tag, n_classes=n_cls, nms_pre=int(d["nms_pre"])))
+    ctr, reg, cls = rp.head([d["f0"], d["f1"], d["f2"]])
+    for i in range(3):
+        assert max_err(ctr[i], d[f"ctr{i}"]) < 1e-5 and max_err(cls[i], d[f"cls{i}"]) < 1e-5
+        assert max_err(reg[i], d[f"reg{i}"]) < 1e-5 * max(1.0, d[f"reg{i}"].abs().max().item())
+    boxes, scores = rp.decode(ctr, reg, cls, d["valid"], img_meta(d), tuple(float(v) for v in d["voxel_size"]))
+    assert boxes.shape == d["boxes"].shape
+    assert max_err(scores, d["scores"]) < 1e-6
+    assert max_err(boxes, d["boxes"]) < 1e-4

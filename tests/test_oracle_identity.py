@@ -1,0 +1,84 @@
+"""Pins the C oracle's kernel arithmetic to an INDEPENDENT formulation: the DFA3D operator
+equals 5-D ``F.grid_sample`` (bilinear, zeros padding, align_corners=False) over the outer
+product value (x) depth_dist followed by the attention-weighted sum;
+its backward equals torch autograd of that formulation."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+CASES = [  # B, M, Cm, D, Q, P, levels
+    (2, 4, 8, 6, 40, 3, [(5, 7), (3, 4)]),
+    (1, 8, 4, 12, 64, 4, [(15, 20)]),
+    (2, 1, 16, 12, 50, 1, [(7, 10)]),
+    (1, 2, 5, 7, 30, 2, [(6, 5), (3, 3), (2, 2)]),
+]
+
+
+def closed_form(value, dist, loc, attn, levels):
+    B, S, M, Cm = value.shape
+    D = dist.shape[-1]
+    Q, P = loc.shape[1], loc.shape[4]
+    out, start = 0, 0
+    for l, (H, W) in enumerate(levels):
+        v = value[:, start:start + H * W].view(B, H, W, M, Cm)
+        d = dist[:, start:start + H * W].view(B, H, W, M, D)
+        vol = torch.einsum("bhwmc,bhwmd->bmcdhw", v, d).reshape(B * M, Cm, D, H, W)
+        g = loc[:, :, :, l].permute(0, 2, 1, 3, 4).reshape(B * M, Q, P, 1, 3) * 2 - 1
+        samp = F.grid_sample(vol, g, mode="bilinear", padding_mode="zeros", align_corners=False).view(B, M, Cm, Q, P)
+        out = out + torch.einsum("bmcqp,bmqp->bqmc", samp, attn[:, :, :, l].permute(0, 2, 1, 3))
+        start += H * W
+    return out.reshape(B, Q, M * Cm)
+
+
+def inputs(case, seed):
+    B, M, Cm, D, Q, P, levels = case
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in levels)
+    L = len(levels)
+    shapes3 = torch.tensor([[h, w, D] for h, w in levels])
+    lsi = torch.tensor([0] + [h * w for h, w in levels]).cumsum(0)[:-1].contiguous()
+    value = torch.randn(B, S, M, Cm, generator=g)
+    dist = torch.randn(B, S, M, D, generator=g).softmax(-1).contiguous()
+    loc = (torch.rand(B, Q, M, L, P, 3, generator=g) * 1.4 - 0.2).contiguous()
+    attn = torch.rand(B, Q, M, L, P, generator=g)
+    return value, dist, shapes3, lsi, loc, attn
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_equals_grid_sample(case, oracle_ops):
+    value, dist, shapes3, lsi, loc, attn = inputs(case, 0)
+    out, score = oracle_ops.dfa3d_forward(value, dist, shapes3, lsi, loc, attn, want_score=True)
+    ref = closed_form(value, dist, loc, attn, case[6])
+    assert (out - ref).abs().max() < 2e-6
+    # two-stage == one-stage (the implied KAT of unittest_DFA3D.py:9-29), bit for bit
+    sc = oracle_ops.depth_score_forward(dist, shapes3, lsi, loc)
+    out2 = oracle_ops.wms_forward(value, shapes3[:, :2].contiguous(), lsi, loc[..., :2].contiguous(), attn, sc)
+    assert torch.equal(sc, score) and torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_equals_autograd_of_grid_sample(case, oracle_ops):
+    value, dist, shapes3, lsi, loc, attn = inputs(case, 1)
+    leaves = [t.clone().requires_grad_() for t in (value, dist, loc, attn)]
+    ref = closed_form(*leaves, case[6])
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+    want = torch.autograd.grad(ref, leaves, go)
+    got = oracle_ops.dfa3d_backward(value, dist, shapes3, lsi, loc, attn, go.contiguous())
+    for w, g in zip(want, got):
+        assert (w - g).abs().max() <= 2e-5 * max(1.0, w.abs().max().item())
+
+
+def test_unreplicated_depth_equals_replicated(oracle_ops):
+    """dist_heads == 1 is the reference's `.repeat(1,1,num_heads,1)` without the copy; its
+    gradient is the head-sum autograd would produce through the repeat."""
+    value, dist, shapes3, lsi, loc, attn = inputs(CASES[1], 3)
+    d1 = dist[:, :, :1].contiguous()
+    drep = d1.repeat(1, 1, value.shape[2], 1).contiguous()
+    a, _ = oracle_ops.dfa3d_forward(value, d1, shapes3, lsi, loc, attn)
+    b, _ = oracle_ops.dfa3d_forward(value, drep, shapes3, lsi, loc, attn)
+    assert torch.equal(a, b)
+    go = torch.randn(a.shape, generator=torch.Generator().manual_seed(4))
+    g1 = oracle_ops.dfa3d_backward(value, d1, shapes3, lsi, loc, attn, go)
+    gr = oracle_ops.dfa3d_backward(value, drep, shapes3, lsi, loc, attn, go)
+    assert (g1[1] - gr[1].sum(2, keepdim=True)).abs().max() < 1e-5
+    assert torch.equal(g1[0], gr[0]) and torch.equal(g1[2], gr[2])
