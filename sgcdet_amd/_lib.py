@@ -6,6 +6,10 @@ error says what to run.
 """
 import os
 
+# torch first: it ships its own libamdhip64; loading our library before torch would bind a
+# second HIP runtime (/opt/rocm) into the process and the GPU would not be visible to it.
+import torch  # noqa: F401
+
 from ._abi import Library
 from . import build as _build
 

@@ -23,6 +23,9 @@ class TensorOps:
     def __init__(self, library, device_type):
         self.lib = library
         self.device_type = device_type
+        # when set to a list, every CUDA call is bracketed by HIP events on the launch stream
+        # and (name, meta, start, end) is appended -- bench.py's per-kernel timing
+        self.event_log = None
 
     # ---- argument checks ------------------------------------------------
     def _check(self, **tensors):
@@ -62,12 +65,20 @@ class TensorOps:
             if t is not None and t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be int32 (got {t.dtype})")
 
-    def _call(self, name, *args):
+    def _call(self, name, *args, _meta=None):
         ptrs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
         if self.device_type == "cuda":
             dev = next(a.device for a in args if isinstance(a, torch.Tensor))
             with torch.cuda.device(dev):
-                return self.lib.call(name, *ptrs, _stream_ptr("cuda"))
+                if self.event_log is None:
+                    return self.lib.call(name, *ptrs, _stream_ptr("cuda"))
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = self.lib.call(name, *ptrs, _stream_ptr("cuda"))
+                e1.record()
+                self.event_log.append((name, _meta or {}, e0, e1))
+                return rc
         return self.lib.call(name, *ptrs, None)
 
     # ---- 1. the four dfa3D._ext operators ----------------------------------
@@ -207,7 +218,8 @@ class TensorOps:
         rows = n_pairs if n_pairs >= 0 else cap
         out = torch.empty((rows, Cc), dtype=torch.float32, device=feat.device)
         self._call("sgc_pairs_geometry_sample", feat, dist, ref_cam, pair_cam, pair_q, totals, out,
-                   N, Nq, H, W, Cc, D, n_pairs, cap)
+                   N, Nq, H, W, Cc, D, n_pairs, cap,
+                   _meta=dict(N=N, H=H, W=W, C=Cc, D=D, n_pairs=rows))
         return out
 
     def pairs_deform_gather(self, value, dist, ref_cam, raw, pair_cam, pair_q, n_pairs, H, W, M, P,
@@ -226,7 +238,8 @@ class TensorOps:
             raise RuntimeError("pairs_deform_gather: inconsistent shapes")
         out = torch.empty((rows, Cc), dtype=torch.float32, device=value.device)
         self._call("sgc_pairs_deform_gather", value, dist, ref_cam, raw, pair_cam, pair_q, totals, out,
-                   N, Nq, H, W, M, Cm, D, P, n_pairs, cap)
+                   N, Nq, H, W, M, Cm, D, P, n_pairs, cap,
+                   _meta=dict(N=N, H=H, W=W, C=Cc, D=D, M=M, P=P, n_pairs=rows))
         return out
 
     # ---- 5. inter-view aggregation ------------------------------------------
