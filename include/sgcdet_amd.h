@@ -231,6 +231,28 @@ int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_
 int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
                           int H, int W, sgc_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * 7. Dense 3D convolution of the neck / head on channels-last volumes
+ *    (FastIndoorImVoxelNeck, necks/imvoxelnet.py:36-64,146-173; head convs,
+ *     dense_heads/imvoxel_head_v2.py:75-78 -- cuDNN / MIOpen in the reference)
+ * ------------------------------------------------------------------------- */
+
+/* t = (sum_{tap,ci} x[nbr(v,tap), ci] * wt[tap][co][ci]) * scale[co] + shift[co];
+ * relu = 0: y = t + residual;  relu = 1: y = max(t + residual, 0)  (BasicBlock3dV2, imvoxelnet.py:161-173);
+ * relu = 2: y = max(t, 0) + residual  (decoder: up_block then skip add, imvoxelnet.py:29-31)
+ *   x  [ix*iy*iz, Cin]  channels-last volume, voxel index (x*iy + y)*iz + z  (== torch [1,C,X,Y,Z]
+ *      in channels_last_3d memory format);  Cin % 32 == 0;
+ *   wt [taps][Cout][Cin]: taps = ksize^3 with tap = (kx*ksize + ky)*ksize + kz (nn.Conv3d weight
+ *      [Cout,Cin,kx,ky,kz] permuted), or, transposed = 1, the 8 parities (px*2+py)*2+pz of
+ *      nn.ConvTranspose3d(k=2, s=2) weight [Cin,Cout,2,2,2];
+ *   scale/shift [Cout] or NULL: folded eval-mode BatchNorm3d (or bias); residual [OV,Cout] or NULL;
+ *   ksize in {1,3} (pad = ksize/2), stride in {1,2};  y [ox*oy*oz, Cout] fully written.
+ * fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).           */
+int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
+                      const float *residual_or_null, float *y,
+                      int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                      int transposed, int relu, sgc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

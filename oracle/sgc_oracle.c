@@ -620,3 +620,48 @@ int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, in
           dst[(((int64_t)n * H + h) * W + w) * C + c] = src[(((int64_t)n * C + c) * Hs + h) * Ws + w];
   return SGC_OK;
 }
+
+/* ---- 7. dense 3D convolution, channels-last (naive loops; semantics of nn.Conv3d(k,s,pad=k/2) /
+ * nn.ConvTranspose3d(2,2) + folded BatchNorm + residual + ReLU as chained in necks/imvoxelnet.py) ---- */
+int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
+                      const float *residual_or_null, float *y,
+                      int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                      int transposed, int relu, sgc_stream_t stream) {
+  (void)stream;
+  if (!x || !wt || !y) return fail(SGC_EINVAL, "null pointer");
+  const int pad = ksize / 2;
+  int ox, oy, oz;
+  if (transposed) { ox = 2 * ix; oy = 2 * iy; oz = 2 * iz; }
+  else { ox = (ix + 2 * pad - ksize) / stride + 1; oy = (iy + 2 * pad - ksize) / stride + 1; oz = (iz + 2 * pad - ksize) / stride + 1; }
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int a = 0; a < ox; ++a)
+    for (int b = 0; b < oy; ++b)
+      for (int c = 0; c < oz; ++c) {
+        const int64_t orow = ((int64_t)a * oy + b) * oz + c;
+        for (int co = 0; co < Cout; ++co) {
+          float acc = 0.f;
+          if (transposed) {
+            const int par = ((a & 1) * 2 + (b & 1)) * 2 + (c & 1);
+            const float *xi = x + (((int64_t)(a / 2) * iy + b / 2) * iz + c / 2) * Cin;
+            const float *w = wt + ((int64_t)par * Cout + co) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc += xi[ci] * w[ci];
+          } else {
+            for (int kx = 0; kx < ksize; ++kx)
+              for (int ky = 0; ky < ksize; ++ky)
+                for (int kz = 0; kz < ksize; ++kz) {
+                  const int xx = a * stride + kx - pad, yy = b * stride + ky - pad, zz = c * stride + kz - pad;
+                  if (xx < 0 || xx >= ix || yy < 0 || yy >= iy || zz < 0 || zz >= iz) continue;
+                  const float *xi = x + (((int64_t)xx * iy + yy) * iz + zz) * Cin;
+                  const float *w = wt + ((int64_t)((kx * ksize + ky) * ksize + kz) * Cout + co) * Cin;
+                  for (int ci = 0; ci < Cin; ++ci) acc += xi[ci] * w[ci];
+                }
+          }
+          float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+          if (relu == 2 && v < 0.f) v = 0.f;
+          if (residual_or_null) v += residual_or_null[orow * Cout + co];
+          if (relu == 1 && v < 0.f) v = 0.f;
+          y[orow * Cout + co] = v;
+        }
+      }
+  return SGC_OK;
+}

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sgc_view_attend": [_p] * 5 + [_i] * 5 + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
+    "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p],
 }
 
 INTROSPECTION = {

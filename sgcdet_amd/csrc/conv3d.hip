@@ -1,0 +1,281 @@
+// Implicit-GEMM 3D convolution on MFMA for gfx950, channels-last volumes.
+//
+// Replaces the dense nn.Conv3d / ConvTranspose3d + BatchNorm3d(eval) + ReLU (+ residual) chains
+// of FastIndoorImVoxelNeck (necks/imvoxelnet.py:36-64,146-173) and the three head convolutions
+// (dense_heads/imvoxel_head_v2.py:75-78).  The reference runs them through cuDNN; on ROCm torch
+// lowers them to MIOpen's Im3d2Col + GEMM (a 27x blown-up column buffer through HBM, measured
+// 14.7 of 17.8 ms per scene at config 2).  Here:
+//
+//   GEMM view   out[v, co] = sum_{tap} sum_{ci} in[nbr(v, tap), ci] * W[tap][co][ci]
+//               M = voxels, N = Cout, K = taps * Cin; no column buffer: the A tile of a K-step is
+//               gathered straight from the channels-last volume (one tap, BK consecutive
+//               channels, zero rows outside the volume) into LDS.
+//   tile        128 voxels x BN channels x 32 (K) per 256-thread workgroup, 4 waves, each wave
+//               (BM/WM x BN/WN) made of 32x32 MFMA tiles; fp32 operands on
+//               v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+//   LDS         A[128][32+4] and B[BN][32+4] floats, K contiguous, double buffered; the +4 pad
+//               makes both the ds_write_b128 rows and the ds_read_b128 fragment reads
+//               conflict-free (row stride 36 dwords -> 16 distinct 4-bank slots per lane group).
+//   fragments   lane (r = l&31, h = l>>5) reads 16 B at [row r][8*kk + 4*h]: the 4 floats feed 4
+//               consecutive MFMAs.  A and B use the same k permutation, so the sum is unchanged.
+//   pipeline    global loads of K-step s+1 are issued into registers before the MFMAs of step s
+//               and written to the other LDS buffer after them (one barrier per K-step).
+//   split-K     layers with few voxels (400 / 3200) split the taps over blockIdx.z and add
+//               partial tiles with float atomics into a zeroed output; a small epilogue kernel
+//               applies BN/ReLU/residual.  Single-pass layers fuse the epilogue.
+//   epilogue    y = acc * scale[co] + shift[co], then relu mode 1: relu(y + residual) (residual
+//               block), mode 2: relu(y) + residual (decoder skip add); scale/shift carry the
+//               folded eval-mode BatchNorm (or the conv bias).
+#include "common.hpp"
+
+namespace sgc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float *x;         // [IV, Cin] channels-last input volume
+  const float *w;         // [taps][Cout][Cin]
+  const float *scale;     // [Cout] or null (= 1)
+  const float *shift;     // [Cout] or null (= 0)
+  const float *residual;  // [OV, Cout] or null
+  float *y;               // [OV, Cout]
+  int Cin, Cout;
+  int ix, iy, iz;         // input grid
+  int gx, gy, gz;         // GEMM-row grid (conv: output grid; transposed: input grid)
+  int ksize, stride, pad; // conv geometry (transposed: ksize = 1 per parity)
+  int transposed;         // 1: ConvTranspose3d k=2 s=2, parity = blockIdx.z % 8
+  int relu;
+  int taps;               // ksize^3
+  int splitk;             // number of tap groups (divides taps); >1 -> atomic accumulate, no epilogue
+  int M;                  // gx*gy*gz
+};
+
+constexpr int BM = 128, BK = 32, LDK = BK + 4;
+
+template <int BN, int WM, int WN>  // WM x WN waves; wave tile (BM/WM) x (BN/WN)
+__global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
+  constexpr int BROWS = BN / 32;                       // B rows per thread (passes of 32 rows)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;                      // [2][BM][LDK]
+  float *Bs = smem + 2 * BM * LDK;       // [2][BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int zid = blockIdx.z;
+  int parity = 0;
+  if (p.transposed) { parity = zid % 8; zid /= 8; }
+  const int taps_per = p.taps / p.splitk;
+  const int tap_lo = zid * taps_per;
+  const int ksteps_c = p.Cin / BK;
+  const int nsteps = taps_per * ksteps_c;
+
+  // --- this thread's load slots: 4 A rows and BROWS B rows, one float4 (c4) each ---
+  const int c4 = tid & 7, r0 = tid >> 3;
+  int ax[4], ay[4], az[4];
+  bool arow_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    arow_ok[i] = m < p.M;
+    const int mm = arow_ok[i] ? m : 0;
+    az[i] = mm % p.gz;
+    ay[i] = (mm / p.gz) % p.gy;
+    ax[i] = mm / (p.gz * p.gy);
+  }
+
+  float4 ra[4], rb[BROWS];
+  auto load_step = [&](int s) {
+    const int tap = p.transposed ? parity : tap_lo + s / ksteps_c;
+    const int ci0 = (s % ksteps_c) * BK + c4 * 4;
+    int dx = 0, dy = 0, dz = 0;
+    if (!p.transposed && p.ksize > 1) {
+      dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xx = ax[i] * p.stride + dx - p.pad, yy = ay[i] * p.stride + dy - p.pad,
+                zz = az[i] * p.stride + dz - p.pad;
+      const bool ok = arow_ok[i] && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
+      ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + ci0)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      rb[i] = n < p.Cout ? *reinterpret_cast<const float4 *>(p.w + ((int64_t)tap * p.Cout + n) * p.Cin + ci0)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_step = [&](int buf) {
+    float *a = As + buf * BM * LDK, *b = Bs + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(a + (r0 + 32 * i) * LDK + c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) *reinterpret_cast<float4 *>(b + (r0 + 32 * i) * LDK + c4 * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    const float *a = As + buf * BM * LDK + (wm * (BM / WM) + fr) * LDK + fh * 4;
+    const float *b = Bs + buf * BN * LDK + (wn * (BN / WN) + fr) * LDK + fh * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4 *>(b + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nsteps) {
+      store_step(buf ^ 1);   // the other buffer was last read in step s-1, before the barrier below
+    }
+    __syncthreads();
+  }
+
+  // --- epilogue: C/D layout col = lane&31, row = (j&3) + 8*(j>>2) + 4*(lane>>5) ---
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (col >= p.Cout) continue;
+      const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        int64_t orow = m;
+        if (p.transposed) {
+          const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
+          const int px = parity >> 2, py = (parity >> 1) & 1, pz = parity & 1;
+          orow = ((int64_t)(2 * x + px) * (2 * p.gy) + (2 * y + py)) * (2 * p.gz) + (2 * z + pz);
+        }
+        float *dst = p.y + orow * p.Cout + col;
+        if (p.splitk > 1) {
+          atomicAdd(dst, acc[i][j][k]);
+        } else {
+          float v = acc[i][j][k] * sc + sh;
+          if (p.relu == 2) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[orow * p.Cout + col];
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+}
+
+__global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                     const float *__restrict__ shift, const float *__restrict__ residual,
+                                     int64_t total4, int C4, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    float4 v = reinterpret_cast<float4 *>(y)[i];
+    const float4 sc = scale ? reinterpret_cast<const float4 *>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? reinterpret_cast<const float4 *>(shift)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (residual) {
+      const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4 *>(y)[i] = v;
+  }
+}
+
+}  // namespace sgc
+
+using namespace sgc;
+
+// x [ix*iy*iz, Cin] channels-last; wt [taps][Cout][Cin]; y [ox*oy*oz, Cout].
+//   ksize 3 (pad 1) or 1 (pad 0), stride 1 or 2;  transposed = 1: ConvTranspose3d(k=2, s=2), wt [8][Cout][Cin]
+//   with parity index (px*2+py)*2+pz.  Cin must be a multiple of 32 (zero-pad the channel dim otherwise).
+extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
+                                 const float *residual_or_null, float *y,
+                                 int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                 int transposed, int relu, sgc_stream_t stream) {
+  if (!x || !wt || !y) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: null pointer");
+  if (Cin <= 0 || Cout <= 0 || ix <= 0 || iy <= 0 || iz <= 0) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: bad size");
+  if (Cin % BK) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: Cin must be a multiple of %d", BK);
+  if (((uintptr_t)x | (uintptr_t)wt | (uintptr_t)y) & 15) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: pointers must be 16-byte aligned");
+  ConvParams p = {};
+  p.x = x; p.w = wt; p.scale = scale; p.shift = shift; p.residual = residual_or_null; p.y = y;
+  p.Cin = Cin; p.Cout = Cout; p.ix = ix; p.iy = iy; p.iz = iz; p.relu = relu; p.transposed = transposed;
+  int ox, oy, oz;
+  if (transposed) {
+    if (ksize != 2 || stride != 2) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: transposed supports k=2, s=2");
+    p.gx = ix; p.gy = iy; p.gz = iz; p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1;
+    ox = 2 * ix; oy = 2 * iy; oz = 2 * iz;
+  } else {
+    if (!((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2)))
+      return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: ksize in {1,3}, stride in {1,2}");
+    p.pad = ksize / 2; p.ksize = ksize; p.stride = stride; p.taps = ksize * ksize * ksize;
+    ox = (ix + 2 * p.pad - ksize) / stride + 1; oy = (iy + 2 * p.pad - ksize) / stride + 1;
+    oz = (iz + 2 * p.pad - ksize) / stride + 1;
+    p.gx = ox; p.gy = oy; p.gz = oz;
+  }
+  p.M = p.gx * p.gy * p.gz;
+  const int64_t OV = (int64_t)ox * oy * oz;
+  const bool narrow = Cout <= 32;
+  const int bn = narrow ? 32 : 128;
+  const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
+  // split the taps until the grid covers the chip (>= 2 workgroups per CU), 27 = 3*3*3
+  int splitk = 1;
+  if (!transposed && p.taps == 27) {
+    const int64_t blocks = (int64_t)mb * nb;
+    while (splitk < 27 && blocks * splitk < 512) splitk *= 3;
+  }
+  p.splitk = splitk;
+  hipStream_t st = (hipStream_t)stream;
+  if (splitk > 1) {
+    hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
+    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_f32: memset: %s", hipGetErrorString(e));
+  }
+  const dim3 grid(mb, nb, (transposed ? 8 : 1) * splitk);
+  const size_t smem = (size_t)2 * (BM + bn) * LDK * sizeof(float);
+  if (narrow) {
+    hipLaunchKernelGGL((conv3d_igemm_f32_kernel<32, 4, 1>), grid, dim3(256), smem, st, p);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void *)conv3d_igemm_f32_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+  }
+  int rc = check_launch("conv3d_igemm_f32_kernel");
+  if (rc) return rc;
+  if (splitk > 1) {
+    if (Cout % 4) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: split-K path needs Cout %% 4 == 0");
+    const int64_t total4 = OV * Cout / 4;
+    const int g = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_epilogue_kernel, dim3(g), dim3(256), 0, st, y, scale, shift, residual_or_null, total4,
+                       Cout / 4, relu);
+    rc = check_launch("conv_epilogue_kernel");
+  }
+  return rc;
+}

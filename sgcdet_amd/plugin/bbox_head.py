@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
+from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
 
 
 @torch.no_grad()
@@ -60,8 +61,38 @@ class ImVoxelHeadV2(nn.Module):
         normal_init(self.reg_conv, std=0.01)
         normal_init(self.cls_conv, std=0.01, bias=bias_init_with_prob(0.01))
 
+    def _plan(self):
+        """The three 3x3x3 convolutions share their input: one fused conv with
+        Cout = 1 + n_reg + n_classes (centerness | reg | cls) on the MFMA kernel."""
+        fp = module_fingerprint(self)
+        if getattr(self, "_hip_plan", None) is not None and self._hip_plan[0] == fp:
+            return self._hip_plan[1]
+        w = torch.cat([self.centerness_conv.weight, self.reg_conv.weight, self.cls_conv.weight], 0)
+        n_reg = self.reg_conv.weight.shape[0]
+        bias = torch.cat([self.cls_conv.bias.new_zeros(1 + n_reg), self.cls_conv.bias])
+        spec = ConvSpec(w, None, bias=bias, ksize=3, pad_out=False)
+        self._hip_plan = (fp, (spec, n_reg))
+        return self._hip_plan[1]
+
+    def _forward_hip(self, feats):
+        spec, n_reg = self._plan()
+        ctr, reg, cls = [], [], []
+        for x, scale in zip(feats, self.scales):
+            rows, grid = to_channels_last_rows(x)
+            y, g = spec(rows, grid)
+            full = rows_to_ncdhw(y, g, spec.cout)
+            ctr.append(full[:, :1])
+            reg.append(self._reg_activation(full[:, 1:1 + n_reg], scale))
+            cls.append(full[:, 1 + n_reg:])
+        return ctr, reg, cls
+
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled() and x[0].is_cuda and x[0].shape[0] == 1:
+            return self._forward_hip(x)
         return multi_apply(self.forward_single, x, self.scales)
+
+    def _reg_activation(self, reg, scale):
+        raise NotImplementedError
 
     @torch.no_grad()
     def get_points(self, featmap_sizes, origin, device):
@@ -123,6 +154,9 @@ class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
     def forward_single(self, x, scale):
         return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
 
+    def _reg_activation(self, reg, scale):
+        return torch.exp(scale(reg))
+
     def _bbox_pred_to_bbox(self, points, bbox_pred):
         """point -/+ distances -> (x0,y0,z0,x1,y1,z1), :456-464."""
         lo = points - bbox_pred[:, [0, 2, 4]]
@@ -149,6 +183,9 @@ class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
     def forward_single(self, x, scale):
         reg = self.reg_conv(x)
         return self.centerness_conv(x), torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1), self.cls_conv(x)
+
+    def _reg_activation(self, reg, scale):
+        return torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1)
 
     @staticmethod
     def _bbox_pred_to_bbox(points, bbox_pred):

@@ -1,0 +1,70 @@
+"""Eval-mode lowering of the neck / head convolution chains onto ``sgc_conv3d_cl_f32``.
+
+BatchNorm3d (running statistics) is folded into a per-channel scale/shift applied in the
+kernel's epilogue, weights are permuted once to the kernel's ``[tap][Cout][Cin]`` layout, and
+channel counts are zero-padded to multiples of 32 (the K tile) -- a no-op for every SGCDet
+config (128 ... 1024 channels).  Plans are cached per module and rebuilt when a parameter or
+buffer changes (``Tensor._version``) or moves device.
+"""
+import torch
+
+from .. import ext
+
+_PAD = 32
+
+
+def _pad_to(n, m=_PAD):
+    return (n + m - 1) // m * m
+
+
+class ConvSpec:
+    """One prepared convolution: wt [taps, Cout_p, Cin_p], scale/shift [Cout_p]."""
+
+    def __init__(self, weight, bn=None, bias=None, ksize=3, stride=1, transposed=False, pad_out=True):
+        w = weight.detach().float()
+        if transposed:                       # nn.ConvTranspose3d weight [Cin, Cout, 2, 2, 2]
+            cin, cout = w.shape[0], w.shape[1]
+            wt = w.permute(2, 3, 4, 1, 0).reshape(8, cout, cin)
+        else:                                # nn.Conv3d weight [Cout, Cin, k, k, k]
+            cout, cin = w.shape[0], w.shape[1]
+            wt = w.permute(2, 3, 4, 0, 1).reshape(ksize ** 3, cout, cin)
+        cin_p = _pad_to(cin)
+        cout_p = _pad_to(cout) if pad_out else _pad_to(cout, 4)
+        wp = torch.zeros((wt.shape[0], cout_p, cin_p), dtype=torch.float32, device=w.device)
+        wp[:, :cout, :cin] = wt
+        scale = torch.ones(cout_p, dtype=torch.float32, device=w.device)
+        shift = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+        if bn is not None:                   # y = (x - mean) / sqrt(var + eps) * gamma + beta
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            scale[:cout] = s
+            shift[:cout] = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+        if bias is not None:
+            shift[:cout] += bias.detach().float() * scale[:cout]
+        self.wt, self.scale, self.shift = wp.contiguous(), scale, shift
+        self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
+        self.ksize, self.stride, self.transposed = ksize, stride, transposed
+
+    def __call__(self, x, grid, residual=None, relu=0):
+        return ext.ops().conv3d_cl(x, self.wt, grid, self.ksize, self.stride, self.transposed, self.scale,
+                                   self.shift, residual, relu)
+
+
+def module_fingerprint(module):
+    return tuple((t.data_ptr(), t._version, t.device) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def to_channels_last_rows(x):
+    """[1,C,X,Y,Z] (any strides) -> ([X*Y*Z, C_padded] contiguous rows, (X,Y,Z)); no copy when the
+    tensor already is channels-last in memory and C % 32 == 0."""
+    _, C, X, Y, Z = x.shape
+    rows = x[0].permute(1, 2, 3, 0).reshape(X * Y * Z, C)          # view if channels-last, copy otherwise
+    cp = _pad_to(C)
+    if cp != C:
+        rows = torch.nn.functional.pad(rows, (0, cp - C))
+    return rows.contiguous().float(), (X, Y, Z)
+
+
+def rows_to_ncdhw(rows, grid, channels):
+    """[V, Cp] rows -> [1, channels, X, Y, Z] view (channels-last memory, no copy)."""
+    X, Y, Z = grid
+    return rows.view(X, Y, Z, rows.shape[1])[..., :channels].permute(3, 0, 1, 2).unsqueeze(0)

@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from ..mmcv_lite import NECKS
+from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
 
 
 class BasicBlock3dV2(nn.Module):
@@ -63,8 +64,55 @@ class FastIndoorImVoxelNeck(nn.Module):
                     nn.ReLU(inplace=True)))
             setattr(self, f"out_block_{i}", _conv_bn_relu(width, out_channels))
 
+    # ---- eval-mode lowering onto the MFMA implicit-GEMM kernel ---------------------------
+    def _plan(self):
+        fp = module_fingerprint(self)
+        if getattr(self, "_hip_plan", None) is not None and self._hip_plan[0] == fp:
+            return self._hip_plan[1]
+        plan = {}
+        for i in range(self.n_scales):
+            blocks = []
+            for blk in getattr(self, f"down_layer_{i}"):
+                blocks.append(dict(
+                    c1=ConvSpec(blk.conv1.weight, blk.norm1, ksize=3, stride=blk.stride),
+                    c2=ConvSpec(blk.conv2.weight, blk.norm2, ksize=3),
+                    ds=ConvSpec(blk.downsample[0].weight, blk.downsample[1], ksize=1, stride=blk.stride)
+                    if blk.stride != 1 else None))
+            plan[f"down_{i}"] = blocks
+            if i > 0:
+                up = getattr(self, f"up_block_{i}")
+                plan[f"up_{i}"] = (ConvSpec(up[0].weight, up[1], ksize=2, stride=2, transposed=True),
+                                   ConvSpec(up[3].weight, up[4], ksize=3))
+            ob = getattr(self, f"out_block_{i}")
+            plan[f"out_{i}"] = ConvSpec(ob[0].weight, ob[1], ksize=3)
+        self._hip_plan = (fp, plan)
+        return plan
+
+    def _forward_hip(self, x):
+        plan = self._plan()
+        rows, grid = to_channels_last_rows(x)
+        skips = []
+        for i in range(self.n_scales):
+            for b in plan[f"down_{i}"]:
+                h, g1 = b["c1"](rows, grid, relu=1)
+                skip = rows if b["ds"] is None else b["ds"](rows, grid)[0]
+                rows, grid = b["c2"](h, g1, residual=skip, relu=1)
+            skips.append((rows, grid))
+        outs = []
+        for i in reversed(range(self.n_scales)):
+            if i < self.n_scales - 1:
+                up_t, up_c = plan[f"up_{i + 1}"]
+                h, g = up_t(rows, grid, relu=1)
+                rows, grid = up_c(h, g, residual=skips[i][0], relu=2)      # relu(bn(conv)) + skip
+            spec = plan[f"out_{i}"]
+            o, g = spec(rows, grid, relu=1)
+            outs.append(rows_to_ncdhw(o, g, spec.cout))
+        return outs[::-1]
+
     def forward(self, x):
         """[1,C,nx,ny,nz] -> [out@1x, out@1/2, out@1/4], finest first (imvoxelnet.py:22-34)."""
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.shape[0] == 1:
+            return self._forward_hip(x)
         skips = []
         for i in range(self.n_scales):
             x = getattr(self, f"down_layer_{i}")(x)

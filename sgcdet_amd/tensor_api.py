@@ -298,3 +298,29 @@ class TensorOps:
         dst = torch.empty((N, H * W, Cc), dtype=torch.float32, device=src.device)
         self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W)
         return dst
+
+    # ---- 7. channels-last 3D convolution -----------------------------------------------
+    def conv3d_cl(self, x, wt, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
+                  residual=None, relu=False):
+        """x [X*Y*Z, Cin] channels-last; wt [taps, Cout, Cin]; grid = (X, Y, Z) of the input;
+        relu: 0/False none, 1/True relu(t + residual), 2 relu(t) + residual.
+        Returns (y [OX*OY*OZ, Cout], (OX, OY, OZ))."""
+        self._check(x=x, wt=wt, scale=scale, shift=shift, residual=residual)
+        self._f32(x=x, wt=wt, scale=scale, shift=shift, residual=residual)
+        ix, iy, iz = grid
+        V, Cin = x.shape
+        taps, Cout, Cin2 = wt.shape
+        if V != ix * iy * iz or Cin2 != Cin or taps != (8 if transposed else ksize ** 3):
+            raise RuntimeError("conv3d_cl: inconsistent shapes")
+        if transposed:
+            og = (2 * ix, 2 * iy, 2 * iz)
+        else:
+            pad = ksize // 2
+            og = tuple((d + 2 * pad - ksize) // stride + 1 for d in grid)
+        y = torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
+        if residual is not None and residual.shape != y.shape:
+            raise RuntimeError("conv3d_cl: residual shape mismatch")
+        self._call("sgc_conv3d_cl_f32", x, wt, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize, stride,
+                   1 if transposed else 0, int(relu),
+                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
+        return y, og

@@ -1,0 +1,33 @@
+"""The oracle's naive channels-last convolution == torch conv3d / conv_transpose3d (CPU)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def cl(x):
+    return x[0].permute(1, 2, 3, 0).reshape(-1, x.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("Cin,Cout,g,k,s", [(32, 8, (6, 5, 4), 3, 1), (32, 16, (6, 6, 4), 3, 2), (64, 8, (5, 4, 3), 1, 2)])
+def test_conv_matches_torch(Cin, Cout, g, k, s, oracle_ops):
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, Cin, *g, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, k, generator=gen) * 0.1
+    sc, sh = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    ref = F.conv3d(x, w, None, s, k // 2)
+    res = torch.randn(ref.shape, generator=gen)
+    want = F.relu(ref * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) + res)
+    wt = w.permute(2, 3, 4, 0, 1).reshape(k ** 3, Cout, Cin).contiguous()
+    y, og = oracle_ops.conv3d_cl(cl(x), wt, g, k, s, False, sc, sh, cl(res), True)
+    assert og == tuple(ref.shape[2:])
+    assert (y - cl(want)).abs().max() < 2e-5
+
+
+def test_transposed_conv_matches_torch(oracle_ops):
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 32, 3, 4, 2, generator=gen)
+    w = torch.randn(32, 8, 2, 2, 2, generator=gen) * 0.1
+    ref = F.conv_transpose3d(x, w, None, 2)
+    wt = w.permute(2, 3, 4, 1, 0).reshape(8, 8, 32).contiguous()
+    y, og = oracle_ops.conv3d_cl(cl(x), wt, (3, 4, 2), 2, 2, True)
+    assert og == (6, 8, 4) and (y - cl(ref)).abs().max() < 1e-5

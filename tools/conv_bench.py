@@ -1,0 +1,31 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+from sgcdet_amd import ext
+ops = ext.ops()
+layers = [  # name, Cin, Cout, grid, k, s, transposed
+ ("down0.conv 256->256 @40x40x16", 256,256,(40,40,16),3,1,False),
+ ("out0 256->128 @40x40x16", 256,128,(40,40,16),3,1,False),
+ ("down1.conv1 256->512 s2", 256,512,(40,40,16),3,2,False),
+ ("down1.conv2 512->512 @20x20x8", 512,512,(20,20,8),3,1,False),
+ ("out1 512->128 @20x20x8", 512,128,(20,20,8),3,1,False),
+ ("down2.conv1 512->1024 s2", 512,1024,(20,20,8),3,2,False),
+ ("down2.conv2 1024->1024 @10x10x4", 1024,1024,(10,10,4),3,1,False),
+ ("out2 1024->128 @10x10x4", 1024,128,(10,10,4),3,1,False),
+ ("up2.convT 1024->512", 1024,512,(10,10,4),2,2,True),
+ ("up1.convT 512->256", 512,256,(20,20,8),2,2,True),
+ ("ds1 1x1 s2 256->512", 256,512,(40,40,16),1,2,False),
+ ("head 128->32 @40x40x16", 128,32,(40,40,16),3,1,False),
+]
+for name,Cin,Cout,g,k,s,tr in layers:
+    V=g[0]*g[1]*g[2]
+    x=torch.randn(V,Cin,device='cuda'); taps=8 if tr else k**3
+    wt=torch.randn(taps,Cout,Cin,device='cuda')*0.01
+    sc=torch.ones(Cout,device='cuda'); sh=torch.zeros(Cout,device='cuda')
+    for _ in range(3): y,og=ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    n=10
+    for _ in range(n): y,og=ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/n
+    OV=og[0]*og[1]*og[2]
+    fl = 2*Cin*Cout*OV*(1 if tr else taps)
+    print(f"{name:36s} {dt*1e6:9.1f} us  {fl/dt/1e12:7.2f} TFLOP/s")
