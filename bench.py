@@ -97,17 +97,16 @@ def cpu_baseline(w, n_views, seed):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    from sgcdet_amd import dist as sgc_dist
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rank, world, _ = sgc_dist.init_from_env(backend="nccl", device=device)   # "nccl" is RCCL on ROCm
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)   # RCCL on ROCm
 
     from sgcdet_amd.scene import make_scene, workload
     from sgcdet_amd import ext
@@ -144,10 +143,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     log, ops.event_log = ops.event_log, None
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sgc_dist.max_over_ranks(elapsed, device=device)
 
     # ---- roofline of the dominant hand-written kernel: finest-level deformable gather ----
     per_kernel = {}

@@ -1,0 +1,93 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, ``torch.distributed`` over RCCL.
+
+The path shards by SCENE (the reference hard-wires one scene per GPU per step,
+mmdet3d_plugin/models/im2voxel/AdaptiveSparseHead.py:45, and shards scenes with a
+DistributedSampler, LightningTools/dataset_dm.py:30-37):
+
+* inference / benchmark: scenes are dealt round-robin to ranks, NO data-path collective; the only
+  collectives are the barrier and the MAX-reduction of the elapsed time;
+* training: one exchange per step -- the gradient all-reduce (reference: torch DDP under Lightning,
+  main.py:64-70).  ``BucketedGradAllReduce`` does it with few, large flat buckets: xGMI is
+  point-to-point (7 links x ~153 GB/s per GPU), so ring collectives are per-link bound and per-call
+  latency matters more than on a switched fabric; ~80 M hot-path parameters = 320 MB fp32 go out in
+  <= 5 asynchronous all-reduces that overlap with the remaining backward.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None, device=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
+    Returns (rank, world, local_rank); a no-op for world == 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def shard_scenes(n_scenes, rank, world, pad=True):
+    """Indices of the scenes rank ``rank`` processes: strided like DistributedSampler(shuffle=False);
+    with ``pad`` every rank gets ceil(n/world) items (wrap-around) so ranks stay in lock-step."""
+    idx = list(range(n_scenes))
+    if pad and n_scenes % world:
+        idx += idx[: world - n_scenes % world]
+    return idx[rank::world]
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX-reduce a python float over all ranks (bench timing contract)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class BucketedGradAllReduce:
+    """Averages ``.grad`` of the given parameters over all ranks with flat buckets.
+
+    Parameters without a gradient (the reference runs DDP with ``find_unused_parameters=True``:
+    e.g. heads whose loss is switched off) contribute zeros, exactly like DDP."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+
+    def __call__(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        pending = []
+        for bucket in self.buckets:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            pending.append((bucket, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)))
+        for bucket, flat, work in pending:
+            work.wait()
+            flat.div_(world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n

@@ -1,0 +1,95 @@
+"""CPU checks of the boundary: the HIP library loads and exports every symbol declared in
+include/sgcdet_amd.h (no compute calls without a GPU), the oracle exports the same set, and the
+reference's four configs build unchanged through the registry surface."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sgcdet_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_match_binding_table():
+    from sgcdet_amd._abi import SIGNATURES, INTROSPECTION
+    assert _declared_symbols() == sorted(list(SIGNATURES) + list(INTROSPECTION))
+
+
+def test_hip_library_loads_and_exports_every_symbol():
+    from sgcdet_amd import build
+    from sgcdet_amd._abi import Library
+    lib = Library(build.build())            # raises ImportError on a missing symbol / ABI mismatch
+    assert lib.backend == "hip-gfx950"
+
+
+def test_oracle_exports_the_same_abi(oracle_ops):
+    assert oracle_ops.lib.backend == "cpu-oracle"
+
+
+def test_product_has_no_cpu_fallback():
+    from sgcdet_amd import ext
+    x = torch.zeros(1, 4, 1, 4)
+    with pytest.raises(RuntimeError):
+        ext.wms_deform_attn_forward(x, torch.tensor([[2, 2]]), torch.zeros(1, dtype=torch.int64),
+                                    torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1),
+                                    torch.zeros(1, 1, 1, 1, 1, 4), im2col_step=64)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sgcdet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+REF_CONFIGS = "/root/reference/configs"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("name,params_m", [("SGCDet_ScanNet", 79.75), ("SGCDet_ARKit", 79.74),
+                                           ("SGCDet_large_ScanNet200", 22.17), ("SGCDet_large_ARKit", 21.58)])
+def test_reference_configs_build_unchanged(name, params_m):
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import Config, build_detector
+    cfg = Config.fromfile(os.path.join(REF_CONFIGS, name + ".py"))
+    det = build_detector(cfg.model)
+    n = sum(p.numel() for p in det.parameters()) / 1e6
+    assert abs(n - params_m) < 0.02, n
+    keys = det.state_dict().keys()
+    for k in ("voxel_head.base_heads.0.ref_3d",
+              "voxel_head.base_heads.2.cross_transformer.encoder.layers.0.attentions.0.deformable_attention.sampling_offsets_depth.bias",
+              "voxel_head.base_heads.1.cross_transformer.encoder.layers.0.attentions.0.attention_pooling.in_proj_weight",
+              "voxel_head.base_heads.0.cross_transformer.encoder.layers.0.ffns.0.layers.0.0.weight",
+              "voxel_head.occ_pred_heads.1.0.bias", "neck_3d.down_layer_1.0.downsample.1.running_var",
+              "neck_3d.up_block_2.3.weight", "neck_3d.out_block_0.1.weight", "bbox_head.scales.2.scale",
+              "bbox_head.cls_conv.bias"):
+        assert k in keys, k
+
+
+def test_module_init_matches_reference_golden_shapes():
+    """The golden state dict (written by the reference's own classes) loads strictly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load
+    import sgcdet_amd.plugin as P
+    from sgcdet_amd.mmcv_lite import build_head
+    from sgcdet_amd.scene import model_config
+    d, sd = load("voxel_head")
+    w = dict(embed_dims=32, n_voxels_list=[tuple(int(v) for v in g) for g in d["grids"]],
+             voxel_size_list=[tuple(float(v) for v in s) for s in d["sizes"]], topk_list=[int(v) for v in d["topk"]],
+             head="ScanNetImVoxelHeadV2", n_classes=18, n_reg_outs=6)
+    head = build_head(model_config(w)["voxel_head"])
+    for i in range(3):      # buffers computed by DenseHead.get_voxel_indices == the reference's (before loading)
+        assert torch.equal(head.base_heads[i].vox_coords, sd[f"base_heads.{i}.vox_coords"])
+        assert torch.equal(head.base_heads[i].ref_3d, sd[f"base_heads.{i}.ref_3d"])
+    head.load_state_dict(sd, strict=True)
+    _, nsd = load("neck")
+    P.FastIndoorImVoxelNeck(in_channels=16, n_blocks=[1, 1, 1], out_channels=8).load_state_dict(nsd, strict=True)

@@ -1,0 +1,65 @@
+"""World-size-2 gloo tests (CPU) of the N>1 plumbing: scene sharding, MAX timing reduction and the
+bucketed gradient all-reduce on the (torch-path) neck in training mode."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sgcdet_amd import dist as sd
+    from sgcdet_amd.plugin.neck3d import FastIndoorImVoxelNeck
+    torch.set_num_threads(1)
+    r, w, _ = sd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    mine = sd.shard_scenes(5, rank, world)
+    slowest = sd.max_over_ranks(1.0 + rank)
+    # one scene per rank through the (CPU, torch) training path of the neck, then gradient averaging
+    torch.manual_seed(0)
+    neck = FastIndoorImVoxelNeck(in_channels=8, n_blocks=[1, 1, 1], out_channels=4).train()
+    scenes = [torch.randn(1, 8, 8, 8, 4, generator=torch.Generator().manual_seed(100 + i)) for i in range(world)]
+    loss = sum(o.square().mean() for o in neck(scenes[rank]))
+    loss.backward()
+    sd.BucketedGradAllReduce(neck.parameters(), bucket_bytes=1 << 12)()
+    grads = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
+    if rank == 0:
+        torch.save(dict(mine=mine, slowest=slowest, grads=grads), out)
+    else:
+        torch.save(dict(mine=mine), out + ".1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sharding_and_grad_allreduce(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out), torch.load(out + ".1")
+    assert r0["mine"] == [0, 2, 4] and r1["mine"] == [1, 3, 0]      # padded strided sharding
+    assert r0["slowest"] == 2.0                                      # MAX over ranks
+    # single-process reference: mean of the two per-scene gradients (BatchNorm sees one scene at a time)
+    from sgcdet_amd.plugin.neck3d import FastIndoorImVoxelNeck
+    ref = []
+    for i in range(2):
+        torch.manual_seed(0)
+        neck = FastIndoorImVoxelNeck(in_channels=8, n_blocks=[1, 1, 1], out_channels=4).train()
+        x = torch.randn(1, 8, 8, 8, 4, generator=torch.Generator().manual_seed(100 + i))
+        sum(o.square().mean() for o in neck(x)).backward()
+        ref.append(torch.cat([p.grad.reshape(-1) for p in neck.parameters()]))
+    want = (ref[0] + ref[1]) / 2
+    assert torch.allclose(r0["grads"], want, rtol=1e-5, atol=1e-7)
