@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_scannet")
     ap.add_argument("--views", type=int, default=None, help="override the number of views")
+    ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="neck/head convolution arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
+                         "default) or exact fp32 products on the fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     return ap.parse_args()
@@ -110,6 +113,8 @@ def main():
 
     from sgcdet_amd.scene import make_scene, workload
     from sgcdet_amd import ext
+    from sgcdet_amd.plugin.conv_plan import set_conv_mode
+    set_conv_mode(args.conv_mode)
     w = workload(args.workload)
     n_views = args.views or w["n_views"]
     det = build_path(w, device)
@@ -134,6 +139,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.event_log = []
+    ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather"}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -179,7 +185,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)",
             "data": "synthetic",
             "config": {"workload": f"{w['name']}: {n_views} views x {w['embed_dims']} ch, FPN maps 60x80/30x40/15x20, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "

@@ -53,6 +53,9 @@ extern "C" {
 typedef void *sgc_stream_t; /* hipStream_t */
 
 int sgc_abi_version(void);
+/* Development knob (A/B of kernel variants in one process); keys: "fwd_variant" (0 block-barrier,
+ * 1 wave-private gather).  Results never depend on it.                                        */
+int sgc_set_tuning(const char *key, int value);
 const char *sgc_last_error(void);
 /* "hip-gfx950" for the product library, "cpu-oracle" for oracle/libsgc_oracle.so */
 const char *sgc_backend(void);
@@ -252,6 +255,17 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
                       const float *residual_or_null, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                       int transposed, int relu, sgc_stream_t stream);
+
+/* Same contract on the bf16 matrix cores with fp32-faithful results: every fp32 operand is split
+ * as v = hi + lo (two bf16); the products hi*hi + hi*lo + lo*hi run on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (the dropped lo*lo term is 2^-16 relative).  w_hi / w_lo [taps][Cout][Cin] are the
+ * host-side split of the fp32 weights (raw bf16 bit patterns): w_hi = bf16_rne(w), w_lo = bf16_rne(w - w_hi).
+ * Activations are fp32 in memory and split while staged into LDS.  Agreement with sgc_conv3d_cl_f32:
+ * ~1e-5 of the tensor scale (tests: 1e-4).                                                      */
+int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                         const float *shift, const float *residual_or_null, float *y,
+                         int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                         int transposed, int relu, sgc_stream_t stream);
 
 #ifdef __cplusplus
 }

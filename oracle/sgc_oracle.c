@@ -45,6 +45,7 @@ static int fail(int code, const char *msg) {
 }
 
 int sgc_abi_version(void) { return SGC_ABI_VERSION; }
+int sgc_set_tuning(const char *key, int value) { (void)key; (void)value; return SGC_OK; }
 const char *sgc_last_error(void) { return g_err; }
 const char *sgc_backend(void) { return "cpu-oracle"; }
 
@@ -664,4 +665,24 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
         }
       }
   return SGC_OK;
+}
+
+/* bf16x3 entry point: the oracle is the fp32 truth -- it rebuilds w = float(hi) + float(lo) and runs
+ * the naive fp32 convolution above. */
+#include <stdlib.h>
+static float bf16_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
+int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                         const float *shift, const float *residual_or_null, float *y,
+                         int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                         int transposed, int relu, sgc_stream_t stream) {
+  if (!w_hi || !w_lo) return fail(SGC_EINVAL, "null pointer");
+  const int taps = transposed ? 8 : ksize * ksize * ksize;
+  const size_t n = (size_t)taps * Cout * Cin;
+  float *w = (float *)malloc(n * sizeof(float));
+  if (!w) return fail(SGC_EINVAL, "out of memory");
+  for (size_t i = 0; i < n; ++i) w[i] = bf16_to_f32(w_hi[i]) + bf16_to_f32(w_lo[i]);
+  const int rc = sgc_conv3d_cl_f32(x, w, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride,
+                                   transposed, relu, stream);
+  free(w);
+  return rc;
 }

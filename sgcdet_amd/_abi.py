@@ -28,6 +28,8 @@ SIGNATURES = {
     "sgc_scatter_rows": [_p] * 4 + [_i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p],
+    "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_set_tuning": [C.c_char_p, _i],
 }
 
 INTROSPECTION = {

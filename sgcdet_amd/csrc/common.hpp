@@ -31,6 +31,8 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
   return x * base + (x < rem ? x : rem) + j;
 }
 
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 4-byte aligned pair load
+
 // One trilinear sample of the DFA3D operator, reduced to what the gather needs:
 // 4 corner weights (bilinear * depth score * attention weight) and 4 pixel indices
 // (-1 = corner outside the map).  Semantics: ms_depth_score_sample_cuda_kernel.cuh:24-148
@@ -71,9 +73,19 @@ __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict_
     sm.off[k] = use ? px[k] : -1;
     float v = 0.f;
     if (sm.in3 && ok[k]) {
+      // one 8-byte load covers (d0, d1): every depth load touches 64 different cache lines per
+      // wave instruction, so the instruction count is what the L1/TA path pays for
       const float *p = dist_px0 + (int64_t)px[k] * pix_stride;
-      const float va = d0 >= 0 ? p[d0] : 0.f;
-      const float vb = d1 <= D - 1 ? p[d1] : 0.f;
+      float va, vb;
+      if (D >= 2) {
+        const int base = d0 < 0 ? 0 : (d0 > D - 2 ? D - 2 : d0);
+        const float2_u pr = *reinterpret_cast<const float2_u *>(p + base);
+        va = d0 < 0 ? 0.f : (d0 == base ? pr.x : pr.y);
+        vb = d1 > D - 1 ? 0.f : (d0 == base ? pr.y : pr.x);
+      } else {
+        va = d0 >= 0 ? p[d0] : 0.f;
+        vb = d1 <= D - 1 ? p[d1] : 0.f;
+      }
       v = va * hd + vb * sm.ld;
     }
     sc[k] = v;

@@ -188,6 +188,186 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16x3 variant: fp32 operands split as a = a_hi + a_lo (two bf16 each), products
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 x bf16
+// products are exact in fp32, the dropped a_lo*b_lo term is 2^-16 relative: the result agrees with
+// the fp32 kernel to ~1e-5 (tests bound it at 1e-4 of the tensor scale, north-star bar 1e-3) at
+// 3/16 of the fp32-MFMA cycles.  Activations stay fp32 in HBM and are split while they are staged
+// into LDS; weights are split once on the host.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDKH = BK + 8;   // bf16 elements per LDS row (80 B): conflict-free ds_read_b128
+
+struct ConvParamsB : ConvParams {
+  const __bf16 *w_hi, *w_lo;   // [taps][Cout][Cin]
+};
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvParamsB p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int BCH = BN * 4 / 256;                    // 16-byte weight chunks per thread per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  // per buffer: A_hi[BM][LDKH], A_lo[BM][LDKH], B_hi[BN][LDKH], B_lo[BN][LDKH]
+  constexpr int A_PLANE = BM * LDKH, B_PLANE = BN * LDKH, BUF = 2 * A_PLANE + 2 * B_PLANE;
+  __bf16 *base = reinterpret_cast<__bf16 *>(smem_b);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int zid = blockIdx.z;
+  int parity = 0;
+  if (p.transposed) { parity = zid % 8; zid /= 8; }
+  const int taps_per = p.taps / p.splitk;
+  const int tap_lo = zid * taps_per;
+  const int ksteps_c = p.Cin / BK;
+  const int nsteps = taps_per * ksteps_c;
+
+  const int c4 = tid & 7, r0 = tid >> 3;        // A: row r0 + 32 i, 4 floats at c4*4
+  const int bc = tid & 3, br0 = tid >> 2;       // B: row br0 + 64 i, 8 bf16 at bc*8
+  int ax[4], ay[4], az[4];
+  bool arow_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    arow_ok[i] = m < p.M;
+    const int mm = arow_ok[i] ? m : 0;
+    az[i] = mm % p.gz;
+    ay[i] = (mm / p.gz) % p.gy;
+    ax[i] = mm / (p.gz * p.gy);
+  }
+  float4 ra[4];
+  uint4 rbh[BCH], rbl[BCH];
+  auto load_step = [&](int s) {
+    const int tap = p.transposed ? parity : tap_lo + s / ksteps_c;
+    const int cib = (s % ksteps_c) * BK;
+    int dx = 0, dy = 0, dz = 0;
+    if (!p.transposed && p.ksize > 1) {
+      dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xx = ax[i] * p.stride + dx - p.pad, yy = ay[i] * p.stride + dy - p.pad,
+                zz = az[i] * p.stride + dz - p.pad;
+      const bool ok = arow_ok[i] && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
+      ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + cib + c4 * 4)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int n = n0 + br0 + 64 * i;
+      const int64_t off = ((int64_t)tap * p.Cout + n) * p.Cin + cib + bc * 8;
+      if (n < p.Cout) {
+        rbh[i] = *reinterpret_cast<const uint4 *>(p.w_hi + off);
+        rbl[i] = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+      } else {
+        rbh[i] = make_uint4(0, 0, 0, 0);
+        rbl[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    __bf16 *a_hi = base + buf * BUF, *a_lo = a_hi + A_PLANE, *b_hi = a_lo + A_PLANE, *b_lo = b_hi + B_PLANE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)v[e];
+        h[e] = hb;
+        l[e] = (__bf16)(v[e] - (float)hb);
+      }
+      const int o = (r0 + 32 * i) * LDKH + c4 * 4;
+      *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
+      *reinterpret_cast<bf16x4 *>(a_lo + o) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int o = (br0 + 64 * i) * LDKH + bc * 8;
+      *reinterpret_cast<uint4 *>(b_hi + o) = rbh[i];
+      *reinterpret_cast<uint4 *>(b_lo + o) = rbl[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_step(s + 1);
+    const __bf16 *a_hi = base + buf * BUF + (wm * (BM / WM) + fr) * LDKH + fh * 8;
+    const __bf16 *a_lo = a_hi + A_PLANE;
+    const __bf16 *b_hi = base + buf * BUF + 2 * A_PLANE + (wn * (BN / WN) + fr) * LDKH + fh * 8;
+    const __bf16 *b_lo = b_hi + B_PLANE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + i * 32 * LDKH + kk * 16);
+        al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + i * 32 * LDKH + kk * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8 *>(b_hi + j * 32 * LDKH + kk * 16);
+        bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + j * 32 * LDKH + kk * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nsteps) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (col >= p.Cout) continue;
+      const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        int64_t orow = m;
+        if (p.transposed) {
+          const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
+          const int px = parity >> 2, py = (parity >> 1) & 1, pz = parity & 1;
+          orow = ((int64_t)(2 * x + px) * (2 * p.gy) + (2 * y + py)) * (2 * p.gz) + (2 * z + pz);
+        }
+        float *dst = p.y + orow * p.Cout + col;
+        if (p.splitk > 1) {
+          atomicAdd(dst, acc[i][j][k]);
+        } else {
+          float v = acc[i][j][k] * sc + sh;
+          if (p.relu == 2) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[orow * p.Cout + col];
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+}
+
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
                                      const float *__restrict__ shift, const float *__restrict__ residual,
                                      int64_t total4, int C4, int relu) {
@@ -211,6 +391,50 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 
 using namespace sgc;
 
+static int conv_setup(ConvParams &p, const char *who, const float *x, const void *w1, const void *w2, float *y,
+                      int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride, int transposed, int relu,
+                      int &ox, int &oy, int &oz) {
+  if (!x || !w1 || !w2 || !y) return set_error(SGC_EINVAL, "%s: null pointer", who);
+  if (Cin <= 0 || Cout <= 0 || ix <= 0 || iy <= 0 || iz <= 0) return set_error(SGC_EINVAL, "%s: bad size", who);
+  if (Cin % BK) return set_error(SGC_EUNSUP, "%s: Cin must be a multiple of %d", who, BK);
+  if (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)y) & 15)
+    return set_error(SGC_EINVAL, "%s: pointers must be 16-byte aligned", who);
+  p.x = x; p.y = y; p.Cin = Cin; p.Cout = Cout; p.ix = ix; p.iy = iy; p.iz = iz; p.relu = relu; p.transposed = transposed;
+  if (transposed) {
+    if (ksize != 2 || stride != 2) return set_error(SGC_EUNSUP, "%s: transposed supports k=2, s=2", who);
+    p.gx = ix; p.gy = iy; p.gz = iz; p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1;
+    ox = 2 * ix; oy = 2 * iy; oz = 2 * iz;
+  } else {
+    if (!((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2)))
+      return set_error(SGC_EUNSUP, "%s: ksize in {1,3}, stride in {1,2}", who);
+    p.pad = ksize / 2; p.ksize = ksize; p.stride = stride; p.taps = ksize * ksize * ksize;
+    ox = (ix + 2 * p.pad - ksize) / stride + 1; oy = (iy + 2 * p.pad - ksize) / stride + 1;
+    oz = (iz + 2 * p.pad - ksize) / stride + 1;
+    p.gx = ox; p.gy = oy; p.gz = oz;
+  }
+  p.M = p.gx * p.gy * p.gz;
+  return SGC_OK;
+}
+
+static int pick_splitk(const ConvParams &p, int mb, int nb, int target_blocks) {
+  int splitk = 1;
+  if (!p.transposed && p.taps == 27) {
+    const int64_t blocks = (int64_t)mb * nb;
+    while (splitk < 27 && blocks * splitk < target_blocks) splitk *= 3;
+  }
+  return splitk;
+}
+
+static int conv_finish(const ConvParams &p, int64_t OV, hipStream_t st) {
+  if (p.splitk <= 1) return SGC_OK;
+  if (p.Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
+  const int64_t total4 = OV * p.Cout / 4;
+  const int g = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(conv_epilogue_kernel, dim3(g), dim3(256), 0, st, p.y, p.scale, p.shift, p.residual, total4,
+                     p.Cout / 4, p.relu);
+  return check_launch("conv_epilogue_kernel");
+}
+
 // x [ix*iy*iz, Cin] channels-last; wt [taps][Cout][Cin]; y [ox*oy*oz, Cout].
 //   ksize 3 (pad 1) or 1 (pad 0), stride 1 or 2;  transposed = 1: ConvTranspose3d(k=2, s=2), wt [8][Cout][Cin]
 //   with parity index (px*2+py)*2+pz.  Cin must be a multiple of 32 (zero-pad the channel dim otherwise).
@@ -218,44 +442,22 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
                                  const float *residual_or_null, float *y,
                                  int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                  int transposed, int relu, sgc_stream_t stream) {
-  if (!x || !wt || !y) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: null pointer");
-  if (Cin <= 0 || Cout <= 0 || ix <= 0 || iy <= 0 || iz <= 0) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: bad size");
-  if (Cin % BK) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: Cin must be a multiple of %d", BK);
-  if (((uintptr_t)x | (uintptr_t)wt | (uintptr_t)y) & 15) return set_error(SGC_EINVAL, "sgc_conv3d_cl_f32: pointers must be 16-byte aligned");
   ConvParams p = {};
-  p.x = x; p.w = wt; p.scale = scale; p.shift = shift; p.residual = residual_or_null; p.y = y;
-  p.Cin = Cin; p.Cout = Cout; p.ix = ix; p.iy = iy; p.iz = iz; p.relu = relu; p.transposed = transposed;
   int ox, oy, oz;
-  if (transposed) {
-    if (ksize != 2 || stride != 2) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: transposed supports k=2, s=2");
-    p.gx = ix; p.gy = iy; p.gz = iz; p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1;
-    ox = 2 * ix; oy = 2 * iy; oz = 2 * iz;
-  } else {
-    if (!((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2)))
-      return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: ksize in {1,3}, stride in {1,2}");
-    p.pad = ksize / 2; p.ksize = ksize; p.stride = stride; p.taps = ksize * ksize * ksize;
-    ox = (ix + 2 * p.pad - ksize) / stride + 1; oy = (iy + 2 * p.pad - ksize) / stride + 1;
-    oz = (iz + 2 * p.pad - ksize) / stride + 1;
-    p.gx = ox; p.gy = oy; p.gz = oz;
-  }
-  p.M = p.gx * p.gy * p.gz;
+  int rc = conv_setup(p, "sgc_conv3d_cl_f32", x, wt, wt, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
+  if (rc) return rc;
+  p.w = wt; p.scale = scale; p.shift = shift; p.residual = residual_or_null;
   const int64_t OV = (int64_t)ox * oy * oz;
   const bool narrow = Cout <= 32;
   const int bn = narrow ? 32 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
-  // split the taps until the grid covers the chip (>= 2 workgroups per CU), 27 = 3*3*3
-  int splitk = 1;
-  if (!transposed && p.taps == 27) {
-    const int64_t blocks = (int64_t)mb * nb;
-    while (splitk < 27 && blocks * splitk < 512) splitk *= 3;
-  }
-  p.splitk = splitk;
+  p.splitk = pick_splitk(p, mb, nb, 512);   // >= 2 workgroups per CU
   hipStream_t st = (hipStream_t)stream;
-  if (splitk > 1) {
+  if (p.splitk > 1) {
     hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
     if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_f32: memset: %s", hipGetErrorString(e));
   }
-  const dim3 grid(mb, nb, (transposed ? 8 : 1) * splitk);
+  const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (BM + bn) * LDK * sizeof(float);
   if (narrow) {
     hipLaunchKernelGGL((conv3d_igemm_f32_kernel<32, 4, 1>), grid, dim3(256), smem, st, p);
@@ -267,15 +469,46 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
     }
     hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
   }
-  int rc = check_launch("conv3d_igemm_f32_kernel");
+  rc = check_launch("conv3d_igemm_f32_kernel");
   if (rc) return rc;
-  if (splitk > 1) {
-    if (Cout % 4) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_f32: split-K path needs Cout %% 4 == 0");
-    const int64_t total4 = OV * Cout / 4;
-    const int g = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_epilogue_kernel, dim3(g), dim3(256), 0, st, y, scale, shift, residual_or_null, total4,
-                       Cout / 4, relu);
-    rc = check_launch("conv_epilogue_kernel");
+  return conv_finish(p, OV, st);
+}
+
+// Same contract with the weights pre-split on the host: w_hi = bf16(w), w_lo = bf16(w - float(w_hi)),
+// both [taps][Cout][Cin] bf16 (raw 16-bit patterns).
+extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                    const float *shift, const float *residual_or_null, float *y,
+                                    int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                    int transposed, int relu, sgc_stream_t stream) {
+  ConvParamsB p = {};
+  int ox, oy, oz;
+  int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
+  if (rc) return rc;
+  p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
+  p.scale = scale; p.shift = shift; p.residual = residual_or_null;
+  const int64_t OV = (int64_t)ox * oy * oz;
+  const bool narrow = Cout <= 64;
+  const int bn = narrow ? 64 : 128;
+  const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
+  p.splitk = pick_splitk(p, mb, nb, 512);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.splitk > 1) {
+    hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
+    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_bf16x3: memset: %s", hipGetErrorString(e));
   }
-  return rc;
+  const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
+  const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t)));
+    attr_set = true;
+  }
+  if (narrow)
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
+  else
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+  rc = check_launch("conv3d_igemm_bf16x3_kernel");
+  if (rc) return rc;
+  return conv_finish(p, OV, st);
 }

@@ -18,6 +18,8 @@
 //
 // Tiles are dealt to XCDs in contiguous chunks (common.hpp: xcd_tile) because items are
 // camera-major: neighbouring tiles hit the same camera's value map in one L2.
+#include <string.h>
+
 #include "common.hpp"
 
 namespace sgc {
@@ -175,6 +177,131 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
   }
 }
 
+
+// Wave-private variant for the pair-list modes (L = 1, SPI = M*P divides 64): every wave owns
+// IPW = 64/SPI items end to end -- descriptors are produced and consumed by the same wave, so the
+// only synchronisation is a wavefront-scope fence (LDS operations of one wave complete in order).
+// Waves of a workgroup drift apart and the dependent-load chain of phase 1 (pair -> ref -> depth)
+// of one wave overlaps the row gather of the others.  PT > 0 fixes the point count at compile time
+// so the gather of one (item, head) is fully unrolled: all 4*PT row loads are in flight together.
+template <int MODE, int PT>
+__global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) {
+  __shared__ float4 lds_w[256];
+  __shared__ int4 lds_o[256];
+  __shared__ int lds_b[256];
+  const int SPI = p.M * p.P;
+  const int IPW = kWave / SPI;               // items per wave
+  const int n_items = p.n_items >= 0 ? p.n_items : p.totals[0];
+  const int per_block = 4 * IPW;
+  const int ntiles = (n_items + per_block - 1) / per_block;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int tile = xcd_tile(blockIdx.x, ntiles);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int item0 = tile * per_block + wid * IPW;
+  if (item0 >= n_items) return;              // whole wave idle (tail)
+  const int MC = p.M * p.Cm;
+  float4 *w_ = lds_w + wid * kWave;
+  int4 *o_ = lds_o + wid * kWave;
+  int *b_ = lds_b + wid * kWave;
+
+  {  // ---- phase 1: lane = sample ----
+    const int il = lane / SPI, r = lane - il * SPI;
+    int item = item0 + il;
+    if (item >= n_items) item = n_items - 1;
+    const int m = r / p.P, pt = r - m * p.P;
+    const int b = p.pair_cam[item];
+    const int q = p.pair_q[item];
+    const float *rc = p.ref_cam + ((int64_t)b * p.Nq + q) * 3;
+    float x = rc[0], y = rc[1], z = rc[2], aw = 1.f;
+    if (MODE == kPairsDeform) {
+      const int MP = p.M * p.P;
+      const float *rw = p.raw + (int64_t)item * MP * 4;
+      const int mp = m * p.P + pt;
+      const float2 uv = *reinterpret_cast<const float2 *>(rw + mp * 2);
+      x = x + uv.x / (float)p.W;
+      y = y + uv.y / (float)p.H;
+      z = z + rw[MP * 2 + mp] / (float)p.D;
+      const float lg = rw[MP * 3 + mp];
+      float mx = lg;
+      for (int o = 1; o < p.P; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float e = expf(lg - mx);
+      float sum = e;
+      for (int o = 1; o < p.P; o <<= 1) sum += __shfl_xor(sum, o);
+      aw = e / sum;
+    }
+    Sample sm;
+    make_sample(sm, p.dist + (int64_t)b * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x, y, z, aw);
+    w_[lane] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
+    o_[lane] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
+    if (r == 0) b_[il] = b;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#if defined(SGC_DIAG_PHASE1_ONLY)
+  {  // diagnostic build only (tools/diag): time phase 1 alone, keep its results live
+    const float4 w = w_[lane];
+    if (item0 * 1 + lane / SPI < n_items) p.out[(int64_t)(item0 + lane / SPI) * MC + (lane % SPI)] = w.x + w.y + w.z + w.w + (float)o_[lane].x;
+    return;
+  }
+#endif
+  // ---- phase 2: lane = 4 channels of a head ----
+  const int CV = p.Cm / 4, LPI = p.M * CV;
+  const int LP = PT > 0 ? PT : p.P;
+  for (int idx = lane; idx < IPW * LPI; idx += kWave) {
+    const int il = idx / LPI;
+    const int item = item0 + il;
+    if (item >= n_items) break;
+    const int r = idx - il * LPI;
+    const int m = r / CV;
+    const int c0 = (r - m * CV) * 4;
+    const float *vbase = p.value + (int64_t)b_[il] * p.S * MC + m * p.Cm + c0;
+    const int d0 = il * SPI + m * LP;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PT > 0) {
+      float4 w[PT > 0 ? PT : 1];
+      int4 o[PT > 0 ? PT : 1];
+      float4 v[PT > 0 ? PT : 1][4];
+#pragma unroll
+      for (int s = 0; s < PT; ++s) { w[s] = w_[d0 + s]; o[s] = o_[d0 + s]; }
+#pragma unroll
+      for (int s = 0; s < PT; ++s) {
+        const int ok[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[s][k] = ok[k] >= 0 ? *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int s = 0; s < PT; ++s) {
+        const float wk[4] = {w[s].x, w[s].y, w[s].z, w[s].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc.x += wk[k] * v[s][k].x; acc.y += wk[k] * v[s][k].y;
+          acc.z += wk[k] * v[s][k].z; acc.w += wk[k] * v[s][k].w;
+        }
+      }
+    } else {
+      for (int s = 0; s < LP; ++s) {
+        const float4 w = w_[d0 + s];
+        const int4 o = o_[d0 + s];
+        const float wk[4] = {w.x, w.y, w.z, w.w};
+        const int ok[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (ok[k] < 0) continue;
+          const float4 v = *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC);
+          acc.x += wk[k] * v.x; acc.y += wk[k] * v.y; acc.z += wk[k] * v.z; acc.w += wk[k] * v.w;
+        }
+      }
+    }
+    *reinterpret_cast<float4 *>(p.out + (int64_t)item * MC + m * p.Cm + c0) = acc;
+  }
+}
+
+int g_tune_fwd_variant = 1;   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
+
 static int pick_tp(int SPI, int LPI) {
   // enough samples to occupy the block in phase 1, bounded LDS (<= 32 KiB of descriptors)
   int tp = 256 / (SPI > 0 ? SPI : 1);
@@ -190,6 +317,20 @@ static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
   const int SPI = p.M * p.L * p.P;
   const bool vec4 = (p.Cm % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.value) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+  // (with one sample per item -- the geometry sample -- the block kernel's wider phase 2 wins: 64 vs 87 us)
+  if (MODE != kBatch && g_tune_fwd_variant == 1 && vec4 && p.L == 1 && p.dist_heads == 1 && SPI >= 8 && SPI <= kWave &&
+      kWave % SPI == 0 && (p.P & (p.P - 1)) == 0 && ((reinterpret_cast<uintptr_t>(p.raw) & 7) == 0)) {
+    const int per_block = 4 * (kWave / SPI);
+    const int grid = ceil_div(grid_items, per_block);
+    if (grid <= 0) return SGC_OK;
+    if (MODE == kPairsDeform && p.P == 4)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4>), dim3(grid), dim3(256), 0, stream, p);
+    else if (MODE == kPairsGeom)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsGeom, 1>), dim3(grid), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<MODE == kBatch ? kPairsDeform : MODE, 0>), dim3(grid), dim3(256), 0, stream, p);
+    return check_launch("dfa3d_fwd_wave_kernel");
+  }
   p.TP = pick_tp(SPI, p.M * p.Cm / (vec4 ? 4 : 1));
   if ((int64_t)SPI * 32 > 60000) return set_error(SGC_EUNSUP, "M*L*P = %d samples per query exceed the LDS tile", SPI);
   const size_t smem = (size_t)p.TP * SPI * 32 + (size_t)p.TP * sizeof(int);
@@ -283,6 +424,12 @@ __global__ __launch_bounds__(256) void wms_fwd_kernel(const float *__restrict__ 
 }  // namespace sgc
 
 using namespace sgc;
+
+extern "C" int sgc_set_tuning(const char *key, int value) {
+  if (!key) return set_error(SGC_EINVAL, "sgc_set_tuning: null key");
+  if (!strcmp(key, "fwd_variant")) { g_tune_fwd_variant = value; return SGC_OK; }
+  return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
+}
 
 extern "C" int sgc_dfa3d_forward(const float *value, const float *dist, const int64_t *shapes3,
                                  const int64_t *lsi, const float *loc3, const float *attn,

@@ -12,6 +12,17 @@ from .. import ext
 
 _PAD = 32
 
+# "bf16x3": fp32 operands split hi/lo onto the bf16 matrix cores (fp32-faithful to ~1e-5, default);
+# "f32": exact fp32 products on the fp32 MFMA (5x slower matrix pipe).  Both are tested against the oracle.
+CONV_MODE = "bf16x3"
+
+
+def set_conv_mode(mode):
+    global CONV_MODE
+    if mode not in ("bf16x3", "f32"):
+        raise ValueError(mode)
+    CONV_MODE = mode
+
 
 def _pad_to(n, m=_PAD):
     return (n + m - 1) // m * m
@@ -41,16 +52,27 @@ class ConvSpec:
         if bias is not None:
             shift[:cout] += bias.detach().float() * scale[:cout]
         self.wt, self.scale, self.shift = wp.contiguous(), scale, shift
+        self.w_hi, self.w_lo = ext.ops().split_bf16(self.wt) if w.is_cuda else (None, None)
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.ksize, self.stride, self.transposed = ksize, stride, transposed
 
     def __call__(self, x, grid, residual=None, relu=0):
+        if CONV_MODE == "bf16x3":
+            return ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, grid, self.ksize, self.stride,
+                                              self.transposed, self.scale, self.shift, residual, relu)
         return ext.ops().conv3d_cl(x, self.wt, grid, self.ksize, self.stride, self.transposed, self.scale,
                                    self.shift, residual, relu)
 
 
 def module_fingerprint(module):
-    return tuple((t.data_ptr(), t._version, t.device) for t in list(module.parameters()) + list(module.buffers()))
+    """Cheap change detector for the cached plans: (storage address, in-place version) of every
+    parameter / buffer.  The tensor list itself is cached on the module (rebuilt on .train()/.to())."""
+    tensors = module.__dict__.get("_fp_tensors")
+    if tensors is None or module.__dict__.get("_fp_training") != module.training:
+        tensors = list(module.parameters()) + list(module.buffers())
+        module.__dict__["_fp_tensors"] = tensors
+        module.__dict__["_fp_training"] = module.training
+    return tuple((t.data_ptr(), t._version) for t in tensors)
 
 
 def to_channels_last_rows(x):

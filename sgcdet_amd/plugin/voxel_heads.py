@@ -64,7 +64,8 @@ class DenseHead(nn.Module):
             unmasked_idx = torch.arange(n_vox, device=device)
         else:
             unmasked_idx = torch.nonzero(proposal > 0).view(-1)          # host sync, reference behaviour
-        volume_queries = torch.zeros((n_vox, C), device=device)           # content-free queries (:63)
+        # content-free queries (:63): only materialised where autograd needs the reference's data flow
+        volume_queries = torch.zeros((n_vox, C), device=device) if torch.is_grad_enabled() else None
         seed_feats = self.cross_transformer.get_vox_features(
             mlvl_feats, volume_queries, ref_3d=self.ref_3d, vox_coords=self.vox_coords,
             unmasked_idx=unmasked_idx, bev_pos=None, prev_bev=None, img_meta=img_meta, **kwargs).squeeze(0)

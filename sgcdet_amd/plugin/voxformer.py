@@ -175,7 +175,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         xavier_init(self.output_proj, distribution="uniform", bias=0.0)
 
     # ---- inference: pair-list pipeline --------------------------------------------------
-    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W):
+    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False):
         """query [1,Nq,C]; feat [N,S,C]; dist [N,S,D]; ref_cam [N,Nq,3]; mask_u8 [N,Nq]."""
         ops = _ops()
         C = self.embed_dims
@@ -184,7 +184,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         n_pairs, n_valid, _, _ = pc["totals"].tolist()       # the one host sync of this level
         out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
         if n_pairs == 0:
-            return self.dropout(out) + query
+            return out if zero_query else self.dropout(out) + query
         pair_cam, pair_q = pc["pair_cam"], pc["pair_q"]
         geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W)
         if self.deformable_attn:
@@ -209,7 +209,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
             ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads)
             pooled = F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
         ops.scatter_rows(pooled, valid_index, out.view(Nq, C))
-        return self.dropout(out) + query
+        out = self.dropout(out)
+        return out if zero_query else out + query
 
     # ---- training: reference data layout, differentiable -----------------------------------
     def _forward_reference_layout(self, query, feat, dist, ref_cam, mask, spatial_shapes, level_start_index,
@@ -276,7 +277,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         mask_u8 = bev_mask.reshape(N, Nq)
         mask_u8 = mask_u8 if mask_u8.dtype == torch.uint8 else mask_u8.to(torch.uint8)
         return self._forward_pairs(query, feat.contiguous(), dist.contiguous(), ref_cam.contiguous(),
-                                   mask_u8.contiguous(), hw[0], hw[1])
+                                   mask_u8.contiguous(), hw[0], hw[1], zero_query=bool(kwargs.get("zero_query")))
 
 
 # ----------------------------------------------------------------------------------------
@@ -454,6 +455,17 @@ class PerceptionTransformer_DFA3D(BaseModule):
             if isinstance(m, (MSDeformableAttention3D_DFA3D, DeformCrossAttention_DFA3D)):
                 (m.init_weight if hasattr(m, "init_weight") else m.init_weights)()
 
+    def _shape_tensors(self, shapes, device):
+        """(spatial_shapes [L,2] int64, level_start_index [L] int64) on the device, cached: building them
+        per call costs a blocking host->device copy (0.8 ms measured) three times per scene."""
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        key = (shapes, str(device))
+        if key not in cache:
+            ss = torch.as_tensor(shapes, dtype=torch.long)
+            lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+            cache[key] = (ss.to(device), lsi.to(device))
+        return cache[key]
+
     def get_vox_features(self, mlvl_feats, bev_queries, ref_3d, vox_coords, unmasked_idx, bev_pos=None,
                          prev_bev=None, img_meta=None, mlvl_dpt_dists=None, **kwargs):
         """transformer.py:118-185.  mlvl_feats: list of [1,N,C,H,W] (possibly crop views);
@@ -461,7 +473,11 @@ class PerceptionTransformer_DFA3D(BaseModule):
         assert mlvl_feats[0].size(0) == 1
         ops = _ops()
         flat_idx = vox_coords[unmasked_idx, 3]
-        queries = bev_queries[flat_idx].unsqueeze(1)                      # [Nq,1,C]
+        if bev_queries is None:   # the reference's queries are all-zero (DenseHead.py:63): skip the gather
+            queries = torch.zeros((flat_idx.shape[0], 1, self.embed_dims), device=mlvl_feats[0].device)
+            kwargs["zero_query"] = True
+        else:
+            queries = bev_queries[flat_idx].unsqueeze(1)                  # [Nq,1,C]
         sel_ref = ref_3d[flat_idx].to(queries.device)                     # [Nq,3]
         feats, dists, shapes = [], [], []
         for feat, dpt in zip(mlvl_feats, mlvl_dpt_dists):
@@ -475,8 +491,7 @@ class PerceptionTransformer_DFA3D(BaseModule):
                 dists.append(ops.nchw_to_nhwc_crop(dpt[0].float(), h, w))
         feat_flatten = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
         dist_flatten = dists[0] if len(dists) == 1 else torch.cat(dists, 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=queries.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = self._shape_tensors(tuple(shapes), queries.device)
         pos = None
         if bev_pos is not None:
             pos = bev_pos.flatten(2).permute(2, 0, 1)[flat_idx]

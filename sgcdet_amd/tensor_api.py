@@ -13,8 +13,10 @@ product instantiates it exactly once, for ``"cuda"``, in ``sgcdet_amd.ext``.
 import torch
 
 
-def _stream_ptr(device_type):
+def _stream_ptr(device_type, index=None):
     if device_type == "cuda":
+        if index is not None and hasattr(torch._C, "_cuda_getCurrentRawStream"):
+            return torch._C._cuda_getCurrentRawStream(index)          # no Stream object round trip
         return torch.cuda.current_stream().cuda_stream
     return None
 
@@ -26,6 +28,7 @@ class TensorOps:
         # when set to a list, every CUDA call is bracketed by HIP events on the launch stream
         # and (name, meta, start, end) is appended -- bench.py's per-kernel timing
         self.event_log = None
+        self.event_names = None      # optional set of entry points to time (None = all)
 
     # ---- argument checks ------------------------------------------------
     def _check(self, **tensors):
@@ -69,16 +72,19 @@ class TensorOps:
         ptrs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
         if self.device_type == "cuda":
             dev = next(a.device for a in args if isinstance(a, torch.Tensor))
-            with torch.cuda.device(dev):
-                if self.event_log is None:
-                    return self.lib.call(name, *ptrs, _stream_ptr("cuda"))
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = self.lib.call(name, *ptrs, _stream_ptr("cuda"))
-                e1.record()
-                self.event_log.append((name, _meta or {}, e0, e1))
-                return rc
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if idx != torch.cuda.current_device():
+                with torch.cuda.device(dev):
+                    return self._call(name, *args, _meta=_meta)
+            if self.event_log is None or (self.event_names is not None and name not in self.event_names):
+                return self.lib.call(name, *ptrs, _stream_ptr("cuda", idx))
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = self.lib.call(name, *ptrs, _stream_ptr("cuda", idx))
+            e1.record()
+            self.event_log.append((name, _meta or {}, e0, e1))
+            return rc
         return self.lib.call(name, *ptrs, None)
 
     # ---- 1. the four dfa3D._ext operators ----------------------------------
@@ -300,6 +306,34 @@ class TensorOps:
         return dst
 
     # ---- 7. channels-last 3D convolution -----------------------------------------------
+    @staticmethod
+    def split_bf16(w):
+        """fp32 -> (hi, lo) bf16 with hi = bf16_rne(w), lo = bf16_rne(w - hi)."""
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return hi.contiguous(), lo.contiguous()
+
+    def conv3d_cl_bf16x3(self, x, w_hi, w_lo, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
+                         residual=None, relu=False):
+        """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual)
+        self._f32(x=x, scale=scale, shift=shift, residual=residual)
+        if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape:
+            raise RuntimeError("conv3d_cl_bf16x3: w_hi / w_lo must be bfloat16 tensors of one shape")
+        ix, iy, iz = grid
+        V, Cin = x.shape
+        taps, Cout, Cin2 = w_hi.shape
+        if V != ix * iy * iz or Cin2 != Cin or taps != (8 if transposed else ksize ** 3):
+            raise RuntimeError("conv3d_cl_bf16x3: inconsistent shapes")
+        og = (2 * ix, 2 * iy, 2 * iz) if transposed else tuple((d + 2 * (ksize // 2) - ksize) // stride + 1 for d in grid)
+        y = torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
+        if residual is not None and residual.shape != y.shape:
+            raise RuntimeError("conv3d_cl_bf16x3: residual shape mismatch")
+        self._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize,
+                   stride, 1 if transposed else 0, int(relu),
+                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
+        return y, og
+
     def conv3d_cl(self, x, wt, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
                   residual=None, relu=False):
         """x [X*Y*Z, Cin] channels-last; wt [taps, Cout, Cin]; grid = (X, Y, Z) of the input;

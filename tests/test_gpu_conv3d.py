@@ -37,3 +37,29 @@ def test_conv3d_cl_matches_oracle(case, oracle_ops, gpu_ops):
     assert og == og_g
     err = (y_g.cpu() - y_c).abs().max().item()
     assert err < 2e-5 * max(1.0, y_c.abs().max().item()), err
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_bf16x3_is_fp32_faithful(case, oracle_ops, gpu_ops):
+    """3-way bf16 split on the bf16 MFMA vs the fp32 oracle: bounded at 1e-4 of the tensor scale
+    (observed ~1e-5; north-star bar 1e-3)."""
+    Cin, Cout, grid, k, s, tr, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, Cin, generator=g)
+    taps = 8 if tr else k ** 3
+    wt = torch.randn(taps, Cout, Cin, generator=g) * (1.0 / (taps * Cin) ** 0.5)
+    sc = torch.rand(Cout, generator=g) + 0.5
+    sh = torch.randn(Cout, generator=g)
+    y_c, og = oracle_ops.conv3d_cl(x, wt, grid, k, s, tr, sc, sh, None, False)
+    res = torch.randn(y_c.shape, generator=g) if use_res else None
+    y_c, og = oracle_ops.conv3d_cl(x, wt, grid, k, s, tr, sc, sh, res, relu)
+    w_hi, w_lo = gpu_ops.split_bf16(wt.cuda())
+    y_g, og_g = gpu_ops.conv3d_cl_bf16x3(x.cuda(), w_hi, w_lo, grid, k, s, tr, sc.cuda(), sh.cuda(),
+                                         res.cuda() if use_res else None, relu)
+    assert og == og_g
+    err = (y_g.cpu() - y_c).abs().max().item()
+    assert err < 1e-4 * max(1.0, y_c.abs().max().item()), err
+    # and the oracle's own bf16x3 entry point (hi + lo recombined) agrees with its fp32 one
+    y_c2, _ = oracle_ops.conv3d_cl_bf16x3(x, w_hi.cpu(), w_lo.cpu(), grid, k, s, tr, sc, sh, res, relu)
+    assert (y_c2 - y_c).abs().max().item() < 1e-4 * max(1.0, y_c.abs().max().item())

@@ -1,5 +1,6 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sgcdet_amd import ext
 ops = ext.ops()
 layers = [  # name, Cin, Cout, grid, k, s, transposed
@@ -21,11 +22,16 @@ for name,Cin,Cout,g,k,s,tr in layers:
     x=torch.randn(V,Cin,device='cuda'); taps=8 if tr else k**3
     wt=torch.randn(taps,Cout,Cin,device='cuda')*0.01
     sc=torch.ones(Cout,device='cuda'); sh=torch.zeros(Cout,device='cuda')
-    for _ in range(3): y,og=ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)
-    torch.cuda.synchronize(); t=time.perf_counter()
-    n=10
-    for _ in range(n): y,og=ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)
-    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/n
+    wh,wl=ops.split_bf16(wt)
+    res={}
+    for mode in ("f32","bf16x3"):
+        f=(lambda: ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)) if mode=="f32" else (lambda: ops.conv3d_cl_bf16x3(x,wh,wl,g,k,s,tr,sc,sh,None,True))
+        for _ in range(3): y,og=f()
+        torch.cuda.synchronize(); t=time.perf_counter()
+        n=10
+        for _ in range(n): y,og=f()
+        torch.cuda.synchronize(); res[mode]=((time.perf_counter()-t)/n, y)
     OV=og[0]*og[1]*og[2]
     fl = 2*Cin*Cout*OV*(1 if tr else taps)
-    print(f"{name:36s} {dt*1e6:9.1f} us  {fl/dt/1e12:7.2f} TFLOP/s")
+    err=(res["f32"][1]-res["bf16x3"][1]).abs().max().item()/max(1.0,res["f32"][1].abs().max().item())
+    print(f"{name:36s} f32 {res['f32'][0]*1e6:8.1f} us {fl/res['f32'][0]/1e12:6.1f} TF | bf16x3 {res['bf16x3'][0]*1e6:8.1f} us {fl/res['bf16x3'][0]/1e12:6.1f} TF-eq | rel diff {err:.1e}")

@@ -1,0 +1,74 @@
+"""A/B of the deformable-gather kernel variants on the config-2 finest-level shape (one process,
+interleaved rounds, HIP events).  Usage: python tools/gather_bench.py [n_views] [C]"""
+import ctypes
+import sys
+
+import torch
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sgcdet_amd import ext
+from sgcdet_amd.scene import make_img_meta
+from sgcdet_amd.plugin.voxformer import compute_projection
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+H, W, D, M, P = 59, 80, 12, 8, 4
+ops = ext.ops()
+if os.environ.get("SGC_DIAG_LIB"):      # diagnostic builds (tools/diag): timing only, results are garbage
+    from sgcdet_amd._abi import Library
+    from sgcdet_amd.tensor_api import TensorOps
+    ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
+dev = "cuda"
+meta = make_img_meta(N, "scannet", 0)
+proj = compute_projection(meta).float().to(dev).contiguous()
+origin = torch.tensor(meta["lidar2img"]["origin"]).to(dev)
+# 6400 random voxels of the 40x40x16 grid (top-k 25 %)
+g = torch.Generator().manual_seed(0)
+nx, ny, nz = 40, 40, 16
+idx = torch.randperm(nx * ny * nz, generator=g)[:6400].sort().values
+xs = torch.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], 1).float()
+ref3d = (xs * torch.tensor([.16, .16, .2]) - torch.tensor([nx, ny, nz]) / 2 * torch.tensor([.16, .16, .2])).to(dev).contiguous()
+ref_cam, mask = ops.project_points(ref3d, origin, proj, 320, 239, 0.2, 5.0)
+pc = ops.compact_pairs(mask)
+n_pairs = int(pc["totals"][0])
+value = torch.randn(N, H * W, M, C // M, device=dev)
+dist = torch.randn(N, H * W, D, device=dev).mul(2).softmax(-1).contiguous()
+raw = torch.randn(n_pairs, M * P * 4, device=dev)
+raw[:, :M * P * 2] *= 2.0
+feat = value.view(N, H * W, C)
+alg = N * H * W * C * 4 + N * H * W * D * 4 + n_pairs * 512 + n_pairs * C * 4
+alg_geo = N * H * W * C * 4 + N * H * W * D * 4 + n_pairs * 12 + n_pairs * C * 4
+print(f"pairs {n_pairs}  algorithmic bytes deform {alg / 1e6:.1f} MB  geom {alg_geo / 1e6:.1f} MB")
+
+
+def run(kind):
+    if kind == "deform":
+        return ops.pairs_deform_gather(value, dist, ref_cam, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P)
+    return ops.pairs_geometry_sample(feat, dist, ref_cam, pc["pair_cam"], pc["pair_q"], n_pairs, H, W)
+
+
+variants = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "1"])]
+outs = {}
+times = {(v, k): [] for v in variants for k in ("deform", "geom")}
+for rnd in range(12):
+    for v in variants:
+        ops.lib.call("sgc_set_tuning", b"fwd_variant", v)
+        for k in ("deform", "geom"):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = run(k)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd >= 2:
+                times[(v, k)].append(e0.elapsed_time(e1) * 1e3)
+            outs[(v, k)] = o
+for (v, k), t in times.items():
+    t = sorted(t)
+    b = alg if k == "deform" else alg_geo
+    print(f"variant {v} {k:7s} median {t[len(t) // 2]:7.1f} us  min {t[0]:7.1f} us  -> {b / t[len(t) // 2] / 1e3:7.1f} GB/s "
+          f"({b / t[len(t) // 2] / 1e3 / 8000:.3f} of 8 TB/s)")
+for k in ("deform", "geom"):
+    ref = outs[(variants[0], k)]
+    for v in variants[1:]:
+        print(k, "variant", v, "max |diff| vs variant", variants[0], (outs[(v, k)] - ref).abs().max().item())
