@@ -206,9 +206,13 @@ struct ConvParamsB : ConvParams {
 };
 
 template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvParamsB p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const ConvParamsB p) {
+  constexpr int NT = WM * WN * 64;                     // threads per workgroup (256 or 512)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int BCH = BN * 4 / 256;                    // 16-byte weight chunks per thread per plane
+  constexpr int ACH = BM * 8 / NT;                     // float4 A chunks per thread (rows r0 + (NT/8) i)
+  constexpr int AROWS = NT / 8;
+  constexpr int BCH = BN * 4 / NT;                     // 16-byte weight chunks per thread per plane
+  constexpr int BROWS_ = NT / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   // per buffer: A_hi[BM][LDKH], A_lo[BM][LDKH], B_hi[BN][LDKH], B_lo[BN][LDKH]
   constexpr int A_PLANE = BM * LDKH, B_PLANE = BN * LDKH, BUF = 2 * A_PLANE + 2 * B_PLANE;
@@ -225,20 +229,20 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvPara
   const int ksteps_c = p.Cin / BK;
   const int nsteps = taps_per * ksteps_c;
 
-  const int c4 = tid & 7, r0 = tid >> 3;        // A: row r0 + 32 i, 4 floats at c4*4
-  const int bc = tid & 3, br0 = tid >> 2;       // B: row br0 + 64 i, 8 bf16 at bc*8
-  int ax[4], ay[4], az[4];
-  bool arow_ok[4];
+  const int c4 = tid & 7, r0 = tid >> 3;        // A: row r0 + AROWS i, 4 floats at c4*4
+  const int bc = tid & 3, br0 = tid >> 2;       // B: row br0 + BROWS_ i, 8 bf16 at bc*8
+  int ax[ACH], ay[ACH], az[ACH];
+  bool arow_ok[ACH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + 32 * i;
+  for (int i = 0; i < ACH; ++i) {
+    const int m = m0 + r0 + AROWS * i;
     arow_ok[i] = m < p.M;
     const int mm = arow_ok[i] ? m : 0;
     az[i] = mm % p.gz;
     ay[i] = (mm / p.gz) % p.gy;
     ax[i] = mm / (p.gz * p.gy);
   }
-  float4 ra[4];
+  float4 ra[ACH];
   uint4 rbh[BCH], rbl[BCH];
   auto load_step = [&](int s) {
     const int tap = p.transposed ? parity : tap_lo + s / ksteps_c;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvPara
       dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       const int xx = ax[i] * p.stride + dx - p.pad, yy = ay[i] * p.stride + dy - p.pad,
                 zz = az[i] * p.stride + dz - p.pad;
       const bool ok = arow_ok[i] && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvPara
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      const int n = n0 + br0 + 64 * i;
+      const int n = n0 + br0 + BROWS_ * i;
       const int64_t off = ((int64_t)tap * p.Cout + n) * p.Cin + cib + bc * 8;
       if (n < p.Cout) {
         rbh[i] = *reinterpret_cast<const uint4 *>(p.w_hi + off);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvPara
   auto store_step = [&](int buf) {
     __bf16 *a_hi = base + buf * BUF, *a_lo = a_hi + A_PLANE, *b_hi = a_lo + A_PLANE, *b_lo = b_hi + B_PLANE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
       bf16x4 h, l;
 #pragma unroll
@@ -280,13 +284,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_bf16x3_kernel(const ConvPara
         h[e] = hb;
         l[e] = (__bf16)(v[e] - (float)hb);
       }
-      const int o = (r0 + 32 * i) * LDKH + c4 * 4;
+      const int o = (r0 + AROWS * i) * LDKH + c4 * 4;
       *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
       *reinterpret_cast<bf16x4 *>(a_lo + o) = l;
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      const int o = (br0 + 64 * i) * LDKH + bc * 8;
+      const int o = (br0 + BROWS_ * i) * LDKH + bc * 8;
       *reinterpret_cast<uint4 *>(b_hi + o) = rbh[i];
       *reinterpret_cast<uint4 *>(b_lo + o) = rbl[i];
     }
@@ -390,6 +394,8 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 }  // namespace sgc
 
 using namespace sgc;
+
+namespace sgc { int g_tune_conv_waves = 8; }
 
 static int conv_setup(ConvParams &p, const char *who, const float *x, const void *w1, const void *w2, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride, int transposed, int relu,
@@ -500,12 +506,15 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t)));
+    const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
+    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     attr_set = true;
   }
   if (narrow)
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
+  else if (g_tune_conv_waves == 8)
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
   else
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
   rc = check_launch("conv3d_igemm_bf16x3_kernel");

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
 // Waves of a workgroup drift apart and the dependent-load chain of phase 1 (pair -> ref -> depth)
 // of one wave overlaps the row gather of the others.  PT > 0 fixes the point count at compile time
 // so the gather of one (item, head) is fully unrolled: all 4*PT row loads are in flight together.
+// (forcing more waves per SIMD with __launch_bounds__(256, 6|8) spills the 16 in-flight rows to scratch:
+//  2-3x slower, measured -- the kernel wants its 99 VGPRs and 4 waves/SIMD.)
 template <int MODE, int PT>
 __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) {
   __shared__ float4 lds_w[256];
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
   }
 }
 
-int g_tune_fwd_variant = 1;   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
+int g_tune_fwd_variant = 1;
+extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
 static int pick_tp(int SPI, int LPI) {
   // enough samples to occupy the block in phase 1, bounded LDS (<= 32 KiB of descriptors)
@@ -428,6 +431,7 @@ using namespace sgc;
 extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!key) return set_error(SGC_EINVAL, "sgc_set_tuning: null key");
   if (!strcmp(key, "fwd_variant")) { g_tune_fwd_variant = value; return SGC_OK; }
+  if (!strcmp(key, "conv_waves")) { g_tune_conv_waves = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }
 
