@@ -234,6 +234,17 @@ int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_
 int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
                           int H, int W, sgc_stream_t stream);
 
+/* Coarse-to-fine glue of AdaptiveSparseHead on channels-last volumes (AdaptiveSparseHead.py:64-82):
+ *   up [8*ix*iy*iz, C] = trilinear x2 upsample of vol [ix*iy*iz, C] (F.interpolate, align_corners=False);
+ *   occ [8*ix*iy*iz]   = sigmoid(up . w + b)  (the occupancy head Sequential(Linear(C,1), Sigmoid)); w/b/occ
+ *   may all be NULL to upsample only.                                                        */
+int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,
+                       float *occ_or_null, int ix, int iy, int iz, int C, sgc_stream_t stream);
+
+/* vol[idx[i], :] += rows[i, :] -- `upsampled_volume + DenseHead(...)` where the dense head's output is zero
+ * outside the selected voxels (AdaptiveSparseHead.py:77-82, DenseHead.py:80-81); idx int64, distinct.   */
+int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int n, int C, sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 7. Dense 3D convolution of the neck / head on channels-last volumes
  *    (FastIndoorImVoxelNeck, necks/imvoxelnet.py:36-64,146-173; head convs,

@@ -686,3 +686,50 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   free(w);
   return rc;
 }
+
+/* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */
+int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,
+                       float *occ_or_null, int ix, int iy, int iz, int C, sgc_stream_t stream) {
+  (void)stream;
+  if (!vol || !up) return fail(SGC_EINVAL, "null pointer");
+  const int ox = 2 * ix, oy = 2 * iy, oz = 2 * iz;
+  const int n[3] = {ix, iy, iz};
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int x = 0; x < ox; ++x)
+    for (int y = 0; y < oy; ++y)
+      for (int z = 0; z < oz; ++z) {
+        const int dst[3] = {x, y, z};
+        int i0[3], i1[3];
+        float l0[3], l1[3];
+        for (int a = 0; a < 3; ++a) {
+          float t = 0.5f * ((float)dst[a] + 0.5f) - 0.5f;
+          if (t < 0.f) t = 0.f;
+          i0[a] = (int)t;
+          i1[a] = i0[a] + (i0[a] < n[a] - 1 ? 1 : 0);
+          l1[a] = t - (float)i0[a];
+          l0[a] = 1.f - l1[a];
+        }
+        const int64_t v = ((int64_t)x * oy + y) * oz + z;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+#define V(a, b, d) vol[((((int64_t)(a)) * iy + (b)) * iz + (d)) * C + c]
+          const float r = l0[0] * (l0[1] * (l0[2] * V(i0[0], i0[1], i0[2]) + l1[2] * V(i0[0], i0[1], i1[2])) +
+                                   l1[1] * (l0[2] * V(i0[0], i1[1], i0[2]) + l1[2] * V(i0[0], i1[1], i1[2]))) +
+                          l1[0] * (l0[1] * (l0[2] * V(i1[0], i0[1], i0[2]) + l1[2] * V(i1[0], i0[1], i1[2])) +
+                                   l1[1] * (l0[2] * V(i1[0], i1[1], i0[2]) + l1[2] * V(i1[0], i1[1], i1[2])));
+#undef V
+          up[v * C + c] = r;
+          if (w_or_null) dot += r * w_or_null[c];
+        }
+        if (w_or_null) occ_or_null[v] = 1.f / (1.f + expf(-(dot + b_or_null[0])));
+      }
+  return SGC_OK;
+}
+
+int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int n, int C, sgc_stream_t stream) {
+  (void)stream;
+  if (!rows || !idx || !vol) return fail(SGC_EINVAL, "null pointer");
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < C; ++c) vol[idx[i] * C + c] += rows[(int64_t)i * C + c];
+  return SGC_OK;
+}

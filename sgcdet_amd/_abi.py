@@ -29,6 +29,8 @@ SIGNATURES = {
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_upsample2x_occ": [_p] * 5 + [_i] * 4 + [_p],
+    "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],
     "sgc_set_tuning": [C.c_char_p, _i],
 }
 

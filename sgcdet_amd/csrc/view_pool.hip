@@ -154,6 +154,79 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
   }
 }
 
+
+// Trilinear x2 upsample of a channels-last volume fused with the occupancy head:
+//   up[v', :] = F.interpolate(vol, scale_factor=2, mode='trilinear', align_corners=False)   (AdaptiveSparseHead.py:64-69)
+//   occ[v']   = sigmoid(dot(up[v', :], w) + b)                                               (:71, Sequential(Linear(C,1), Sigmoid))
+// One group of C/4 lanes per OUTPUT voxel (a full wave at C = 256): up to 8 input rows are read as
+// float4 lanes (L2-resident, the input is 1/8 of the output), the row is written once, and the dot
+// product is reduced over the group with wave shuffles.  Source index / weights as torch's
+// upsample_trilinear3d: t = max(0.5*(dst+0.5)-0.5, 0), i0 = floor(t), i1 = i0 + (i0 < n-1), l1 = t - i0.
+__global__ __launch_bounds__(256) void upsample2x_occ_kernel(const float *__restrict__ vol, const float *__restrict__ w,
+                                                             const float *__restrict__ b, float *__restrict__ up,
+                                                             float *__restrict__ occ, int ix, int iy, int iz, int C, int G) {
+  const int C4 = C >> 2;
+  const int ox = 2 * ix, oy = 2 * iy, oz = 2 * iz;
+  const int64_t nvox = (int64_t)ox * oy * oz;
+  const int gpb = blockDim.x / G;                       // voxel groups per block
+  const int g = threadIdx.x / G, l = threadIdx.x % G;
+  for (int64_t v = (int64_t)blockIdx.x * gpb + g; v < nvox; v += (int64_t)gridDim.x * gpb) {
+    const int z = (int)(v % oz), y = (int)((v / oz) % oy), x = (int)(v / ((int64_t)oz * oy));
+    int i0[3], i1[3];
+    float l0[3], l1[3];
+    const int dst[3] = {x, y, z}, n[3] = {ix, iy, iz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float t = 0.5f * ((float)dst[a] + 0.5f) - 0.5f;
+      t = t < 0.f ? 0.f : t;
+      i0[a] = (int)t;
+      i1[a] = i0[a] + (i0[a] < n[a] - 1 ? 1 : 0);
+      l1[a] = t - (float)i0[a];
+      l0[a] = 1.f - l1[a];
+    }
+    float dot = 0.f;
+    for (int c4 = l; c4 < C4; c4 += G) {
+      auto row = [&](int a, int bq, int c) {
+        return reinterpret_cast<const float4 *>(vol + (((int64_t)a * iy + bq) * iz + c) * C)[c4];
+      };
+      const float4 v000 = row(i0[0], i0[1], i0[2]), v001 = row(i0[0], i0[1], i1[2]);
+      const float4 v010 = row(i0[0], i1[1], i0[2]), v011 = row(i0[0], i1[1], i1[2]);
+      const float4 v100 = row(i1[0], i0[1], i0[2]), v101 = row(i1[0], i0[1], i1[2]);
+      const float4 v110 = row(i1[0], i1[1], i0[2]), v111 = row(i1[0], i1[1], i1[2]);
+      float4 r;
+#define SGC_TRI(f)                                                                                     \
+  r.f = l0[0] * (l0[1] * (l0[2] * v000.f + l1[2] * v001.f) + l1[1] * (l0[2] * v010.f + l1[2] * v011.f)) + \
+        l1[0] * (l0[1] * (l0[2] * v100.f + l1[2] * v101.f) + l1[1] * (l0[2] * v110.f + l1[2] * v111.f));
+      SGC_TRI(x) SGC_TRI(y) SGC_TRI(z) SGC_TRI(w)
+#undef SGC_TRI
+      reinterpret_cast<float4 *>(up + v * C)[c4] = r;
+      if (w) {
+        const float4 ww = reinterpret_cast<const float4 *>(w)[c4];
+        dot += r.x * ww.x + r.y * ww.y + r.z * ww.z + r.w * ww.w;
+      }
+    }
+    if (w) {
+      for (int o = 1; o < G; o <<= 1) dot += __shfl_xor(dot, o);
+      if (l == 0) occ[v] = 1.f / (1.f + expf(-(dot + b[0])));
+    }
+  }
+}
+
+// vol[idx[i], :] += rows[i, :]  (volume = upsampled + DenseHead(selected voxels), AdaptiveSparseHead.py:77-82:
+// the dense head's output is zero outside the selected voxels, so the full-volume add is a row scatter-add)
+__global__ void scatter_add_rows_kernel(const float *__restrict__ rows, const int64_t *__restrict__ idx,
+                                        float *__restrict__ vol, int n, int C4) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)n * C4;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C4), c = (int)(t - (int64_t)i * C4);
+    float4 *dst = reinterpret_cast<float4 *>(vol + idx[i] * (int64_t)C4 * 4) + c;
+    const float4 a = reinterpret_cast<const float4 *>(rows + (int64_t)i * C4 * 4)[c];
+    float4 d = *dst;
+    d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    *dst = d;
+  }
+}
+
 }  // namespace sgc
 
 using namespace sgc;
@@ -219,4 +292,30 @@ extern "C" int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C,
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, Hs, Ws, H, W);
   return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,
+                                  float *occ_or_null, int ix, int iy, int iz, int C, sgc_stream_t stream) {
+  if (!vol || !up) return set_error(SGC_EINVAL, "sgc_upsample2x_occ: null pointer");
+  if ((w_or_null != nullptr) != (occ_or_null != nullptr) || (w_or_null && !b_or_null))
+    return set_error(SGC_EINVAL, "sgc_upsample2x_occ: w, b and occ go together");
+  if (C % 4 || ix <= 0 || iy <= 0 || iz <= 0 || (((uintptr_t)vol | (uintptr_t)up | (uintptr_t)w_or_null) & 15))
+    return set_error(SGC_EUNSUP, "sgc_upsample2x_occ: C %% 4 == 0 and 16-byte aligned pointers required");
+  int G = 1;
+  while (G < 64 && G < C / 4) G <<= 1;      // lanes per output voxel (power of two <= 64)
+  const int64_t nvox = (int64_t)8 * ix * iy * iz;
+  const int gpb = 256 / G;
+  hipLaunchKernelGGL(upsample2x_occ_kernel, dim3(grid_for(nvox * G, 256)), dim3(256), 0, (hipStream_t)stream, vol,
+                     w_or_null, b_or_null, up, occ_or_null, ix, iy, iz, C, G);
+  (void)gpb;
+  return check_launch("upsample2x_occ_kernel");
+}
+
+extern "C" int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int n, int C, sgc_stream_t stream) {
+  if (!rows || !idx || !vol) return set_error(SGC_EINVAL, "sgc_scatter_add_rows: null pointer");
+  if (C % 4 || (((uintptr_t)rows | (uintptr_t)vol) & 15)) return set_error(SGC_EUNSUP, "sgc_scatter_add_rows: C %% 4 == 0 required");
+  if (n <= 0) return SGC_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((int64_t)n * (C / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, rows, idx, vol, n, C / 4);
+  return check_launch("scatter_add_rows_kernel");
 }

@@ -49,6 +49,19 @@ class DenseHead(nn.Module):
         points = grid * self.voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
         return vox_coords, points.view(3, -1).permute(1, 0)
 
+    def seed_rows(self, mlvl_feats, img_meta, idx=None, **kwargs):
+        """Inference building block: features of the selected voxels as rows [Nq, C] (``idx`` ascending
+        int64 flat voxel indices, None = every voxel) -- what ``forward`` scatters into the dense volume."""
+        device = mlvl_feats[0].device
+        if idx is None:
+            idx = self.__dict__.get("_all_idx")
+            if idx is None or idx.device != device:
+                idx = torch.arange(int(self.n_voxels.prod()), device=device)
+                self.__dict__["_all_idx"] = idx
+        return self.cross_transformer.get_vox_features(
+            mlvl_feats, None, ref_3d=self.ref_3d, vox_coords=self.vox_coords, unmasked_idx=idx, bev_pos=None,
+            prev_bev=None, img_meta=img_meta, **kwargs).squeeze(0)
+
     def forward(self, mlvl_feats, img_meta=None, proposal=None, proposal_idx=None, **kwargs):
         """mlvl_feats: list of [1,N,C,H,W]; proposal: [Nvox] {0,1} mask or None (= all);
         proposal_idx: optional ascending int64 indices equal to ``nonzero(proposal > 0)``.
@@ -92,8 +105,51 @@ class AdaptiveSparseHead(nn.Module):
             [nn.Sequential(nn.Linear(embed_dims, 1), nn.Sigmoid()) for _ in range(len(self.base_heads) - 1)])
         self.loss = nn.BCELoss()
 
+    def _level_inputs(self, i, mlvl_feats, img_meta, mlvl_dpt_dists):
+        """level i samples FPN map n_lvl-1-i cropped to the un-padded image (AdaptiveSparseHead.py:52-59)"""
+        n_lvl = len(self.base_heads)
+        ds = 4 * (2 ** (n_lvl - 1 - i))
+        h, w = img_meta["img_shape"][0] // ds, img_meta["img_shape"][1] // ds
+        k = n_lvl - 1 - i
+        return mlvl_feats[k][:, :, :, :h, :w], mlvl_dpt_dists[k][:, :, :, :h, :w]
+
+    def _forward_rows(self, mlvl_feats, img_meta, mlvl_dpt_dists):
+        """Inference path on channels-last rows [V, C]: trilinear upsample + occupancy head in one HIP
+        launch, `upsampled + DenseHead(selected)` as a row scatter-add (the dense head's output is zero
+        outside the selection), no NCDHW <-> NDHWC copies, no dense zero volumes."""
+        ops = ext.ops()
+        C = self.embed_dims
+        feat, dpt = self._level_inputs(0, mlvl_feats, img_meta, mlvl_dpt_dists)
+        rows = self.base_heads[0].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt]).contiguous()
+        grid = tuple(int(v) for v in self.base_heads[0].n_voxels)
+        occ_list, top = [], None
+        for i in range(1, len(self.base_heads)):
+            lin = self.occ_pred_heads[i - 1][0]
+            up, occ, grid = ops.upsample2x_occ(rows, grid, lin.weight.reshape(-1), lin.bias)
+            occ = occ.view(1, -1)
+            occ_list.append(occ)
+            feat, dpt = self._level_inputs(i, mlvl_feats, img_meta, mlvl_dpt_dists)
+            if (i - 1) < len(self.topk_list):
+                _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
+                idx = top.squeeze(0).sort().values                          # == nonzero(mask), no host sync
+                seed = self.base_heads[i].seed_rows([feat], img_meta, idx, mlvl_dpt_dists=[dpt])
+                ops.scatter_add_rows(seed.contiguous(), idx, up)
+            else:
+                top = None
+                up.add_(self.base_heads[i].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt]))
+            rows = up
+        nx, ny, nz = grid
+        volume = rows.view(nx, ny, nz, C).permute(3, 0, 1, 2).unsqueeze(0)
+        if not occ_list:
+            return volume, torch.ones([1, 1, nx, ny, nz], device=volume.device), None
+        occ_preds = torch.cat(occ_list[::-1], dim=1)
+        mask = torch.zeros_like(occ_list[-1]).scatter_(1, top, 1.0).squeeze(0)
+        return volume, self.get_valid(mask).unsqueeze(0).unsqueeze(0), occ_preds
+
     def forward(self, mlvl_feats, img_meta, mlvl_dpt_dists):
         assert mlvl_feats[0].shape[0] == 1
+        if not torch.is_grad_enabled() and mlvl_feats[0].is_cuda and self.embed_dims % 4 == 0:
+            return self._forward_rows(mlvl_feats, img_meta, mlvl_dpt_dists)
         n_lvl = len(self.base_heads)
         volume = None
         occ_preds_list = []

@@ -358,3 +358,26 @@ class TensorOps:
                    1 if transposed else 0, int(relu),
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
         return y, og
+
+    # ---- coarse-to-fine glue -------------------------------------------------------------
+    def upsample2x_occ(self, vol, grid, w=None, b=None):
+        """vol [X*Y*Z, C] rows -> (up [8*X*Y*Z, C], occ [8*X*Y*Z] or None, (2X, 2Y, 2Z))."""
+        self._check(vol=vol, w=w, b=b)
+        self._f32(vol=vol, w=w, b=b)
+        ix, iy, iz = grid
+        V, Cc = vol.shape
+        if V != ix * iy * iz or (w is not None and w.numel() != Cc):
+            raise RuntimeError("upsample2x_occ: inconsistent shapes")
+        up = torch.empty((8 * V, Cc), dtype=torch.float32, device=vol.device)
+        occ = torch.empty(8 * V, dtype=torch.float32, device=vol.device) if w is not None else None
+        self._call("sgc_upsample2x_occ", vol, w, b, up, occ, ix, iy, iz, Cc)
+        return up, occ, (2 * ix, 2 * iy, 2 * iz)
+
+    def scatter_add_rows(self, rows, idx, vol):
+        self._check(rows=rows, idx=idx, vol=vol)
+        self._f32(rows=rows, vol=vol)
+        self._i64(idx=idx)
+        if rows.shape[1] != vol.shape[1] or idx.numel() != rows.shape[0]:
+            raise RuntimeError("scatter_add_rows: inconsistent shapes")
+        self._call("sgc_scatter_add_rows", rows, idx, vol, rows.shape[0], rows.shape[1])
+        return vol

@@ -208,3 +208,29 @@ def test_errors_are_raised_not_printed(gpu_ops):
         gpu_ops.dfa3d_forward(v.transpose(1, 3), d, sh, lsi, loc)  # non-contiguous
     out, _ = gpu_ops.dfa3d_forward(v, d, sh, lsi, loc)
     assert out.shape == (1, 1, 4)
+
+
+@pytest.mark.parametrize("C,grid", [(256, (5, 6, 4)), (128, (10, 10, 4)), (32, (3, 4, 2))])
+def test_upsample_occ_and_scatter_add(C, grid, oracle_ops, gpu_ops):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C)
+    V = grid[0] * grid[1] * grid[2]
+    vol = torch.randn(V, C, generator=g)
+    w, b = torch.randn(C, generator=g) * 0.1, torch.randn(1, generator=g)
+    up_c, occ_c, og = oracle_ops.upsample2x_occ(vol, grid, w, b)
+    up_g, occ_g, og_g = gpu_ops.upsample2x_occ(vol.cuda(), grid, w.cuda(), b.cuda())
+    assert og == og_g
+    close(up_g, up_c, tol=1e-6)
+    close(occ_g, occ_c, tol=2e-6)
+    # and against torch's own trilinear kernel (the reference's call, AdaptiveSparseHead.py:64-69)
+    x = vol.view(*grid, C).permute(3, 0, 1, 2)[None]
+    ref = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)[0].permute(1, 2, 3, 0).reshape(-1, C)
+    close(up_g, ref, tol=1e-6)
+    up_only, none, _ = gpu_ops.upsample2x_occ(vol.cuda(), grid)
+    assert none is None and torch.equal(up_only, up_g)
+    idx = torch.randperm(8 * V, generator=g)[: 2 * V].sort().values
+    rows = torch.randn(2 * V, C, generator=g)
+    want = up_c.clone()
+    oracle_ops.scatter_add_rows(rows, idx, want)
+    got = gpu_ops.scatter_add_rows(rows.cuda(), idx.cuda(), up_g.clone())
+    close(got, want, tol=1e-6)
