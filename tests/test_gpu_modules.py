@@ -152,3 +152,9 @@ def test_module_training_path_runs_and_matches_inference_path():
     assert feats[0].grad is not None and torch.isfinite(feats[0].grad).all() and feats[0].grad.abs().sum() > 0
     n_with_grad = sum(p.grad is not None and p.grad.abs().sum() > 0 for p in head.parameters())
     assert n_with_grad > 20
+
+
+def test_projection_composition_on_this_host():
+    """single-mm == reference loop on the GPU box's host CPU as well (BLAS code paths are host specific)"""
+    from test_host_logic import test_single_mm_projection_equals_reference_loop
+    test_single_mm_projection_equals_reference_loop()
