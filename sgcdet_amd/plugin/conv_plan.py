@@ -90,3 +90,31 @@ def rows_to_ncdhw(rows, grid, channels):
     """[V, Cp] rows -> [1, channels, X, Y, Z] view (channels-last memory, no copy)."""
     X, Y, Z = grid
     return rows.view(X, Y, Z, rows.shape[1])[..., :channels].permute(3, 0, 1, 2).unsqueeze(0)
+
+
+class LinearSpec:
+    """nn.Linear (or a row-block of stacked weights) prepared for ``sgc_conv3d_cl_bf16x3`` as a 1x1x1
+    convolution over M rows: y[M, out] = x[M, in] @ W^T + b on the bf16 matrix cores with the 3-way split."""
+
+    def __init__(self, weight, bias):
+        w = weight.detach().float()
+        cout, cin = w.shape
+        if cin % _PAD:
+            raise ValueError("LinearSpec needs in_features % 32 == 0")
+        cout_p = _pad_to(cout, 4)
+        wp = torch.zeros((1, cout_p, cin), dtype=torch.float32, device=w.device)
+        wp[0, :cout] = w
+        self.wt = wp
+        self.w_hi, self.w_lo = ext.ops().split_bf16(wp)
+        self.shift = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+        if bias is not None:
+            self.shift[:cout] = bias.detach().float()
+        self.cout, self.cout_p = cout, cout_p
+
+    def __call__(self, x):
+        M = x.shape[0]
+        if CONV_MODE == "bf16x3":
+            y, _ = ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, (M, 1, 1), 1, 1, False, None, self.shift)
+        else:
+            y, _ = ext.ops().conv3d_cl(x, self.wt, (M, 1, 1), 1, 1, False, None, self.shift)
+        return y if self.cout_p == self.cout else y[:, :self.cout]

@@ -45,6 +45,7 @@ from ..mmcv_lite import (ATTENTION, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_
                          build_transformer_layer_sequence, constant_init, xavier_init)
 from ..functions import MultiScale3DDeformableAttnFunction_fp32
 from .. import ext
+from .conv_plan import LinearSpec, module_fingerprint
 
 
 def _ops():
@@ -174,6 +175,23 @@ class DeformCrossAttention_DFA3D(BaseModule):
     def init_weight(self):
         xavier_init(self.output_proj, distribution="uniform", bias=0.0)
 
+    def _gemm_plan(self):
+        """The three large GEMMs of a level (value_proj over N*S rows, the fused offset/logit projection and
+        the K/V in-projection over the visible pairs) on the MFMA kernel; rebuilt when a parameter changes."""
+        fp = module_fingerprint(self)
+        if self.__dict__.get("_gemm_cache") is not None and self._gemm_cache[0] == fp:
+            return self._gemm_cache[1]
+        da, mha, C = self.deformable_attention, self.attention_pooling, self.embed_dims
+        plan = dict(
+            value=LinearSpec(da.value_proj.weight, da.value_proj.bias),
+            raw=LinearSpec(torch.cat([da.sampling_offsets.weight, da.sampling_offsets_depth.weight,
+                                      da.attention_weights.weight], 0),
+                           torch.cat([da.sampling_offsets.bias, da.sampling_offsets_depth.bias,
+                                      da.attention_weights.bias], 0)),
+            kv=LinearSpec(mha.in_proj_weight[C:], mha.in_proj_bias[C:]))
+        self.__dict__["_gemm_cache"] = (fp, plan)
+        return plan
+
     # ---- inference: pair-list pipeline --------------------------------------------------
     def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False):
         """query [1,Nq,C]; feat [N,S,C]; dist [N,S,D]; ref_cam [N,Nq,3]; mask_u8 [N,Nq]."""
@@ -191,8 +209,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
             da = self.deformable_attention
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
-            value = da.value_proj(feat)
-            raw = da.raw_projection(geo)
+            use_mfma = self.inter_view_aggregation == "attn" and C % 32 == 0
+            gemm = self._gemm_plan() if use_mfma else None
+            value = gemm["value"](feat.view(N * H * W, C)) if use_mfma else da.value_proj(feat)
+            raw = gemm["raw"](geo) if use_mfma else da.raw_projection(geo)
             per_pair = ops.pairs_deform_gather(value.view(N, H * W, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
                                                da.num_heads, da.num_points)
@@ -205,7 +225,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
             mha = self.attention_pooling
             w, b = mha.in_proj_weight, mha.in_proj_bias
             q = F.linear(pooled, w[:C], b[:C])
-            kv = F.linear(per_pair, w[C:], b[C:])
+            kv = self._gemm_plan()["kv"](per_pair) if (self.deformable_attn and C % 32 == 0) else F.linear(per_pair, w[C:], b[C:])
             ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads)
             pooled = F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
         ops.scatter_rows(pooled, valid_index, out.view(Nq, C))
