@@ -372,6 +372,212 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2 for the 3x3x3 stride-1 layers (90 % of the neck's FLOPs): halo-resident A.
+// A workgroup owns a brick of BX*BY*BZ = 256 output voxels.  For one 32-channel slice it stages the
+// brick's input HALO ((BX+2)(BY+2)(BZ+2) rows, split to bf16 hi/lo once) in LDS and then walks the 27
+// taps with the SAME staged rows: the A fragment of output row r at tap t is the halo row
+// hr(r) + toff(t), a wave-uniform offset on a per-lane base.  Only the weights stream (16 KB hi+lo per
+// tap, double buffered).  L2->LDS traffic per MAC drops 3.4x against the per-tap gather above, and the
+// fp32->bf16 split runs once per halo element instead of 27 times.
+// 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64, BN = 128 output channels.
+// LDS: A 2 planes x HROWS x 80 B (<= 104 KB) + B 2 buffers x 2 planes x 128 x 80 B (41 KB).
+// ---------------------------------------------------------------------------------------------
+template <int BX, int BY, int BZ>
+__global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
+  constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
+  constexpr int BNV = 128, NT = 512;
+  constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
+  constexpr int A_PLANE = HROWS * LDKH, B_PLANE = BNV * LDKH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
+  __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nbx = (p.gx + BX - 1) / BX, nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
+  (void)nbx;
+  int bid = blockIdx.x;
+  const int bk = bid % nbz; bid /= nbz;
+  const int bj = bid % nby; const int bi = bid / nby;
+  const int X0 = bi * BX, Y0 = bj * BY, Z0 = bk * BZ;
+  const int n0 = blockIdx.y * BNV;
+  const int nchunks = p.Cin / BK;
+  const int per = (nchunks + p.splitk - 1) / p.splitk;
+  const int c_lo = blockIdx.z * per, c_hi = min(nchunks, c_lo + per);
+  if (c_lo >= c_hi) return;
+
+  // per-lane halo base rows of the wave's two 32-row MFMA tiles
+  const int fr = lane & 31, fh = lane >> 5;
+  int arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + fr;
+    const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
+    arow[i] = ((x + 1) * HY + (y + 1)) * HZ + (z + 1);
+  }
+  // B staging slot of this thread: row n = tid>>2, 8 bf16 at (tid&3)*8
+  const int bn = tid >> 2, bc = tid & 3;
+  const bool bn_ok = n0 + bn < p.Cout;
+
+  float4 ra[NA];
+  uint4 rbh, rbl;
+  auto load_A = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = i * NT + tid;
+      const int row = idx >> 3, c4 = idx & 7;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < HROWS) {
+        const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
+        const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+        if (gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz)
+          ra[i] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4);
+      }
+    }
+  };
+  auto store_A = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = i * NT + tid;
+      const int row = idx >> 3, c4 = idx & 7;
+      if (row < HROWS) {
+        const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 hb = (__bf16)v[e];
+          h[e] = hb;
+          l[e] = (__bf16)(v[e] - (float)hb);
+        }
+        *reinterpret_cast<bf16x4 *>(A_hi + row * LDKH + c4 * 4) = h;
+        *reinterpret_cast<bf16x4 *>(A_lo + row * LDKH + c4 * 4) = l;
+      }
+    }
+  };
+  auto load_B = [&](int tap, int cc) {
+    if (bn_ok) {
+      const int64_t off = ((int64_t)tap * p.Cout + n0 + bn) * p.Cin + cc * BK + bc * 8;
+      rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
+      rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+    } else {
+      rbh = make_uint4(0, 0, 0, 0);
+      rbl = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_B = [&](int buf) {
+    __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
+    *reinterpret_cast<uint4 *>(b) = rbh;
+    *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  int g = 0;                       // global step counter -> B buffer parity
+  load_A(c_lo);
+  load_B(0, c_lo);
+  store_A();
+  store_B(0);
+  __syncthreads();
+  for (int cc = c_lo; cc < c_hi; ++cc) {
+    for (int tap = 0; tap < 27; ++tap, ++g) {
+      const bool last_tap = tap == 26;
+      const bool more = !last_tap || cc + 1 < c_hi;
+      if (more) load_B(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
+      if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+      const int toff = ((dx - 1) * HY + (dy - 1)) * HZ + (dz - 1);
+      const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
+      const __bf16 *bl_ = bh_ + B_PLANE;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
+          ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+          al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
+          bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      if (more) store_B((g + 1) & 1);
+      __syncthreads();
+    }
+    if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
+      store_A();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= p.Cout) continue;
+      const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int r = wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
+        if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
+        const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
+        float *dst = p.y + orow * p.Cout + col;
+        if (p.splitk > 1) {
+          atomicAdd(dst, acc[i][j][k]);
+        } else {
+          float v = acc[i][j][k] * sc + sh;
+          if (p.relu == 2) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[orow * p.Cout + col];
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+}
+
+template <int BX, int BY, int BZ>
+static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
+  constexpr int HROWS = (BX + 2) * (BY + 2) * (BZ + 2);
+  const size_t smem = (size_t)(2 * HROWS + 4 * 128) * LDKH * sizeof(uint16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
+  const int nb = ceil_div(p.Cout, 128);
+  const int nchunks = p.Cin / BK;
+  int splitk = 1;
+  while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;   // fill >= 3/4 of the CUs
+  p.splitk = splitk;
+  if (splitk > 1) {
+    hipError_t e = hipMemsetAsync(p.y, 0, OV * p.Cout * sizeof(float), st);
+    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "conv3d halo: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  return check_launch("conv3d_halo_bf16x3_kernel");
+}
+
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
                                      const float *__restrict__ shift, const float *__restrict__ residual,
                                      int64_t total4, int C4, int relu) {
@@ -395,7 +601,7 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 
 using namespace sgc;
 
-namespace sgc { int g_tune_conv_waves = 8; }
+namespace sgc { int g_tune_conv_waves = 8; int g_tune_conv_halo = 1; }
 
 static int conv_setup(ConvParams &p, const char *who, const float *x, const void *w1, const void *w2, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride, int transposed, int relu,
@@ -493,11 +699,19 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.scale = scale; p.shift = shift; p.residual = residual_or_null;
   const int64_t OV = (int64_t)ox * oy * oz;
+  hipStream_t st = (hipStream_t)stream;
+  // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
+  if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= 64 && p.M >= 2048) {
+    if (p.gz >= 16) rc = launch_halo<4, 4, 16>(p, OV, st);
+    else if (p.gz >= 8) rc = launch_halo<4, 8, 8>(p, OV, st);
+    else rc = launch_halo<8, 8, 4>(p, OV, st);
+    if (rc) return rc;
+    return conv_finish(p, OV, st);
+  }
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
   p.splitk = pick_splitk(p, mb, nb, 512);
-  hipStream_t st = (hipStream_t)stream;
   if (p.splitk > 1) {
     hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
     if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_bf16x3: memset: %s", hipGetErrorString(e));

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
 }
 
 int g_tune_fwd_variant = 1;
-extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
+extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile
+extern int g_tune_conv_halo;    // conv3d.hip: halo-resident kernel for the 3x3x3 stride-1 layers   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
 static int pick_tp(int SPI, int LPI) {
   // enough samples to occupy the block in phase 1, bounded LDS (<= 32 KiB of descriptors)
@@ -432,6 +433,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!key) return set_error(SGC_EINVAL, "sgc_set_tuning: null key");
   if (!strcmp(key, "fwd_variant")) { g_tune_fwd_variant = value; return SGC_OK; }
   if (!strcmp(key, "conv_waves")) { g_tune_conv_waves = value; return SGC_OK; }
+  if (!strcmp(key, "conv_halo")) { g_tune_conv_halo = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }
 

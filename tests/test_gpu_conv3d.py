@@ -16,6 +16,12 @@ CASES = [  # Cin, Cout, grid, ksize, stride, transposed, residual, relu
     (256, 256, (12, 12, 8), 3, 1, False, True, True),     # config-2 channel count, multi-block
     (64, 128, (9, 7, 4), 3, 1, False, True, 2),           # decoder epilogue: relu(t) + skip
     (64, 256, (4, 4, 2), 3, 1, False, True, 2),           # same through the split-K epilogue kernel
+    # halo-resident kernel (3x3x3 stride 1, >= 2048 voxels): the three brick shapes, partial bricks, split-K
+    (64, 128, (16, 16, 16), 3, 1, False, True, True),     # bricks 4x4x16
+    (64, 128, (20, 20, 8), 3, 1, False, True, 2),         # bricks 4x8x8, 20 % 8 != 0
+    (32, 64, (24, 24, 4), 3, 1, False, False, True),      # bricks 8x8x4
+    (64, 192, (17, 13, 16), 3, 1, False, True, True),     # partial bricks in x and y, Cout % 128 != 0
+    (32, 256, (40, 40, 16), 3, 1, False, True, True),     # config-2 volume, 200 workgroups, no split-K
 ]
 
 

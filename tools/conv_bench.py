@@ -25,7 +25,7 @@ for name,Cin,Cout,g,k,s,tr in layers:
     wh,wl=ops.split_bf16(wt)
     res={}
     for mode in ("f32","bf16x3w4","bf16x3"):
-        if mode.startswith("bf16x3"): ops.lib.call("sgc_set_tuning", b"conv_waves", 4 if mode.endswith("w4") else 8)
+        if mode.startswith("bf16x3"): ops.lib.call("sgc_set_tuning", b"conv_halo", 0 if mode.endswith("w4") else 1)
         f=(lambda: ops.conv3d_cl(x,wt,g,k,s,tr,sc,sh,None,True)) if mode=="f32" else (lambda: ops.conv3d_cl_bf16x3(x,wh,wl,g,k,s,tr,sc,sh,None,True))
         for _ in range(3): y,og=f()
         torch.cuda.synchronize(); t=time.perf_counter()
@@ -35,4 +35,4 @@ for name,Cin,Cout,g,k,s,tr in layers:
     OV=og[0]*og[1]*og[2]
     fl = 2*Cin*Cout*OV*(1 if tr else taps)
     err=(res["f32"][1]-res["bf16x3"][1]).abs().max().item()/max(1.0,res["f32"][1].abs().max().item())
-    print(f"{name:36s} f32 {res['f32'][0]*1e6:8.1f} us {fl/res['f32'][0]/1e12:6.1f} TF | bf16x3 4w {res['bf16x3w4'][0]*1e6:8.1f} us | 8w {res['bf16x3'][0]*1e6:8.1f} us {fl/res['bf16x3'][0]/1e12:6.1f} TF-eq | rel diff {err:.1e}")
+    print(f"{name:36s} f32 {res['f32'][0]*1e6:8.1f} us {fl/res['f32'][0]/1e12:6.1f} TF | bf16x3 per-tap {res['bf16x3w4'][0]*1e6:8.1f} us | halo {res['bf16x3'][0]*1e6:8.1f} us {fl/res['bf16x3'][0]/1e12:6.1f} TF-eq | rel diff {err:.1e}")
