@@ -53,10 +53,48 @@ class SGCDet(nn.Module):
     def extract_feat(self, volumes):
         return self.neck_3d(volumes)
 
+    # ---- hipGraph replay of the static-shape tail (neck + head: ~30 launches, fixed shapes) -----------
+    use_graph = True
+
+    def _neck_head_eager(self, volume):
+        outs = self.bbox_head(self.extract_feat(volume))
+        return tuple(list(o) for o in outs)
+
+    def _neck_head(self, volume):
+        """neck_3d + bbox_head.  In eval / no-grad on the GPU the launch sequence is captured once into a
+        hipGraph per input shape and replayed (one host call instead of ~30 kernel launches plus their
+        Python orchestration).  Outputs then live in the graph's static buffers: they are overwritten by the
+        next call, so consume (or clone) them before calling again."""
+        if (not self.use_graph) or self.training or torch.is_grad_enabled() or not volume.is_cuda:
+            return self._neck_head_eager(volume)
+        from .conv_plan import CONV_MODE, module_fingerprint
+        key = (tuple(volume.shape), tuple(volume.stride()), CONV_MODE, module_fingerprint(self.neck_3d),
+               module_fingerprint(self.bbox_head))
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        entry = cache.get(key)
+        if entry is None:
+            if len(cache) > 8:
+                cache.clear()
+            static_in = torch.empty_strided(volume.shape, volume.stride(), dtype=volume.dtype, device=volume.device)
+            static_in.copy_(volume)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up outside capture (plans, attributes, allocator)
+                self._neck_head_eager(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._neck_head_eager(static_in)
+            entry = cache[key] = (graph, static_in, outs)
+        graph, static_in, outs = entry
+        static_in.copy_(volume)
+        graph.replay()
+        return outs
+
     def forward_features(self, x, img_metas, dpt_dist):
         """FPN maps + depth distribution -> head tensors (the timed hot path)."""
         volume, valid, occ = self.build_volume_from_features(x, img_metas, dpt_dist)
-        outs = self.bbox_head(self.extract_feat(volume))
+        outs = self._neck_head(volume)
         return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])
 
     def simple_test_from_features(self, x, img_metas, dpt_dist):
