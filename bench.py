@@ -164,8 +164,14 @@ def main():
         b_avg = sum(algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"])
                     for _, m in finest) / len(finest)
         achieved = b_avg / t_avg / 1e9
+        # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_gather_pmc_v2.json")
+        if args.workload == "cfg2_scannet" and args.views in (None, 40) and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         kernel="dfa3d_fwd_kernel<kPairsDeform> (finest level)",
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
     if args.breakdown and rank == 0:

@@ -1,6 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.log
-timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1
-timeout 300 python bench.py --steps 30 --warmup 5 2>gpurun_out/bench.err | tee gpurun_out/bench.json
-timeout 300 python tools/host_profile.py 2>&1 | grep -E "^issue|^voxel_head|^neck"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_v2 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof_v2.json 2> $R/gpurun_out/bench_prof_v2.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc2_fetch -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc2_write -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+cat gpurun_out/bench_prof_v2.json | cut -c1-200
