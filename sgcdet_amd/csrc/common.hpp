@@ -33,13 +33,18 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles) {
 
 typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 4-byte aligned pair load
 
+constexpr int kOutside = (int)0x80000000;
+__device__ __forceinline__ int off_index(int off) { return off & 0x7fffffff; }
+
 // One trilinear sample of the DFA3D operator, reduced to what the gather needs:
 // 4 corner weights (bilinear * depth score * attention weight) and 4 pixel indices
 // (-1 = corner outside the map).  Semantics: ms_depth_score_sample_cuda_kernel.cuh:24-148
 // and wms_deform_attn_cuda_kernel.cuh:24-80,286-294 of the reference.
 struct Sample {
   float w[4];   // order: (h0,w0) (h0,w1) (h1,w0) (h1,w1)
-  int off[4];   // pixel index inside the level (h*W + w), -1 if outside
+  int off[4];   // pixel index inside the level (h*W + w); corners outside the map carry the sign bit
+                // (kOutside) on top of a CLAMPED in-range index, so consumers can load unconditionally
+                // (no exec-mask branch per load) and zero the value with a select
   float s[4];   // depth scores in the REFERENCE order (h0,w0) (h0,w1) (h1,w1) (h1,w0)
   // pieces the backward needs
   float lh, lw, ld;
@@ -66,11 +71,14 @@ __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict_
   const bool okh0 = h0 >= 0, okh1 = h1 <= H - 1, okw0 = w0 >= 0, okw1 = w1 <= W - 1;
   const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
   const int px[4] = {h0 * W + w0, h0 * W + w1, h1 * W + w0, h1 * W + w1};
+  const int ch0 = min(max(h0, 0), H - 1), ch1 = min(max(h1, 0), H - 1);
+  const int cw0 = min(max(w0, 0), W - 1), cw1 = min(max(w1, 0), W - 1);
+  const int cpx[4] = {ch0 * W + cw0, ch0 * W + cw1, ch1 * W + cw0, ch1 * W + cw1};
   float sc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool use = sm.in2 && ok[k];
-    sm.off[k] = use ? px[k] : -1;
+    sm.off[k] = use ? px[k] : (cpx[k] | kOutside);
     float v = 0.f;
     if (sm.in3 && ok[k]) {
       // one 8-byte load covers (d0, d1): every depth load touches 64 different cache lines per
@@ -79,7 +87,11 @@ __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict_
       float va, vb;
       if (D >= 2) {
         const int base = d0 < 0 ? 0 : (d0 > D - 2 ? D - 2 : d0);
+#if defined(SGC_DIAG_NO_DEPTH_LOADS)
+        float2_u pr; pr.x = 0.3f + (float)base; pr.y = 0.2f; (void)p;
+#else
         const float2_u pr = *reinterpret_cast<const float2_u *>(p + base);
+#endif
         va = d0 < 0 ? 0.f : (d0 == base ? pr.x : pr.y);
         vb = d1 > D - 1 ? 0.f : (d0 == base ? pr.y : pr.x);
       } else {

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dfa3d_bwd_kernel(const BwdParams p) {
       sm.s[0] = sc.x; sm.s[1] = sc.y; sm.s[2] = sc.z; sm.s[3] = sc.w;
     }
     R.off = make_int4(sm.off[0] < 0 ? -1 : sm.off[0] + lvl0, sm.off[1] < 0 ? -1 : sm.off[1] + lvl0,
-                      sm.off[2] < 0 ? -1 : sm.off[2] + lvl0, sm.off[3] < 0 ? -1 : sm.off[3] + lvl0);
+                      sm.off[2] < 0 ? -1 : sm.off[2] + lvl0, sm.off[3] < 0 ? -1 : sm.off[3] + lvl0);  // < 0 = outside
     R.sg = make_float4(sm.s[0], sm.s[1], sm.s[3], sm.s[2]);
     R.misc = make_float4(sm.lh, sm.lw, aw, sm.in2 ? 1.f : 0.f);
     R.wh = make_float2((float)W, (float)H);

@@ -119,8 +119,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
     make_sample(sm, dpx, (int64_t)p.dist_heads * p.D, H, W, D, x, y, z, aw);
     if (in_tile) {
       lds_w[tt] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
-      lds_o[tt] = make_int4(sm.off[0] < 0 ? -1 : sm.off[0] + lvl0, sm.off[1] < 0 ? -1 : sm.off[1] + lvl0,
-                            sm.off[2] < 0 ? -1 : sm.off[2] + lvl0, sm.off[3] < 0 ? -1 : sm.off[3] + lvl0);
+      lds_o[tt] = make_int4(sm.off[0] + lvl0, sm.off[1] + lvl0, sm.off[2] + lvl0, sm.off[3] + lvl0);  // sign bit survives
       if (r == 0) lds_b[il] = b;
       if (live && p.score)
         reinterpret_cast<float4 *>(p.score)[(int64_t)item * SPI + r] =
@@ -151,9 +150,10 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
         const int ok[4] = {o.x, o.y, o.z, o.w};
         float4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          v[k] = ok[k] >= 0 ? *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 4; ++k) {   // unconditional load from the clamped index, value zeroed by a select
+          v[k] = *reinterpret_cast<const float4 *>(vbase + (int64_t)off_index(ok[k]) * MC);
+          if (ok[k] < 0) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           acc.x += wk[k] * v[k].x; acc.y += wk[k] * v[k].y;
@@ -169,8 +169,10 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
         const float wk[4] = {w.x, w.y, w.z, w.w};
         const int ok[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (ok[k] >= 0) acc += wk[k] * vbase[(int64_t)ok[k] * MC];
+        for (int k = 0; k < 4; ++k) {
+          const float x = vbase[(int64_t)off_index(ok[k]) * MC];
+          acc += wk[k] * (ok[k] < 0 ? 0.f : x);
+        }
       }
       p.out[(int64_t)item * MC + m * p.Cm + c0] = acc;
     }
@@ -186,13 +188,21 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
 // so the gather of one (item, head) is fully unrolled: all 4*PT row loads are in flight together.
 // (forcing more waves per SIMD with __launch_bounds__(256, 6|8) spills the 16 in-flight rows to scratch:
 //  2-3x slower, measured -- the kernel wants its 99 VGPRs and 4 waves/SIMD.)
-template <int MODE, int PT>
+template <int MODE, int PT, int MT = 0, int CMT = 0, int SPL = 1>
 __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) {
-  __shared__ float4 lds_w[256];
-  __shared__ int4 lds_o[256];
-  __shared__ int lds_b[256];
-  const int SPI = p.M * p.P;
-  const int IPW = kWave / SPI;               // items per wave
+  // SPL = samples per lane in phase 1: a wave owns SPL * 64 / SPI items.  Phase 1 is a chain of dependent
+  // loads (pair -> reference point -> depth); with SPL > 1 the chains of SPL samples are issued together,
+  // which is where its time goes (measured: phase 1 alone 45 us at SPL = 1, latency- not bandwidth-bound).
+  __shared__ float4 lds_w[256 * SPL];
+  __shared__ int4 lds_o[256 * SPL];
+  __shared__ int lds_b[256 * SPL];
+  // MT / CMT / PT > 0 pin heads / channels-per-head / points at compile time (the hot shapes M = 8,
+  // P = 4, Cm = 32 | 16): every divide and modulo of the index arithmetic below folds to shifts.
+  const int M = MT > 0 ? MT : p.M;
+  const int P = PT > 0 ? PT : p.P;
+  const int Cm = CMT > 0 ? CMT : p.Cm;
+  const int SPI = M * P;
+  const int IPW = SPL * kWave / SPI;         // items per wave
   const int n_items = p.n_items >= 0 ? p.n_items : p.totals[0];
   const int per_block = 4 * IPW;
   const int ntiles = (n_items + per_block - 1) / per_block;
@@ -201,41 +211,64 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int item0 = tile * per_block + wid * IPW;
   if (item0 >= n_items) return;              // whole wave idle (tail)
-  const int MC = p.M * p.Cm;
-  float4 *w_ = lds_w + wid * kWave;
-  int4 *o_ = lds_o + wid * kWave;
-  int *b_ = lds_b + wid * kWave;
+  const int MC = M * Cm;
+  const float rW = 1.0f / (float)p.W, rH = 1.0f / (float)p.H, rD = 1.0f / (float)p.D;
+  float4 *w_ = lds_w + wid * kWave * SPL;
+  int4 *o_ = lds_o + wid * kWave * SPL;
+  int *b_ = lds_b + wid * kWave * SPL;
 
-  {  // ---- phase 1: lane = sample ----
-    const int il = lane / SPI, r = lane - il * SPI;
-    int item = item0 + il;
-    if (item >= n_items) item = n_items - 1;
-    const int m = r / p.P, pt = r - m * p.P;
-    const int b = p.pair_cam[item];
-    const int q = p.pair_q[item];
-    const float *rc = p.ref_cam + ((int64_t)b * p.Nq + q) * 3;
-    float x = rc[0], y = rc[1], z = rc[2], aw = 1.f;
-    if (MODE == kPairsDeform) {
-      const int MP = p.M * p.P;
-      const float *rw = p.raw + (int64_t)item * MP * 4;
-      const int mp = m * p.P + pt;
-      const float2 uv = *reinterpret_cast<const float2 *>(rw + mp * 2);
-      x = x + uv.x / (float)p.W;
-      y = y + uv.y / (float)p.H;
-      z = z + rw[MP * 2 + mp] / (float)p.D;
-      const float lg = rw[MP * 3 + mp];
-      float mx = lg;
-      for (int o = 1; o < p.P; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      const float e = expf(lg - mx);
-      float sum = e;
-      for (int o = 1; o < p.P; o <<= 1) sum += __shfl_xor(sum, o);
-      aw = e / sum;
+  {  // ---- phase 1: lane = SPL samples (slot = j*64 + lane) ----
+    int bb[SPL];
+    float x[SPL], y[SPL], z[SPL], aw[SPL];
+    float2 uv[SPL];
+    float dzv[SPL], lgv[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {          // stage A: everything that only needs the item index
+      const int slot = j * kWave + lane;
+      const int il = slot / SPI, r = slot - il * SPI;
+      int item = item0 + il;
+      if (item >= n_items) item = n_items - 1;
+      bb[j] = p.pair_cam[item];
+      const int q = p.pair_q[item];
+      const float *rc = p.ref_cam + ((int64_t)bb[j] * p.Nq + q) * 3;
+      x[j] = rc[0]; y[j] = rc[1]; z[j] = rc[2];
+      aw[j] = 1.f;
+      if (MODE == kPairsDeform) {
+        const int MP = M * P;
+        const float *rw = p.raw + (int64_t)item * (MP * 4);
+        uv[j] = *reinterpret_cast<const float2 *>(rw + r * 2);
+        dzv[j] = rw[MP * 2 + r];
+        lgv[j] = rw[MP * 3 + r];
+      }
     }
-    Sample sm;
-    make_sample(sm, p.dist + (int64_t)b * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x, y, z, aw);
-    w_[lane] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
-    o_[lane] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
-    if (r == 0) b_[il] = b;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {          // stage B: locations, softmax over the P adjacent lanes
+      if (MODE == kPairsDeform) {
+        // offset / (W,H,D) as a multiply by the (wave-uniform) reciprocal and exp / division through the
+        // hardware v_exp / v_rcp: <= 2 ulp from the reference's IEEE forms
+        x[j] = x[j] + uv[j].x * rW;
+        y[j] = y[j] + uv[j].y * rH;
+        z[j] = z[j] + dzv[j] * rD;
+        float mx = lgv[j];
+#pragma unroll
+        for (int o = 1; o < P; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = __expf(lgv[j] - mx);
+        float sum = e;
+#pragma unroll
+        for (int o = 1; o < P; o <<= 1) sum += __shfl_xor(sum, o);
+        aw[j] = e * __frcp_rn(sum);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {          // stage C: depth loads + descriptors
+      const int slot = j * kWave + lane;
+      const int il = slot / SPI, r = slot - il * SPI;
+      Sample sm;
+      make_sample(sm, p.dist + (int64_t)bb[j] * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x[j], y[j], z[j], aw[j]);
+      w_[slot] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
+      o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
+      if (r == 0) b_[il] = bb[j];
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -249,8 +282,8 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
   }
 #endif
   // ---- phase 2: lane = 4 channels of a head ----
-  const int CV = p.Cm / 4, LPI = p.M * CV;
-  const int LP = PT > 0 ? PT : p.P;
+  const int CV = Cm / 4, LPI = M * CV;
+  const int LP = P;
   for (int idx = lane; idx < IPW * LPI; idx += kWave) {
     const int il = idx / LPI;
     const int item = item0 + il;
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
     const int r = idx - il * LPI;
     const int m = r / CV;
     const int c0 = (r - m * CV) * 4;
-    const float *vbase = p.value + (int64_t)b_[il] * p.S * MC + m * p.Cm + c0;
+    const float *vbase = p.value + (int64_t)b_[il] * p.S * MC + (m * Cm + c0);
     const int d0 = il * SPI + m * LP;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PT > 0) {
@@ -271,9 +304,17 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       for (int s = 0; s < PT; ++s) {
         const int ok[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          v[s][k] = ok[k] >= 0 ? *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 4; ++k) {   // no branch per load: clamped index + select (see Sample::off);
+                                        // 32-bit element offset (host checks S*M*Cm < 2^31)
+#if defined(SGC_DIAG_NO_ROW_LOADS)
+          v[s][k] = make_float4((float)ok[k], 1.f, 2.f, 3.f);
+#elif defined(SGC_DIAG_SAME_ROW)
+          v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)((off_index(ok[k]) & 7) * MC));
+#else
+          v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)(off_index(ok[k]) * MC));
+#endif
+          if (ok[k] < 0) v[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
 #pragma unroll
       for (int s = 0; s < PT; ++s) {
@@ -292,17 +333,23 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
         const int ok[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (ok[k] < 0) continue;
-          const float4 v = *reinterpret_cast<const float4 *>(vbase + (int64_t)ok[k] * MC);
+          float4 v = *reinterpret_cast<const float4 *>(vbase + (unsigned)(off_index(ok[k]) * MC));
+          if (ok[k] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
           acc.x += wk[k] * v.x; acc.y += wk[k] * v.y; acc.z += wk[k] * v.z; acc.w += wk[k] * v.w;
         }
       }
     }
-    *reinterpret_cast<float4 *>(p.out + (int64_t)item * MC + m * p.Cm + c0) = acc;
+    *reinterpret_cast<float4 *>(p.out + (int64_t)item * MC + (m * Cm + c0)) = acc;
   }
 }
 
+// (A software-pipelined persistent form -- rows of tile t, depth loads of t+1 and inputs of t+2 in flight
+//  together -- was built and measured: 168-238 us against 138 us for the plain wave kernel on the same
+//  inputs.  The gather is bound by instruction issue on the load path, not by exposed latency; what did
+//  help is removing the exec-mask branch around every corner load, see Sample::off.)
+
 int g_tune_fwd_variant = 1;
+int g_tune_fwd_spl = 1;         // samples per lane in phase 1 of the wave kernel (1, 2, 4)
 extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile
 extern int g_tune_conv_halo;    // conv3d.hip: halo-resident kernel for the 3x3x3 stride-1 layers   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
@@ -327,7 +374,16 @@ static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
     const int per_block = 4 * (kWave / SPI);
     const int grid = ceil_div(grid_items, per_block);
     if (grid <= 0) return SGC_OK;
-    if (MODE == kPairsDeform && p.P == 4)
+    if ((int64_t)p.S * p.M * p.Cm >= (1ll << 31)) return set_error(SGC_EUNSUP, "gather: S*M*Cm >= 2^31");
+    if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && g_tune_fwd_spl == 4)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 4>), dim3(ceil_div(grid_items, 32)), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && g_tune_fwd_spl == 2)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 2>), dim3(ceil_div(grid_items, 16)), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32>), dim3(grid), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 16)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 16>), dim3(grid), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsGeom)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsGeom, 1>), dim3(grid), dim3(256), 0, stream, p);
@@ -433,6 +489,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!key) return set_error(SGC_EINVAL, "sgc_set_tuning: null key");
   if (!strcmp(key, "fwd_variant")) { g_tune_fwd_variant = value; return SGC_OK; }
   if (!strcmp(key, "conv_waves")) { g_tune_conv_waves = value; return SGC_OK; }
+  if (!strcmp(key, "fwd_spl")) { g_tune_fwd_spl = value; return SGC_OK; }
   if (!strcmp(key, "conv_halo")) { g_tune_conv_halo = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }

@@ -35,7 +35,9 @@ n_pairs = int(pc["totals"][0])
 value = torch.randn(N, H * W, M, C // M, device=dev)
 dist = torch.randn(N, H * W, D, device=dev).mul(2).softmax(-1).contiguous()
 raw = torch.randn(n_pairs, M * P * 4, device=dev)
-raw[:, :M * P * 2] *= 2.0
+raw[:, :M * P * 2] *= float(os.environ.get("SGC_OFFSET_SCALE", "2.0"))
+if os.environ.get("SGC_ZERO_DEPTH_OFF"):
+    raw[:, M * P * 2:M * P * 3] = 0
 feat = value.view(N, H * W, C)
 alg = N * H * W * C * 4 + N * H * W * D * 4 + n_pairs * 512 + n_pairs * C * 4
 alg_geo = N * H * W * C * 4 + N * H * W * D * 4 + n_pairs * 12 + n_pairs * C * 4
@@ -53,7 +55,8 @@ outs = {}
 times = {(v, k): [] for v in variants for k in ("deform", "geom")}
 for rnd in range(12):
     for v in variants:
-        ops.lib.call("sgc_set_tuning", b"fwd_variant", v)
+        ops.lib.call("sgc_set_tuning", b"fwd_variant", 1 if v >= 1 else 0)
+        ops.lib.call("sgc_set_tuning", b"fwd_spl", v if v > 1 else 1)
         for k in ("deform", "geom"):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
