@@ -1,9 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_v2 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof_v2.json 2> $R/gpurun_out/bench_prof_v2.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc2_fetch -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc2_write -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-cd $R
-cat gpurun_out/bench_prof_v2.json | cut -c1-200
+timeout 900 python -m pytest tests/test_gpu_modules.py -m gpu -x -q 2>&1 | tail -6
+for w in cfg3_arkit cfg4_scannet200_large cfg5_arkit_large; do
+  timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])"
+done
+timeout 300 python bench.py --workload cfg2_scannet --views 100 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cfg2@100views', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])"

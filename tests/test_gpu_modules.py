@@ -84,7 +84,8 @@ def test_neck_and_heads_against_reference_golden():
         assert max_err(boxes.cpu()[key_g], d["boxes"][key_r]) < 1e-3
 
 
-@pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 2), ("cfg2_scannet", 6)])
+@pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 2), ("cfg2_scannet", 6), ("cfg3_arkit", 4),
+                                          ("cfg4_scannet200_large", 3), ("cfg5_arkit_large", 3)])
 def test_hot_path_against_oracle(name, n_views):
     """Seeded synthetic scene of the BASELINE shapes (views reduced for cfg2 so the CPU oracle
     finishes in seconds) -- volume / neck / head tensors within 1e-3, masks and top-k sets bit-exact."""
@@ -114,7 +115,10 @@ def test_hot_path_against_oracle(name, n_views):
     # neck + head on the oracle's volume (torch-CPU conv3d) vs the GPU path
     rp2 = RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},
                    **{"head." + k: v for k, v in det.bbox_head.state_dict().items()}},
-                  dict(head="scannet", n_classes=w["n_classes"], nms_pre=1000))
+                  dict(head="scannet" if w["head"].startswith("ScanNet") else "sunrgbd", n_classes=w["n_classes"],
+                       nms_pre=1000))
+    if res["tie_flips"]:      # a flipped voxel changes its neighbourhood through the 3x3x3 convs: compare the
+        return                # neck/head only when both sides refined exactly the same voxels
     feats3d = rp2.neck(vol_c, prefix="neck.")
     ctr, reg, cls = rp2.head(feats3d, prefix="head.")
     for a, b in zip(r["centerness"] + r["bbox_pred"] + r["cls_score"], ctr + reg + cls):
