@@ -488,12 +488,26 @@ int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float 
   return SGC_OK;
 }
 
-int sgc_pairs_deform_gather(const float *value, const float *dist, const float *ref_cam,
+int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream) {
+  (void)stream;
+  if (!dist || !dp) return fail(SGC_EINVAL, "null pointer");
+  for (int64_t nh = 0; nh < (int64_t)N * H; ++nh)
+    for (int wq = 0; wq <= W; ++wq)
+      for (int d = 0; d < D; ++d) {
+        float *o = dp + ((nh * (W + 1) + wq) * D + d) * 2;
+        o[0] = wq > 0 ? dist[(nh * W + wq - 1) * D + d] : 0.f;
+        o[1] = wq < W ? dist[(nh * W + wq) * D + d] : 0.f;
+      }
+  return SGC_OK;
+}
+
+int sgc_pairs_deform_gather(const float *value, const float *dist, const float *dist_pairs_or_null,
+                            const float *ref_cam,
                             const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                             const int32_t *totals, float *out,
                             int N, int Nq, int H, int W, int M, int Cm, int D, int P,
                             int n_pairs_or_neg, int cap, sgc_stream_t stream) {
-  (void)stream; (void)N;
+  (void)stream; (void)N; (void)dist_pairs_or_null;   /* the oracle always samples the plain map */
   if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
   if (P > 64) return fail(SGC_EUNSUP, "P > 64");
   int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);

@@ -30,6 +30,7 @@ struct FwdParams {
   // maps
   const float *value;       // [B,S,M,Cm]
   const float *dist;        // [B,S,dist_heads,D]
+  const float *dist_pairs;  // optional pair-interleaved depth [N,H,W+1,D,2] (pairs modes), see make_sample_dp
   const int64_t *shapes3;   // [L,3] (batch mode)  -- device
   const int64_t *lsi;       // [L]
   // batch-mode sample source
@@ -44,6 +45,7 @@ struct FwdParams {
   float *score;             // optional [items,M,L,P,4]
   int S, M, Cm, D, dist_heads, L, Q, P, Nq;
   int H, W;                 // pairs mode (single level)
+  int64_t value_bytes;      // size of the value map in bytes (pairs modes)
   int n_items;              // < 0: read totals[0]
   int TP;                   // items per tile
 };
@@ -228,17 +230,25 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       const int il = slot / SPI, r = slot - il * SPI;
       int item = item0 + il;
       if (item >= n_items) item = n_items - 1;
+#if defined(SGC_DIAG_NO_PAIR_LOADS)
+      bb[j] = item % 40; x[j] = 0.3f + 1e-6f * item; y[j] = 0.4f; z[j] = 0.5f;
+#else
       bb[j] = p.pair_cam[item];
       const int q = p.pair_q[item];
       const float *rc = p.ref_cam + ((int64_t)bb[j] * p.Nq + q) * 3;
       x[j] = rc[0]; y[j] = rc[1]; z[j] = rc[2];
+#endif
       aw[j] = 1.f;
       if (MODE == kPairsDeform) {
         const int MP = M * P;
         const float *rw = p.raw + (int64_t)item * (MP * 4);
+#if defined(SGC_DIAG_NO_RAW_LOADS)
+        (void)rw; uv[j] = make_float2(0.1f * r, -0.2f * r); dzv[j] = 0.01f * r; lgv[j] = 0.3f * r;
+#else
         uv[j] = *reinterpret_cast<const float2 *>(rw + r * 2);
         dzv[j] = rw[MP * 2 + r];
         lgv[j] = rw[MP * 3 + r];
+#endif
       }
     }
 #pragma unroll
@@ -264,7 +274,10 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       const int slot = j * kWave + lane;
       const int il = slot / SPI, r = slot - il * SPI;
       Sample sm;
-      make_sample(sm, p.dist + (int64_t)bb[j] * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x[j], y[j], z[j], aw[j]);
+      if (p.dist_pairs)
+        make_sample_dp(sm, p.dist_pairs + (int64_t)bb[j] * p.H * (p.W + 1) * p.D * 2, p.H, p.W, p.D, x[j], y[j], z[j], aw[j]);
+      else
+        make_sample(sm, p.dist + (int64_t)bb[j] * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x[j], y[j], z[j], aw[j]);
       w_[slot] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
       o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
       if (r == 0) b_[il] = bb[j];
@@ -291,7 +304,13 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
     const int r = idx - il * LPI;
     const int m = r / CV;
     const int c0 = (r - m * CV) * 4;
+    // 32-bit byte offsets on the uniform base pointer (host checks N*S*M*Cm*4 < 2^32): the loads take the
+    // saddr + voffset form and the per-corner address is one 32-bit mad instead of 64-bit vector arithmetic
+    const char *vbytes = reinterpret_cast<const char *>(p.value);
+    const unsigned rowb = ((unsigned)b_[il] * (unsigned)p.S * (unsigned)MC + (unsigned)(m * Cm + c0)) * 4u;
+    const unsigned rstride = (unsigned)MC * 4u;
     const float *vbase = p.value + (int64_t)b_[il] * p.S * MC + (m * Cm + c0);
+    (void)vbase;
     const int d0 = il * SPI + m * LP;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PT > 0) {
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
 #elif defined(SGC_DIAG_SAME_ROW)
           v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)((off_index(ok[k]) & 7) * MC));
 #else
-          v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)(off_index(ok[k]) * MC));
+          v[s][k] = *reinterpret_cast<const float4 *>(vbytes + (rowb + (unsigned)off_index(ok[k]) * rstride));
 #endif
           if (ok[k] < 0) v[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
         const int ok[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float4 v = *reinterpret_cast<const float4 *>(vbase + (unsigned)(off_index(ok[k]) * MC));
+          float4 v = *reinterpret_cast<const float4 *>(vbytes + (rowb + (unsigned)off_index(ok[k]) * rstride));
           if (ok[k] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
           acc.x += wk[k] * v.x; acc.y += wk[k] * v.y; acc.z += wk[k] * v.z; acc.w += wk[k] * v.w;
         }
@@ -370,11 +389,11 @@ static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
                     ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   // (with one sample per item -- the geometry sample -- the block kernel's wider phase 2 wins: 64 vs 87 us)
   if (MODE != kBatch && g_tune_fwd_variant == 1 && vec4 && p.L == 1 && p.dist_heads == 1 && SPI >= 8 && SPI <= kWave &&
+      p.value_bytes > 0 && p.value_bytes < (1ll << 32) &&   // 32-bit byte offsets in the wave kernel
       kWave % SPI == 0 && (p.P & (p.P - 1)) == 0 && ((reinterpret_cast<uintptr_t>(p.raw) & 7) == 0)) {
     const int per_block = 4 * (kWave / SPI);
     const int grid = ceil_div(grid_items, per_block);
     if (grid <= 0) return SGC_OK;
-    if ((int64_t)p.S * p.M * p.Cm >= (1ll << 31)) return set_error(SGC_EUNSUP, "gather: S*M*Cm >= 2^31");
     if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && g_tune_fwd_spl == 4)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 4>), dim3(ceil_div(grid_items, 32)), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && g_tune_fwd_spl == 2)
@@ -481,9 +500,30 @@ __global__ __launch_bounds__(256) void wms_fwd_kernel(const float *__restrict__ 
   }
 }
 
+// dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0), wq in [0, W]
+__global__ void depth_pairs_kernel(const float *__restrict__ dist, float2 *__restrict__ dp, int64_t total, int H, int W, int D) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int wq = (int)((i / D) % (W + 1));
+    const int64_t nh = i / ((int64_t)D * (W + 1));
+    const float *row = dist + nh * W * D;
+    dp[i] = make_float2(wq > 0 ? row[(wq - 1) * D + d] : 0.f, wq < W ? row[wq * D + d] : 0.f);
+  }
+}
+
 }  // namespace sgc
 
 using namespace sgc;
+
+extern "C" int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream) {
+  if (!dist || !dp) return set_error(SGC_EINVAL, "sgc_depth_pairs: null pointer");
+  const int64_t total = (int64_t)N * H * (W + 1) * D;
+  if (total <= 0) return set_error(SGC_EINVAL, "sgc_depth_pairs: bad size");
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(depth_pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dist,
+                     reinterpret_cast<float2 *>(dp), total, H, W, D);
+  return check_launch("depth_pairs_kernel");
+}
 
 extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!key) return set_error(SGC_EINVAL, "sgc_set_tuning: null key");
@@ -530,7 +570,8 @@ extern "C" int sgc_pairs_geometry_sample(const float *feat, const float *dist, c
   return launch_fwd<kPairsGeom>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }
 
-extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, const float *ref_cam,
+extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, const float *dist_pairs_or_null,
+                                       const float *ref_cam,
                                        const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                                        const int32_t *totals, float *out,
                                        int N, int Nq, int H, int W, int M, int Cm, int D, int P,
@@ -544,9 +585,11 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   if (P > 64 || (P & (P - 1)))
     return set_error(SGC_EUNSUP, "sgc_pairs_deform_gather: P must be a power of two <= 64 (wave-shuffle softmax)");
   FwdParams p = {};
-  p.value = value; p.dist = dist; p.ref_cam = ref_cam; p.raw = raw; p.pair_cam = pair_cam; p.pair_q = pair_q;
+  p.value = value; p.dist = dist; p.dist_pairs = dist_pairs_or_null; p.ref_cam = ref_cam; p.raw = raw;
+  p.pair_cam = pair_cam; p.pair_q = pair_q;
   p.totals = totals; p.out = out;
   p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
+  p.value_bytes = (int64_t)N * H * W * M * Cm * 4;
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
   return launch_fwd<kPairsDeform>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }

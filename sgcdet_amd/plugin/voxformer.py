@@ -215,7 +215,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
             raw = gemm["raw"](geo) if use_mfma else da.raw_projection(geo)
             per_pair = ops.pairs_deform_gather(value.view(N, H * W, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
-                                               da.num_heads, da.num_points)
+                                               da.num_heads, da.num_points, dist_pairs=ops.depth_pairs(dist, H, W))
         else:
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]

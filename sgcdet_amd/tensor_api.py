@@ -228,11 +228,22 @@ class TensorOps:
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, n_pairs=rows))
         return out
 
+    def depth_pairs(self, dist, H, W):
+        """dist [N, H*W, D] -> pair-interleaved copy [N, H, W+1, D, 2] for ``pairs_deform_gather``."""
+        self._check(dist=dist)
+        self._f32(dist=dist)
+        N, S, D = dist.shape
+        if S != H * W:
+            raise RuntimeError("depth_pairs: inconsistent shapes")
+        dp = torch.empty((N, H, W + 1, D, 2), dtype=torch.float32, device=dist.device)
+        self._call("sgc_depth_pairs", dist, dp, N, H, W, D)
+        return dp
+
     def pairs_deform_gather(self, value, dist, ref_cam, raw, pair_cam, pair_q, n_pairs, H, W, M, P,
-                            totals=None):
+                            totals=None, dist_pairs=None):
         self._check(value=value, dist=dist, ref_cam=ref_cam, raw=raw, pair_cam=pair_cam,
-                    pair_q=pair_q, totals=totals)
-        self._f32(value=value, dist=dist, ref_cam=ref_cam, raw=raw)
+                    pair_q=pair_q, totals=totals, dist_pairs=dist_pairs)
+        self._f32(value=value, dist=dist, ref_cam=ref_cam, raw=raw, dist_pairs=dist_pairs)
         self._i32(pair_cam=pair_cam, pair_q=pair_q, totals=totals)
         N, S, Cc = value.shape[0], value.shape[1], value.shape[-1] * (value.shape[2] if value.dim() == 4 else 1)
         Cm = Cc // M
@@ -243,7 +254,9 @@ class TensorOps:
         if S != H * W or raw.shape[-1] != M * P * 4 or raw.shape[0] < rows:
             raise RuntimeError("pairs_deform_gather: inconsistent shapes")
         out = torch.empty((rows, Cc), dtype=torch.float32, device=value.device)
-        self._call("sgc_pairs_deform_gather", value, dist, ref_cam, raw, pair_cam, pair_q, totals, out,
+        if dist_pairs is not None and dist_pairs.shape != (N, H, W + 1, D, 2):
+            raise RuntimeError("pairs_deform_gather: dist_pairs must be [N, H, W+1, D, 2]")
+        self._call("sgc_pairs_deform_gather", value, dist, dist_pairs, ref_cam, raw, pair_cam, pair_q, totals, out,
                    N, Nq, H, W, M, Cm, D, P, n_pairs, cap,
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, M=M, P=P, n_pairs=rows))
         return out

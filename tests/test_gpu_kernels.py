@@ -179,6 +179,11 @@ def test_pair_list_gathers_and_view_pool(C, M, P, HW, oracle_ops, gpu_ops):
     dg_g = gpu_ops.pairs_deform_gather(cu(value), cu(dist), cu(rc), cu(raw), cu(pc["pair_cam"]), cu(pc["pair_q"]),
                                        n_pairs, H, W, M, P)
     close(dg_g, dg_c)
+    dp = gpu_ops.depth_pairs(cu(dist), H, W)
+    assert torch.equal(dp.cpu(), oracle_ops.depth_pairs(dist, H, W))
+    dg_g2 = gpu_ops.pairs_deform_gather(cu(value), cu(dist), cu(rc), cu(raw), cu(pc["pair_cam"]), cu(pc["pair_q"]),
+                                        n_pairs, H, W, M, P, dist_pairs=dp)
+    close(dg_g2, dg_c)                                       # pair-interleaved depth taps: same results
     mean_c = oracle_ops.view_mean(dg_c, pc["slot"], pc["valid_index"], n_valid)
     mean_g = gpu_ops.view_mean(dg_g, cu(pc["slot"]), cu(pc["valid_index"]), n_valid)
     close(mean_g, mean_c)

@@ -44,9 +44,13 @@ alg_geo = N * H * W * C * 4 + N * H * W * D * 4 + n_pairs * 12 + n_pairs * C * 4
 print(f"pairs {n_pairs}  algorithmic bytes deform {alg / 1e6:.1f} MB  geom {alg_geo / 1e6:.1f} MB")
 
 
+dp = ops.depth_pairs(dist, H, W) if os.environ.get("SGC_DP", "1") == "1" else None
+
+
 def run(kind):
     if kind == "deform":
-        return ops.pairs_deform_gather(value, dist, ref_cam, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P)
+        return ops.pairs_deform_gather(value, dist, ref_cam, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P,
+                                       dist_pairs=dp)
     return ops.pairs_geometry_sample(feat, dist, ref_cam, pc["pair_cam"], pc["pair_q"], n_pairs, H, W)
 
 
