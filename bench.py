@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="neck/head convolution arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
                          "default) or exact fp32 products on the fp32 MFMA")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="scenes in flight per GPU: consecutive steps alternate over this many HIP streams so the host "
+                         "syncs / launch gaps of one scene overlap the kernels of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     return ap.parse_args()
@@ -127,10 +130,15 @@ def main():
 
     ops = ext.ops()
 
+    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
+
     def step(i):
         feats, dpt, metas = scenes[i % n_scenes]
         with torch.no_grad():
-            return det.forward_features(feats, metas, dpt)
+            if streams is None:
+                return det.forward_features(feats, metas, dpt)
+            with torch.cuda.stream(streams[i % len(streams)]):
+                return det.forward_features(feats, metas, dpt)
 
     for i in range(args.warmup):
         step(i)
@@ -172,7 +180,7 @@ def main():
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                        kernel="dfa3d_fwd_kernel<kPairsDeform> (finest level)",
+                        kernel="sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8, Cm=32> (finest level)",
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
     if args.breakdown and rank == 0:
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
@@ -196,7 +204,8 @@ def main():
             "config": {"workload": f"{w['name']}: {n_views} views x {w['embed_dims']} ch, FPN maps 60x80/30x40/15x20, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
-                       "scenes_per_step_per_gpu": 1, "sharding": "scenes across ranks, no collective"},
+                       "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams,
+                       "sharding": "scenes across ranks, no collective"},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

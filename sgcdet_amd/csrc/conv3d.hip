@@ -486,6 +486,20 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   store_A();
   store_B(0);
   __syncthreads();
+  // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
+  // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
+  bf16x8 ah_n[2], al_n[2];
+  auto read_A0 = [&](int tap) {
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    const int toff = ((dx - 1) * HY + (dy - 1)) * HZ + (dz - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (arow[i] + toff) * LDKH + fh * 8;
+      ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+      al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+    }
+  };
+  read_A0(0);
   for (int cc = c_lo; cc < c_hi; ++cc) {
     for (int tap = 0; tap < 27; ++tap, ++g) {
       const bool last_tap = tap == 26;
@@ -501,9 +515,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
-          ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-          al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+          if (kk == 0) {
+            ah[i] = ah_n[i]; al[i] = al_n[i];
+          } else {
+            const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
+            ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+            al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -519,12 +537,14 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           }
       }
+      if (!last_tap) read_A0(tap + 1);
       if (more) store_B((g + 1) & 1);
       __syncthreads();
     }
     if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
       store_A();
       __syncthreads();
+      read_A0(0);
     }
   }
 

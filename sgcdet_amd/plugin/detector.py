@@ -68,8 +68,10 @@ class SGCDet(nn.Module):
         if (not self.use_graph) or self.training or torch.is_grad_enabled() or not volume.is_cuda:
             return self._neck_head_eager(volume)
         from .conv_plan import CONV_MODE, module_fingerprint
+        # one graph (and one set of static buffers) per stream: scenes in flight on different streams
+        # must not share replay buffers
         key = (tuple(volume.shape), tuple(volume.stride()), CONV_MODE, module_fingerprint(self.neck_3d),
-               module_fingerprint(self.bbox_head))
+               module_fingerprint(self.bbox_head), torch.cuda.current_stream().cuda_stream)
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
