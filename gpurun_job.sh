@@ -1,7 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_modules.py -m gpu -x -q 2>&1 | tail -6
-for w in cfg3_arkit cfg4_scannet200_large cfg5_arkit_large; do
-  timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])"
-done
-timeout 300 python bench.py --workload cfg2_scannet --views 100 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cfg2@100views', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'])"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_v3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/bench_prof_v3.json 2> $R/gpurun_out/bench_prof_v3.err
+cd $R
+cut -c1-250 gpurun_out/bench_prof_v3.json
+timeout 300 python bench.py --steps 40 --warmup 6 2>/dev/null > gpurun_out/bench_v3.json; cut -c1-250 gpurun_out/bench_v3.json

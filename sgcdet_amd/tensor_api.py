@@ -155,6 +155,8 @@ class TensorOps:
             raise RuntimeError("dfa3d_forward: inconsistent shapes")
         out = torch.empty((B, Q, M * Cm), dtype=value.dtype, device=value.device)
         score = torch.empty((B, Q, M, L, P, 4), dtype=value.dtype, device=value.device) if want_score else None
+        if B * Q == 0:                        # nothing to sample (e.g. no camera sees any voxel)
+            return out, score
         self._call("sgc_dfa3d_forward", value, dist, shapes3, lsi, loc3, attn, out, score,
                    B, S, M, Cm, D, dist_heads, L, Q, P)
         return out, score
@@ -173,6 +175,8 @@ class TensorOps:
         grad_loc3 = torch.empty_like(loc3)
         grad_attn = torch.empty((B, Q, M, L, P), dtype=value.dtype, device=value.device) \
             if want_grad_attn else None
+        if B * Q == 0:
+            return grad_value, grad_dist, grad_loc3, grad_attn
         self._call("sgc_dfa3d_backward", value, dist, shapes3, lsi, loc3, attn, grad_out, grad_value,
                    grad_dist, grad_loc3, grad_attn, B, S, M, Cm, D, dist_heads, L, Q, P)
         return grad_value, grad_dist, grad_loc3, grad_attn
@@ -223,6 +227,8 @@ class TensorOps:
         cap = pair_cam.numel()
         rows = n_pairs if n_pairs >= 0 else cap
         out = torch.empty((rows, Cc), dtype=torch.float32, device=feat.device)
+        if rows == 0:
+            return out
         self._call("sgc_pairs_geometry_sample", feat, dist, ref_cam, pair_cam, pair_q, totals, out,
                    N, Nq, H, W, Cc, D, n_pairs, cap,
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, n_pairs=rows))
@@ -254,6 +260,8 @@ class TensorOps:
         if S != H * W or raw.shape[-1] != M * P * 4 or raw.shape[0] < rows:
             raise RuntimeError("pairs_deform_gather: inconsistent shapes")
         out = torch.empty((rows, Cc), dtype=torch.float32, device=value.device)
+        if rows == 0:
+            return out
         if dist_pairs is not None and dist_pairs.shape != (N, H, W + 1, D, 2):
             raise RuntimeError("pairs_deform_gather: dist_pairs must be [N, H, W+1, D, 2]")
         self._call("sgc_pairs_deform_gather", value, dist, dist_pairs, ref_cam, raw, pair_cam, pair_q, totals, out,
@@ -269,6 +277,8 @@ class TensorOps:
         N, Nq = slot.shape
         Cc = feat.shape[1]
         mean = torch.empty((n_valid, Cc), dtype=torch.float32, device=feat.device)
+        if n_valid == 0:
+            return mean
         self._call("sgc_view_mean", feat, slot, valid_index, mean, N, Nq, Cc, n_valid)
         return mean
 
@@ -281,6 +291,8 @@ class TensorOps:
         if kv.shape[1] != 2 * Cc:
             raise RuntimeError("view_attend: kv must be [n_pairs, 2C]")
         ctx = torch.empty_like(q)
+        if n_valid == 0:
+            return ctx
         self._call("sgc_view_attend", q, kv, slot, valid_index, ctx, N, Nq, Cc, heads, n_valid)
         return ctx
 
@@ -292,6 +304,8 @@ class TensorOps:
         n, Cc = rows.shape
         if vol.shape[-1] != Cc:
             raise RuntimeError("scatter_rows: channel mismatch")
+        if n == 0:
+            return vol
         self._call("sgc_scatter_rows", rows, idx, idx2, vol, n, Cc)
         return vol
 
@@ -392,5 +406,7 @@ class TensorOps:
         self._i64(idx=idx)
         if rows.shape[1] != vol.shape[1] or idx.numel() != rows.shape[0]:
             raise RuntimeError("scatter_add_rows: inconsistent shapes")
+        if rows.shape[0] == 0:
+            return vol
         self._call("sgc_scatter_add_rows", rows, idx, vol, rows.shape[0], rows.shape[1])
         return vol
