@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="scenes in flight per GPU: consecutive steps alternate over this many HIP streams so the host "
                          "syncs / launch gaps of one scene overlap the kernels of the other")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the neck/head kernels eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     return ap.parse_args()
@@ -121,6 +123,9 @@ def main():
     w = workload(args.workload)
     n_views = args.views or w["n_views"]
     det = build_path(w, device)
+    from sgcdet_amd import runtime_env
+    if args.no_graph or (args.streams > 1 and not runtime_env.graph_concurrency_safe()):
+        det.use_graph = False      # see sgcdet_amd/runtime_env.py: graph replays beside another stream's eager kernels
     # a few distinct scenes per rank, resident in HBM before the timed region
     n_scenes = 3
     scenes = []
@@ -158,6 +163,33 @@ def main():
     elapsed = time.perf_counter() - t0
     log, ops.event_log = ops.event_log, None
     elapsed = sgc_dist.max_over_ranks(elapsed, device=device)
+
+    # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
+    self_check = None
+    if rank == 0:
+        graph_was = det.use_graph
+        det.use_graph = False
+        with torch.no_grad():
+            serial = []
+            for feats, dpt, metas in scenes:
+                r = det.forward_features(feats, metas, dpt)
+                serial.append((r["volume"].clone(), r["occ"].clone()))
+        torch.cuda.synchronize()
+        det.use_graph = graph_was
+        runs = [(i, step(i)) for i in range(10 * n_scenes)]
+        torch.cuda.synchronize()
+        bad = [i for i, r in runs if not (torch.equal(r["volume"], serial[i % n_scenes][0])
+                                           and torch.equal(r["occ"], serial[i % n_scenes][1]))]
+        worst = max([float((r["volume"] - serial[i % n_scenes][0]).abs().max()) for i, r in runs] + [0.0])
+        self_check = dict(scene_runs=len(runs), mismatching=len(bad), max_abs_diff=worst,
+                          compared="volume+occ bit-exact vs serial eager launch")
+        if os.environ.get("SGC_BENCH_DEBUG"):
+            print("self-check mismatching runs:", bad, file=sys.stderr)
+            for i, r in runs[:6]:
+                print(i, float((r["volume"] - serial[i % n_scenes][0]).abs().max()),
+                      float((r["occ"] - serial[i % n_scenes][1]).abs().max()),
+                      int((r["valid"] != 0).sum()), file=sys.stderr)
+        del runs
 
     # ---- roofline of the dominant hand-written kernel: finest-level deformable gather ----
     per_kernel = {}
@@ -205,8 +237,10 @@ def main():
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
                        "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams,
+                       "neck_head_launch": "hipGraph replay" if det.use_graph else "eager",
                        "sharding": "scenes across ranks, no collective"},
             "roofline": roofline,
+            "self_check": self_check,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

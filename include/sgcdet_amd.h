@@ -196,13 +196,16 @@ int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float 
  *       [ M*P*2 uv offsets (m,p,xy) | M*P depth offsets (m,p) | M*P attention logits (m,p) ],
  *   out [n_pairs, M*Cm] fully written.
  *   dist_pairs_or_null: optional pair-interleaved copy of dist made by sgc_depth_pairs -- same results,
- *   half the depth load instructions (the depth taps of one image row become 16 contiguous bytes). */
+ *   half the depth load instructions (the depth taps of one image row become 16 contiguous bytes).
+ *   value_has_zero_row != 0: the caller appended ONE all-zero row after the N*S rows of `value`
+ *   (value then holds N*S+1 rows); corners outside the image are pointed at it instead of being zeroed
+ *   by a select per load -- same results, fewer instructions on the load path.                     */
 int sgc_pairs_deform_gather(const float *value, const float *dist, const float *dist_pairs_or_null,
                             const float *ref_cam,
                             const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                             const int32_t *totals, float *out,
                             int N, int Nq, int H, int W, int M, int Cm, int D, int P,
-                            int n_pairs_or_neg, int cap, sgc_stream_t stream);
+                            int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream);
 
 /* dp [N,H,W+1,D,2]: dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0); dist [N,H*W,D]. */
 int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream);

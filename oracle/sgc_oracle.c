@@ -506,8 +506,8 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
                             const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                             const int32_t *totals, float *out,
                             int N, int Nq, int H, int W, int M, int Cm, int D, int P,
-                            int n_pairs_or_neg, int cap, sgc_stream_t stream) {
-  (void)stream; (void)N; (void)dist_pairs_or_null;   /* the oracle always samples the plain map */
+                            int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  (void)stream; (void)N; (void)dist_pairs_or_null; (void)value_has_zero_row;   /* the oracle always samples the plain map */
   if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
   if (P > 64) return fail(SGC_EUNSUP, "P > 64");
   int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);

@@ -22,7 +22,7 @@ SIGNATURES = {
     "sgc_project_points": [_p] * 5 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 8 + [_p],
-    "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 10 + [_p],
+    "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 11 + [_p],
     "sgc_depth_pairs": [_p, _p] + [_i] * 4 + [_p],
     "sgc_view_mean": [_p] * 4 + [_i] * 4 + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 5 + [_p],

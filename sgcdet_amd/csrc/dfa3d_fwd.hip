@@ -46,6 +46,8 @@ struct FwdParams {
   int S, M, Cm, D, dist_heads, L, Q, P, Nq;
   int H, W;                 // pairs mode (single level)
   int64_t value_bytes;      // size of the value map in bytes (pairs modes)
+  int zero_row;             // >= 0: row index (in units of M*Cm floats from `value`) of an all-zero row the caller
+                            // appended to the map; corners outside the image are pointed at it (no select needed)
   int n_items;              // < 0: read totals[0]
   int TP;                   // items per tile
 };
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
 // so the gather of one (item, head) is fully unrolled: all 4*PT row loads are in flight together.
 // (forcing more waves per SIMD with __launch_bounds__(256, 6|8) spills the 16 in-flight rows to scratch:
 //  2-3x slower, measured -- the kernel wants its 99 VGPRs and 4 waves/SIMD.)
-template <int MODE, int PT, int MT = 0, int CMT = 0, int SPL = 1>
+template <int MODE, int PT, int MT = 0, int CMT = 0, int SPL = 1, bool ZR = false>
 __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) {
   // SPL = samples per lane in phase 1: a wave owns SPL * 64 / SPI items.  Phase 1 is a chain of dependent
   // loads (pair -> reference point -> depth); with SPL > 1 the chains of SPL samples are issued together,
@@ -279,7 +281,13 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       else
         make_sample(sm, p.dist + (int64_t)bb[j] * p.S * p.D, (int64_t)p.D, p.H, p.W, p.D, x[j], y[j], z[j], aw[j]);
       w_[slot] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);
-      o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
+      if (ZR) {   // global row index, outside corners -> the appended zero row
+        const int cb = bb[j] * p.S;
+        o_[slot] = make_int4(sm.off[0] < 0 ? p.zero_row : cb + sm.off[0], sm.off[1] < 0 ? p.zero_row : cb + sm.off[1],
+                             sm.off[2] < 0 ? p.zero_row : cb + sm.off[2], sm.off[3] < 0 ? p.zero_row : cb + sm.off[3]);
+      } else {
+        o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
+      }
       if (r == 0) b_[il] = bb[j];
     }
   }
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
     // 32-bit byte offsets on the uniform base pointer (host checks N*S*M*Cm*4 < 2^32): the loads take the
     // saddr + voffset form and the per-corner address is one 32-bit mad instead of 64-bit vector arithmetic
     const char *vbytes = reinterpret_cast<const char *>(p.value);
-    const unsigned rowb = ((unsigned)b_[il] * (unsigned)p.S * (unsigned)MC + (unsigned)(m * Cm + c0)) * 4u;
+    const unsigned rowb = ((ZR ? 0u : (unsigned)b_[il] * (unsigned)p.S * (unsigned)MC) + (unsigned)(m * Cm + c0)) * 4u;
     const unsigned rstride = (unsigned)MC * 4u;
     const float *vbase = p.value + (int64_t)b_[il] * p.S * MC + (m * Cm + c0);
     (void)vbase;
@@ -330,9 +338,9 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
 #elif defined(SGC_DIAG_SAME_ROW)
           v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)((off_index(ok[k]) & 7) * MC));
 #else
-          v[s][k] = *reinterpret_cast<const float4 *>(vbytes + (rowb + (unsigned)off_index(ok[k]) * rstride));
+          v[s][k] = *reinterpret_cast<const float4 *>(vbytes + (rowb + (unsigned)(ZR ? ok[k] : off_index(ok[k])) * rstride));
 #endif
-          if (ok[k] < 0) v[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!ZR && ok[k] < 0) v[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
 #pragma unroll
@@ -398,6 +406,8 @@ static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 4>), dim3(ceil_div(grid_items, 32)), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && g_tune_fwd_spl == 2)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 2>), dim3(ceil_div(grid_items, 16)), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32 && p.zero_row >= 0)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 1, true>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 16)
@@ -575,7 +585,7 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
                                        const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                                        const int32_t *totals, float *out,
                                        int N, int Nq, int H, int W, int M, int Cm, int D, int P,
-                                       int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+                                       int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
   if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out)
     return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: null pointer");
   if (n_pairs_or_neg < 0 && !totals) return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: totals required");
@@ -589,7 +599,8 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   p.pair_cam = pair_cam; p.pair_q = pair_q;
   p.totals = totals; p.out = out;
   p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
-  p.value_bytes = (int64_t)N * H * W * M * Cm * 4;
+  p.value_bytes = ((int64_t)N * H * W + 1) * M * Cm * 4;
+  p.zero_row = value_has_zero_row ? N * H * W : -1;
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
   return launch_fwd<kPairsDeform>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }

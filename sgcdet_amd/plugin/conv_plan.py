@@ -111,8 +111,15 @@ class LinearSpec:
             self.shift[:cout] = bias.detach().float()
         self.cout, self.cout_p = cout, cout_p
 
-    def __call__(self, x):
+    def __call__(self, x, extra_zero_row=False):
+        """``extra_zero_row``: the result is a view of an [M+1, out] buffer whose last row is zero (the
+        gather kernel points out-of-image corners at it)."""
         M = x.shape[0]
+        if extra_zero_row and CONV_MODE == "bf16x3" and self.cout_p == self.cout:
+            buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
+            buf[M].zero_()
+            ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, (M, 1, 1), 1, 1, False, None, self.shift, out=buf[:M])
+            return buf[:M]
         if CONV_MODE == "bf16x3":
             y, _ = ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, (M, 1, 1), 1, 1, False, None, self.shift)
         else:

@@ -75,8 +75,13 @@ class SGCDet(nn.Module):
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
-            if len(cache) > 8:
-                cache.clear()
+            if len(cache) >= 16:
+                # evict the oldest graph -- only after the device is idle: destroying a graph (and handing its
+                # private memory pool back to the allocator) while one of its replays is still running on
+                # another stream corrupts whatever gets that memory next (seen as rare wrong voxel features
+                # with two scenes in flight)
+                torch.cuda.synchronize()
+                cache.pop(next(iter(cache)))
             static_in = torch.empty_strided(volume.shape, volume.stride(), dtype=volume.dtype, device=volume.device)
             static_in.copy_(volume)
             side = torch.cuda.Stream()

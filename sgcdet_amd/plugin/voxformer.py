@@ -211,11 +211,14 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
             use_mfma = self.inter_view_aggregation == "attn" and C % 32 == 0
             gemm = self._gemm_plan() if use_mfma else None
-            value = gemm["value"](feat.view(N * H * W, C)) if use_mfma else da.value_proj(feat)
+            from .conv_plan import CONV_MODE
+            zero_row = use_mfma and CONV_MODE == "bf16x3"
+            value = gemm["value"](feat.view(N * H * W, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
             raw = gemm["raw"](geo) if use_mfma else da.raw_projection(geo)
             per_pair = ops.pairs_deform_gather(value.view(N, H * W, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
-                                               da.num_heads, da.num_points, dist_pairs=ops.depth_pairs(dist, H, W))
+                                               da.num_heads, da.num_points, dist_pairs=ops.depth_pairs(dist, H, W),
+                                               zero_row=zero_row)
         else:
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]

@@ -246,7 +246,9 @@ class TensorOps:
         return dp
 
     def pairs_deform_gather(self, value, dist, ref_cam, raw, pair_cam, pair_q, n_pairs, H, W, M, P,
-                            totals=None, dist_pairs=None):
+                            totals=None, dist_pairs=None, zero_row=False):
+        """``zero_row=True`` promises that ``value`` is a view of a buffer holding one extra all-zero row
+        right behind its N*S rows (see ``LinearSpec.__call__(extra_zero_row=True)``)."""
         self._check(value=value, dist=dist, ref_cam=ref_cam, raw=raw, pair_cam=pair_cam,
                     pair_q=pair_q, totals=totals, dist_pairs=dist_pairs)
         self._f32(value=value, dist=dist, ref_cam=ref_cam, raw=raw, dist_pairs=dist_pairs)
@@ -265,7 +267,7 @@ class TensorOps:
         if dist_pairs is not None and dist_pairs.shape != (N, H, W + 1, D, 2):
             raise RuntimeError("pairs_deform_gather: dist_pairs must be [N, H, W+1, D, 2]")
         self._call("sgc_pairs_deform_gather", value, dist, dist_pairs, ref_cam, raw, pair_cam, pair_q, totals, out,
-                   N, Nq, H, W, M, Cm, D, P, n_pairs, cap,
+                   N, Nq, H, W, M, Cm, D, P, 1 if zero_row else 0, n_pairs, cap,
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, M=M, P=P, n_pairs=rows))
         return out
 
@@ -341,7 +343,7 @@ class TensorOps:
         return hi.contiguous(), lo.contiguous()
 
     def conv3d_cl_bf16x3(self, x, w_hi, w_lo, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
-                         residual=None, relu=False):
+                         residual=None, relu=False, out=None):
         """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``)."""
         self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual)
         self._f32(x=x, scale=scale, shift=shift, residual=residual)
@@ -353,7 +355,11 @@ class TensorOps:
         if V != ix * iy * iz or Cin2 != Cin or taps != (8 if transposed else ksize ** 3):
             raise RuntimeError("conv3d_cl_bf16x3: inconsistent shapes")
         og = (2 * ix, 2 * iy, 2 * iz) if transposed else tuple((d + 2 * (ksize // 2) - ksize) // stride + 1 for d in grid)
-        y = torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
+        if out is not None:
+            self._check(out=out)
+            if out.shape != (og[0] * og[1] * og[2], Cout) or out.dtype != torch.float32:
+                raise RuntimeError("conv3d_cl_bf16x3: bad `out` tensor")
+        y = out if out is not None else torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError("conv3d_cl_bf16x3: residual shape mismatch")
         self._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize,

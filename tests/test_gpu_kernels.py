@@ -184,6 +184,11 @@ def test_pair_list_gathers_and_view_pool(C, M, P, HW, oracle_ops, gpu_ops):
     dg_g2 = gpu_ops.pairs_deform_gather(cu(value), cu(dist), cu(rc), cu(raw), cu(pc["pair_cam"]), cu(pc["pair_q"]),
                                         n_pairs, H, W, M, P, dist_pairs=dp)
     close(dg_g2, dg_c)                                       # pair-interleaved depth taps: same results
+    vbuf = torch.cat([cu(value).reshape(N * H * W, C), torch.zeros(1, C, device="cuda")])
+    dg_g3 = gpu_ops.pairs_deform_gather(vbuf[:N * H * W].view(N, H * W, M, C // M), cu(dist), cu(rc), cu(raw),
+                                        cu(pc["pair_cam"]), cu(pc["pair_q"]), n_pairs, H, W, M, P, dist_pairs=dp,
+                                        zero_row=True)
+    close(dg_g3, dg_c)                                       # outside corners -> appended zero row: same results
     mean_c = oracle_ops.view_mean(dg_c, pc["slot"], pc["valid_index"], n_valid)
     mean_g = gpu_ops.view_mean(dg_g, cu(pc["slot"]), cu(pc["valid_index"]), n_valid)
     close(mean_g, mean_c)

@@ -32,7 +32,10 @@ ref3d = (xs * torch.tensor([.16, .16, .2]) - torch.tensor([nx, ny, nz]) / 2 * to
 ref_cam, mask = ops.project_points(ref3d, origin, proj, 320, 239, 0.2, 5.0)
 pc = ops.compact_pairs(mask)
 n_pairs = int(pc["totals"][0])
-value = torch.randn(N, H * W, M, C // M, device=dev)
+vbuf = torch.randn(N * H * W + 1, C, device=dev)
+vbuf[-1].zero_()
+value = vbuf[:N * H * W].view(N, H * W, M, C // M)
+ZR = os.environ.get("SGC_ZR", "1") == "1"
 dist = torch.randn(N, H * W, D, device=dev).mul(2).softmax(-1).contiguous()
 raw = torch.randn(n_pairs, M * P * 4, device=dev)
 raw[:, :M * P * 2] *= float(os.environ.get("SGC_OFFSET_SCALE", "2.0"))
@@ -50,7 +53,7 @@ dp = ops.depth_pairs(dist, H, W) if os.environ.get("SGC_DP", "1") == "1" else No
 def run(kind):
     if kind == "deform":
         return ops.pairs_deform_gather(value, dist, ref_cam, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P,
-                                       dist_pairs=dp)
+                                       dist_pairs=dp, zero_row=ZR)
     return ops.pairs_geometry_sample(feat, dist, ref_cam, pc["pair_cam"], pc["pair_q"], n_pairs, H, W)
 
 
