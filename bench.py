@@ -123,9 +123,8 @@ def main():
     w = workload(args.workload)
     n_views = args.views or w["n_views"]
     det = build_path(w, device)
-    from sgcdet_amd import runtime_env
-    if args.no_graph or (args.streams > 1 and not runtime_env.graph_concurrency_safe()):
-        det.use_graph = False      # see sgcdet_amd/runtime_env.py: graph replays beside another stream's eager kernels
+    if args.no_graph:
+        det.use_graph = False
     # a few distinct scenes per rank, resident in HBM before the timed region
     n_scenes = 3
     scenes = []

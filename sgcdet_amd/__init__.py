@@ -10,6 +10,3 @@ Layout (only what the path needs):
 """
 __version__ = "0.1.0"
 
-from . import runtime_env as _runtime_env
-
-_runtime_env.apply()          # HIP runtime knobs that must be in the environment before the first HIP call

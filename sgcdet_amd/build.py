@@ -13,6 +13,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsgcdet_amd.so")
 ARCH = "gfx950"
+# Packed-FP32 VALU instructions are switched off for every kernel of this library.  Measured on MI355X
+# (tools/hazard/pk_mfma_repro.hip, a 150-line reproducer): `v_pk_fma_f32` with an op_sel operand swizzle returns
+# wrong values in lanes 48-63 while waves of the bf16 implicit-GEMM kernel (v_mfma_f32_32x32x16_bf16) run on the
+# same SIMD from another stream.  The compiler emits exactly that instruction for `x * W - 0.5` pairs in the
+# gather kernels, which corrupted ~0.3 % of the gathered rows whenever two scenes were in flight.  Without
+# the packed forms the kernels are bit-identical to their serial results under any overlap.
+NO_PACKED_FP32 = ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops")
+# per-file extra flags (experiments: SGC_FLAGS_<stem>="..." in the environment)
+FILE_FLAGS = {}
+for _k, _v in os.environ.items():
+    if _k.startswith("SGC_FLAGS_"):
+        FILE_FLAGS[_k[len("SGC_FLAGS_"):] + ".hip"] = _v.split()
 
 
 def sources():
@@ -37,7 +49,8 @@ def build(force=False, verbose=False, extra_flags=()):
     for src in sources():
         obj = src[:-4] + ".o"
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", *extra_flags]
+               "-Wall", "-Wno-unused-function", *NO_PACKED_FP32, *extra_flags,
+               *FILE_FLAGS.get(os.path.basename(src), ())]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

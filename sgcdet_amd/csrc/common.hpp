@@ -36,6 +36,18 @@ typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));  // 4-by
 constexpr int kOutside = (int)0x80000000;
 __device__ __forceinline__ int off_index(int off) { return off & 0x7fffffff; }
 
+// Butterfly exchange with lane ^ o.  o = 1, 2 stay on the VALU as DPP quad permutes (no trip through the
+// LDS crossbar that ds_bpermute takes); larger strides fall back to __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor(float v, int o) {
+  if (o == 1) return dpp_move<0xB1>(v);    // quad_perm:[1,0,3,2]
+  if (o == 2) return dpp_move<0x4E>(v);    // quad_perm:[2,3,0,1]
+  return __shfl_xor(v, o);
+}
+
 // One trilinear sample of the DFA3D operator, reduced to what the gather needs:
 // 4 corner weights (bilinear * depth score * attention weight) and 4 pixel indices
 // (-1 = corner outside the map).  Semantics: ms_depth_score_sample_cuda_kernel.cuh:24-148

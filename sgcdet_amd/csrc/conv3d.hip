@@ -256,14 +256,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       const int xx = ax[i] * p.stride + dx - p.pad, yy = ay[i] * p.stride + dy - p.pad,
                 zz = az[i] * p.stride + dz - p.pad;
       const bool ok = arow_ok[i] && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
+#if defined(SGC_DIAG_IG_NO_LOADS)
+      ra[i] = make_float4(0.001f * xx, 0.002f * yy, 0.003f * zz, ok ? 1.f : 0.f);
+#else
       ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + cib + c4 * 4)
                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int n = n0 + br0 + BROWS_ * i;
       const int64_t off = ((int64_t)tap * p.Cout + n) * p.Cin + cib + bc * 8;
+#if defined(SGC_DIAG_IG_NO_LOADS)
+      if (n < 0) {
+#else
       if (n < p.Cout) {
+#endif
         rbh[i] = *reinterpret_cast<const uint4 *>(p.w_hi + off);
         rbl[i] = *reinterpret_cast<const uint4 *>(p.w_lo + off);
       } else {
@@ -280,9 +288,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+#if defined(SGC_DIAG_IG_NO_SPLIT)
+        h[e] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(v[e]) >> 16));
+        l[e] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(v[e]) & 0xffffu));
+#else
         const __bf16 hb = (__bf16)v[e];
         h[e] = hb;
         l[e] = (__bf16)(v[e] - (float)hb);
+#endif
       }
       const int o = (r0 + AROWS * i) * LDKH + c4 * 4;
       *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
@@ -332,14 +345,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+#if defined(SGC_DIAG_IG_NO_MFMA)
+          acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1] + (float)ah[i][2] * (float)bh[j][2];
+#elif defined(SGC_DIAG_IG_ONE_PRODUCT)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#elif defined(SGC_DIAG_IG_REORDER)
+          (void)0;
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
         }
+#if defined(SGC_DIAG_IG_REORDER)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
     }
     if (s + 1 < nsteps) store_step(buf ^ 1);
     __syncthreads();
   }
+#if defined(SGC_DIAG_IG_NO_EPILOGUE)
+  if (acc[0][0][0] != 123.456f) return;
+#endif
 
 #pragma unroll
   for (int i = 0; i < TM; ++i)

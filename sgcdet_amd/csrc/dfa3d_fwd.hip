@@ -50,7 +50,14 @@ struct FwdParams {
                             // appended to the map; corners outside the image are pointed at it (no select needed)
   int n_items;              // < 0: read totals[0]
   int TP;                   // items per tile
+#if defined(SGC_DIAG_DESC)
+  float *dbg;               // diagnostic build: [2][items][M*P][12] produced / consumed descriptors
+#endif
 };
+#if defined(SGC_DIAG_DESC)
+static float *g_dbg = nullptr;
+extern "C" int sgc_debug_buffer(void *ptr) { g_dbg = (float *)ptr; return 0; }
+#endif
 
 template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
@@ -263,11 +270,11 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
         z[j] = z[j] + dzv[j] * rD;
         float mx = lgv[j];
 #pragma unroll
-        for (int o = 1; o < P; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        for (int o = 1; o < P; o <<= 1) mx = fmaxf(mx, lane_xor(mx, o));
         const float e = __expf(lgv[j] - mx);
         float sum = e;
 #pragma unroll
-        for (int o = 1; o < P; o <<= 1) sum += __shfl_xor(sum, o);
+        for (int o = 1; o < P; o <<= 1) sum += lane_xor(sum, o);
         aw[j] = e * __frcp_rn(sum);
       }
     }
@@ -289,6 +296,15 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
         o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
       }
       if (r == 0) b_[il] = bb[j];
+#if defined(SGC_DIAG_DESC)
+      if (p.dbg && item0 + il < n_items) {
+        float *d = p.dbg + ((int64_t)(item0 + il) * SPI + r) * 12;
+        const int4 oo = o_[slot];
+        d[0] = sm.w[0]; d[1] = sm.w[1]; d[2] = sm.w[2]; d[3] = sm.w[3];
+        d[4] = __int_as_float(oo.x); d[5] = __int_as_float(oo.y); d[6] = __int_as_float(oo.z); d[7] = __int_as_float(oo.w);
+        d[8] = x[j]; d[9] = y[j]; d[10] = z[j]; d[11] = aw[j];
+      }
+#endif
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -327,6 +343,16 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       float4 v[PT > 0 ? PT : 1][4];
 #pragma unroll
       for (int s = 0; s < PT; ++s) { w[s] = w_[d0 + s]; o[s] = o_[d0 + s]; }
+#if defined(SGC_DIAG_DESC)
+      if (p.dbg && c0 == 0) {
+#pragma unroll
+        for (int s = 0; s < PT; ++s) {
+          float *d = p.dbg + ((int64_t)(n_items + item) * SPI + m * LP + s) * 12;
+          d[0] = w[s].x; d[1] = w[s].y; d[2] = w[s].z; d[3] = w[s].w;
+          d[4] = __int_as_float(o[s].x); d[5] = __int_as_float(o[s].y); d[6] = __int_as_float(o[s].z); d[7] = __int_as_float(o[s].w);
+        }
+      }
+#endif
 #pragma unroll
       for (int s = 0; s < PT; ++s) {
         const int ok[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
@@ -601,6 +627,9 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
   p.value_bytes = ((int64_t)N * H * W + 1) * M * Cm * 4;
   p.zero_row = value_has_zero_row ? N * H * W : -1;
+#if defined(SGC_DIAG_DESC)
+  p.dbg = g_dbg;
+#endif
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
   return launch_fwd<kPairsDeform>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }

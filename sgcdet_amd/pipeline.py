@@ -16,37 +16,17 @@ class ScenePipeline:
 
     ``scenes`` is an iterable of ``(mlvl_feats, img_metas, dpt_dist)``; every result is the dict of
     ``SGCDet.forward_features`` with the head tensors CLONED (the neck/head tail replays a per-stream
-    hipGraph whose output buffers are reused by the next scene on that stream).
-
-    With more than one stream the hipGraph replay is only used when the HIP runtime was configured for it
-    in time (``runtime_env.graph_concurrency_safe``); otherwise the neck/head kernels are launched eagerly:
-    graph replays beside eager kernels of another stream are not reliable on ROCm 7's default launch path."""
+    hipGraph whose output buffers are reused by the next scene on that stream)."""
 
     def __init__(self, detector, n_streams=2, device=None):
         self.det = detector
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_streams))]
         self.host_sync = False
-        from . import runtime_env
-        self.allow_graph = len(self.streams) == 1 or runtime_env.graph_concurrency_safe()
-        if not self.allow_graph:
-            import warnings
-            warnings.warn("sgcdet_amd: the GPU was initialised before the package could set "
-                          f"{runtime_env.GRAPH_KNOB}=0; scenes in flight on several streams will launch the "
-                          "neck/head eagerly (slower) instead of replaying hipGraphs", RuntimeWarning)
 
     @torch.no_grad()
     def run(self, scenes, keep=("volume", "valid", "occ", "centerness", "bbox_pred", "cls_score")):
         results = []
-        graph_before = self.det.use_graph
-        if not self.allow_graph:
-            self.det.use_graph = False
-        try:
-            return self._run(scenes, keep, results)
-        finally:
-            self.det.use_graph = graph_before
-
-    def _run(self, scenes, keep, results):
         main = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(main)                      # inputs produced on the caller's stream

@@ -76,10 +76,8 @@ class SGCDet(nn.Module):
         entry = cache.get(key)
         if entry is None:
             if len(cache) >= 16:
-                # evict the oldest graph -- only after the device is idle: destroying a graph (and handing its
-                # private memory pool back to the allocator) while one of its replays is still running on
-                # another stream corrupts whatever gets that memory next (seen as rare wrong voxel features
-                # with two scenes in flight)
+                # evict the oldest graph -- only after the device is idle: destroying a graph hands its private
+                # memory pool back to the allocator, which must not happen while a replay is still running
                 torch.cuda.synchronize()
                 cache.pop(next(iter(cache)))
             static_in = torch.empty_strided(volume.shape, volume.stride(), dtype=volume.dtype, device=volume.device)

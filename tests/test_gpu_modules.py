@@ -191,3 +191,47 @@ def test_two_scenes_in_flight_give_the_same_results():
             for k in ("centerness", "bbox_pred", "cls_score"):
                 for x, y in zip(a[k], b[k]):
                     assert max_err(x, y) < 1e-5 * max(1.0, x.abs().max().item())   # split-K atomics reorder sums
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_overlapping_scenes_are_bit_exact_at_full_size(use_graph):
+    """Config 2 (40 views, 40x40x16) stepped the way bench.py does -- consecutive scenes on alternating
+    streams, nothing cloned, no sync in between, so the neck convolutions of one scene run beside the
+    gathers of the next -- must reproduce the serial, eagerly launched voxel features bit for bit.
+    (Before the packed-FP32 forms were switched off in the build this failed on ~9 of 10 scenes: the
+    gfx950 hazard of DESIGN.md 4.6.)"""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg2_scannet")
+    torch.manual_seed(0)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for _, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.02)
+    det = det.cuda()
+    scenes = []
+    for s in range(3):
+        feats, dpt, meta = make_scene(w["n_views"], w["embed_dims"], kind=w["kind"], seed=s, device="cuda")
+        scenes.append((feats, dpt, [meta]))
+    det.use_graph = False
+    serial = []
+    with torch.no_grad():
+        for feats, dpt, metas in scenes:
+            r = det.forward_features(feats, metas, dpt)
+            serial.append((r["volume"].clone(), r["occ"].clone(), r["valid"].clone()))
+    torch.cuda.synchronize()
+    det.use_graph = use_graph
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    runs = []
+    with torch.no_grad():
+        for i in range(24):
+            feats, dpt, metas = scenes[i % 3]
+            with torch.cuda.stream(streams[i % 2]):
+                r = det.forward_features(feats, metas, dpt)
+                runs.append((i, r["volume"], r["occ"], r["valid"]))
+    torch.cuda.synchronize()
+    wrong = [i for i, v, o, m in runs
+             if not (torch.equal(v, serial[i % 3][0]) and torch.equal(o, serial[i % 3][1]) and torch.equal(m, serial[i % 3][2]))]
+    assert not wrong, f"scene runs {wrong} differ from the serial result"

@@ -16,6 +16,31 @@ for s in range(3):
 ops = ext.ops()
 if os.environ.get("NONECK"):
     det._neck_head = lambda volume: ([volume], [volume], [volume])
+if os.environ.get("NECKSUB"):
+    kind = os.environ["NECKSUB"]
+    def mk(grid, cin, cout, k):
+        x = torch.randn(grid[0] * grid[1] * grid[2], cin, device=dev)
+        wt = torch.randn(k ** 3 if k != 2 else 8, cout, cin, device=dev) * 0.02
+        wh, wl = ops.split_bf16(wt)
+        return x, wh, wl
+    if kind == "halo":
+        X = mk((40, 40, 16), 256, 256, 3); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (40, 40, 16), 3, 1, False)
+    elif kind == "s2":       # stride-2 igemm 256 -> 512
+        X = mk((40, 40, 16), 256, 512, 3); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (40, 40, 16), 3, 2, False)
+    elif kind == "splitk":   # small grid, 27 taps -> split-K with atomics + memset + epilogue
+        X = mk((10, 10, 4), 1024, 1024, 3); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (10, 10, 4), 3, 1, False)
+    elif kind == "mid":      # 20x20x8 x 512
+        X = mk((20, 20, 8), 512, 512, 3); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (20, 20, 8), 3, 1, False)
+    elif kind == "tr":       # transposed 2x2x2
+        X = mk((20, 20, 8), 512, 256, 2); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (20, 20, 8), 2, 2, True)
+    elif kind == "k1":
+        X = mk((25600, 1, 1), 256, 256, 1); call = lambda: ops.conv3d_cl_bf16x3(X[0], X[1], X[2], (25600, 1, 1), 1, 1, False)
+    reps = int(os.environ.get("REPS", "12"))
+    def sub(volume):
+        for _ in range(reps):
+            call()
+        return ([volume], [volume], [volume])
+    det._neck_head = sub
 if os.environ.get("CONVHALO"):
     ops.lib.call("sgc_set_tuning", b"conv_halo", int(os.environ["CONVHALO"]))
 if os.environ.get("CONVWAVES"):

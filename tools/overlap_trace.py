@@ -32,6 +32,14 @@ def wrap(name):
 for n in ("project_points", "compact_pairs", "nchw_to_nhwc_crop", "pairs_geometry_sample", "conv3d_cl_bf16x3", "depth_pairs",
           "pairs_deform_gather", "view_mean", "view_attend", "upsample2x_occ", "scatter_add_rows", "scatter_rows"):
     wrap(n)
+if os.environ.get("RAWSHIFT"):
+    _g = ops.pairs_deform_gather
+    sh = int(os.environ["RAWSHIFT"])          # floats
+    def g(value, dist, ref_cam, raw, *a, **k):
+        buf = torch.empty(raw.numel() + sh, dtype=raw.dtype, device=raw.device)
+        r2 = buf[sh:].view(raw.shape); r2.copy_(raw)
+        return _g(value, dist, ref_cam, r2, *a, **k)
+    ops.pairs_deform_gather = g
 _lin = F.linear
 def lin(x, w_, b=None):
     y = _lin(x, w_, b); rec("F.linear", y); return y
