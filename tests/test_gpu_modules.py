@@ -199,7 +199,7 @@ def test_overlapping_scenes_are_bit_exact_at_full_size(use_graph):
     streams, nothing cloned, no sync in between, so the neck convolutions of one scene run beside the
     gathers of the next -- must reproduce the serial, eagerly launched voxel features bit for bit.
     (Before the packed-FP32 forms were switched off in the build this failed on ~9 of 10 scenes: the
-    gfx950 hazard of DESIGN.md 4.6.)"""
+    gfx950 hazard of DESIGN.md 4.7.)"""
     import sgcdet_amd.plugin  # noqa: F401
     from sgcdet_amd.mmcv_lite import build_detector
     from sgcdet_amd.scene import make_scene, model_config, workload
