@@ -214,10 +214,17 @@ int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sg
  * 5. Inter-view aggregation (TU/deformable_cross_attention.py:815-837)
  * ------------------------------------------------------------------------- */
 
+/* Row counts that live on the device.  sgc_compact_pairs leaves {n_pairs, n_valid, ...} in totals[]; the entry
+ * points below take an optional `*_dev_or_null` pointer to such a count next to the host-side integer: when it
+ * is non-NULL the kernels use min(host value, *device value) rows and the host value only bounds the grid
+ * (pass the capacity).  A whole scene can then be issued -- or captured into one hipGraph -- without the
+ * reference's per-level host read-back (`nonzero`, DenseHead.py:66, TU/deformable_cross_attention.py:759-762).  */
+
 /* Masked mean over the cameras that see a voxel (:819-826):
  *   feat [n_pairs,C], slot [N,Nq], valid_index [n_valid] -> mean [n_valid,C].      */
 int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
-                  float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream);
+                  float *mean, int N, int Nq, int C, const int32_t *n_valid_dev_or_null, int n_valid,
+                  sgc_stream_t stream);
 
 /* Softmax over views of nn.MultiheadAttention with query length 1 (:829-833):
  *   q [n_valid,C] (already in-projected, NOT yet scaled), kv [n_pairs,2C] (k | v
@@ -225,7 +232,8 @@ int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_i
  *   Invisible cameras are the reference's key_padding_mask = -inf entries.          */
 int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
                     const int32_t *valid_index, float *ctx,
-                    int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream);
+                    int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                    sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 6. Volume glue
@@ -235,7 +243,7 @@ int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
  * and `output[:,valid_index,:] = slots_mean`, TU/deformable_cross_attention.py:835-836).
  * idx2_or_null composes two index maps: dst row = idx2[idx[i]].                     */
 int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
-                     float *vol, int n, int C, sgc_stream_t stream);
+                     float *vol, const int32_t *n_dev_or_null, int n, int C, sgc_stream_t stream);
 
 /* NCHW -> NHWC crop-and-transpose of the FPN / depth maps
  * (TU/transformer.py:151-170 flatten+permute, AdaptiveSparseHead.py:53-59 crop):
@@ -286,6 +294,16 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                          int transposed, int relu, sgc_stream_t stream);
+
+/* nn.Linear over a row list whose length lives on the device (the Linears of
+ * MSDeformableAttention3D_DFA3D / nn.MultiheadAttention applied to the visible pairs,
+ * TU/deformable_cross_attention.py:423-436,829-833):
+ *   y[r, :] = x[r, :] @ W^T + shift  for r < min(rows_cap, *rows_dev_or_null);  rows past the count are neither
+ *   read nor written.  W as w_hi / w_lo [Cout][Cin] (the split of sgc_conv3d_cl_bf16x3), Cin % 32 == 0,
+ *   Cout % 4 == 0; same bf16x3 arithmetic.                                                            */
+int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                           float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                           sgc_stream_t stream);
 
 #ifdef __cplusplus
 }

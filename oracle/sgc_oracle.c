@@ -548,9 +548,11 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
 
 /* ---- 5. inter-view aggregation ---------------------------------------------- */
 int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
-                  float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream) {
+                  float *mean, int N, int Nq, int C, const int32_t *n_valid_dev_or_null, int n_valid,
+                  sgc_stream_t stream) {
   (void)stream;
   if (!feat || !slot || !valid_index || !mean) return fail(SGC_EINVAL, "null pointer");
+  if (n_valid_dev_or_null && *n_valid_dev_or_null < n_valid) n_valid = *n_valid_dev_or_null;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n_valid; ++i) {
     const int q = valid_index[i];
@@ -570,10 +572,12 @@ int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_i
 
 int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
                     const int32_t *valid_index, float *ctx,
-                    int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+                    int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                    sgc_stream_t stream) {
   (void)stream;
   if (!q || !kv || !slot || !valid_index || !ctx) return fail(SGC_EINVAL, "null pointer");
   if (C % heads) return fail(SGC_EINVAL, "C % heads != 0");
+  if (n_valid_dev_or_null && *n_valid_dev_or_null < n_valid) n_valid = *n_valid_dev_or_null;
   const int hd = C / heads;
   const float scale = sqrtf(1.0f / (float)hd); /* torch MHA: q * sqrt(1/head_dim) */
 #pragma omp parallel for schedule(static)
@@ -612,9 +616,10 @@ int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
 
 /* ---- 6. volume glue ------------------------------------------------------------ */
 int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
-                     float *vol, int n, int C, sgc_stream_t stream) {
+                     float *vol, const int32_t *n_dev_or_null, int n, int C, sgc_stream_t stream) {
   (void)stream;
   if (!rows || !idx || !vol) return fail(SGC_EINVAL, "null pointer");
+  if (n_dev_or_null && *n_dev_or_null < n) n = *n_dev_or_null;
   for (int i = 0; i < n; ++i) {
     int64_t d = idx[i];
     if (idx2_or_null) d = idx2_or_null[d];
@@ -699,6 +704,18 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                                    transposed, relu, stream);
   free(w);
   return rc;
+}
+
+/* Linear over a row list whose length lives on the "device" (here: host memory): fp32 truth of
+ * sgc_linear_rows_bf16x3; rows past the count are left untouched. */
+int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                           float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                           sgc_stream_t stream) {
+  if (!x || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  int rows = rows_cap;
+  if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
+  if (rows <= 0) return SGC_OK;
+  return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, stream);
 }
 
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */

@@ -24,12 +24,13 @@ SIGNATURES = {
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 8 + [_p],
     "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 11 + [_p],
     "sgc_depth_pairs": [_p, _p] + [_i] * 4 + [_p],
-    "sgc_view_mean": [_p] * 4 + [_i] * 4 + [_p],
-    "sgc_view_attend": [_p] * 5 + [_i] * 5 + [_p],
-    "sgc_scatter_rows": [_p] * 4 + [_i, _i, _p],
+    "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
+    "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
+    "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
     "sgc_upsample2x_occ": [_p] * 5 + [_i] * 4 + [_p],
     "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],
     "sgc_set_tuning": [C.c_char_p, _i],

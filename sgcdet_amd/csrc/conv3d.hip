@@ -48,6 +48,8 @@ struct ConvParams {
   int taps;               // ksize^3
   int splitk;             // number of tap groups (divides taps); >1 -> atomic accumulate, no epilogue
   int M;                  // gx*gy*gz
+  const int32_t *m_dev;   // optional: the live row count lives on the device (sgc_linear_rows_*); rows >= *m_dev
+                          // are neither read nor written and workgroups past it exit at once
 };
 
 constexpr int BM = 128, BK = 32, LDK = BK + 4;
@@ -221,6 +223,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int Mrows = p.m_dev ? min(p.M, *p.m_dev) : p.M;
+  if (m0 >= Mrows) return;
   int zid = blockIdx.z;
   int parity = 0;
   if (p.transposed) { parity = zid % 8; zid /= 8; }
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
     const int m = m0 + r0 + AROWS * i;
-    arow_ok[i] = m < p.M;
+    arow_ok[i] = m < Mrows;
     const int mm = arow_ok[i] ? m : 0;
     az[i] = mm % p.gz;
     ay[i] = (mm / p.gz) % p.gy;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int m = m0 + wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
+        if (m >= Mrows) continue;
         int64_t orow = m;
         if (p.transposed) {
           const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
@@ -422,15 +426,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 // 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64, BN = 128 output channels.
 // LDS: A 2 planes x HROWS x 80 B (<= 104 KB) + B 2 buffers x 2 planes x 128 x 80 B (41 KB).
 // ---------------------------------------------------------------------------------------------
+// z-pitch (in rows) of the halo image in LDS: the smallest pitch >= BZ + 2 for which every 32-row MFMA tile
+// of the brick holds each halo-row residue mod 16 exactly twice (checked offline for the three brick shapes:
+// 18 for BZ = 16, 12 for BZ = 8, 6 for BZ = 4) -- the precondition of the conflict-free lane assignment.
+__host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ + 2; }
+
 template <int BX, int BY, int BZ>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
+  constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int BNV = 128, NT = 512;
   constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
-  constexpr int A_PLANE = HROWS * LDKH, B_PLANE = BNV * LDKH;
+  constexpr int A_PLANE = LROWS * LDKH, B_PLANE = BNV * LDKH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(Bbase + 4 * B_PLANE);   // [8 tiles][32 lanes]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -446,14 +457,35 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   const int c_lo = blockIdx.z * per, c_hi = min(nchunks, c_lo + per);
   if (c_lo >= c_hi) return;
 
-  // per-lane halo base rows of the wave's two 32-row MFMA tiles
+  // Which output voxel of the brick each MFMA row (= lane & 31 of a 32-row tile) works on.  ds_read_b128
+  // serves a wave in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) over 64 banks,
+  // i.e. with the 80-byte row stride a group is conflict-free iff its halo rows are distinct mod 16.  The
+  // natural order (lane = z-run position) is not: a tile spans several z-runs whose halo rows are HZP apart
+  // (measured: 38 % of the LDS cycles of this kernel were bank-conflict cycles).  Every tile holds each
+  // residue exactly twice (halo_pitch guarantees it), so lane l takes the first (l < 16) or second voxel of
+  // the tile whose halo row is == l mod 16 -- any assignment works as long as the epilogue uses the same one.
+  if (tid < 256) {
+    const int t = tid >> 5, l = tid & 31;
+    int seen = 0, pick = t * 32 + l;
+    for (int j = 0; j < 32; ++j) {
+      const int r = t * 32 + j;
+      const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
+      const int hr = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
+      if ((hr & 15) == (l & 15)) {
+        if (seen == (l >> 4)) pick = r;
+        ++seen;
+      }
+    }
+    vox_tab[tid] = (unsigned short)pick;
+  }
+  __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   int arow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = wm * 64 + i * 32 + fr;
+    const int r = vox_tab[(wm * 2 + i) * 32 + fr];
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
-    arow[i] = ((x + 1) * HY + (y + 1)) * HZ + (z + 1);
+    arow[i] = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
   }
   // B staging slot of this thread: row n = tid>>2, 8 bf16 at (tid&3)*8
   const int bn = tid >> 2, bc = tid & 3;
@@ -481,6 +513,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       const int idx = i * NT + tid;
       const int row = idx >> 3, c4 = idx & 7;
       if (row < HROWS) {
+        const int lrow = (row / HZ) * HZP + row % HZ;
         const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
         bf16x4 h, l;
 #pragma unroll
@@ -489,8 +522,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           h[e] = hb;
           l[e] = (__bf16)(v[e] - (float)hb);
         }
-        *reinterpret_cast<bf16x4 *>(A_hi + row * LDKH + c4 * 4) = h;
-        *reinterpret_cast<bf16x4 *>(A_lo + row * LDKH + c4 * 4) = l;
+        *reinterpret_cast<bf16x4 *>(A_hi + lrow * LDKH + c4 * 4) = h;
+        *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
       }
     }
   };
@@ -529,7 +562,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   bf16x8 ah_n[2], al_n[2];
   auto read_A0 = [&](int tap) {
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    const int toff = ((dx - 1) * HY + (dy - 1)) * HZ + (dz - 1);
+    const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int o = (arow[i] + toff) * LDKH + fh * 8;
@@ -545,7 +578,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       if (more) load_B(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
       if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
       const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-      const int toff = ((dx - 1) * HY + (dy - 1)) * HZ + (dz - 1);
+      const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
       const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
       const __bf16 *bl_ = bh_ + B_PLANE;
 #pragma unroll
@@ -595,7 +628,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int r = wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        const int r = vox_tab[(wm * 2 + i) * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)];
         const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
         if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
         const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
@@ -613,10 +646,25 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     }
 }
 
+// Zero-fill of a split-K accumulation target as a KERNEL, not hipMemsetAsync: a memset captured into a large
+// hipGraph (the whole-scene graph) is not ordered with the kernel nodes around it on ROCm 7.2 -- from the second
+// replay on the accumulators started from whatever earlier nodes had left in the recycled pool memory
+// (tools/scene_graph_check2.py); a kernel node is.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float4 *__restrict__ p, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+static int zero_fill(float *y, int64_t n, hipStream_t st) {      // n floats, n % 4 == 0, y 16-byte aligned
+  const int64_t n4 = n / 4;
+  const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(g > 0 ? g : 1), dim3(256), 0, st, reinterpret_cast<float4 *>(y), n4);
+  return check_launch("zero_fill_kernel");
+}
+
 template <int BX, int BY, int BZ>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
-  constexpr int HROWS = (BX + 2) * (BY + 2) * (BZ + 2);
-  const size_t smem = (size_t)(2 * HROWS + 4 * 128) * LDKH * sizeof(uint16_t);
+  constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
+  const size_t smem = (size_t)(2 * LROWS + 4 * 128) * LDKH * sizeof(uint16_t) + 256 * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -629,8 +677,9 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;   // fill >= 3/4 of the CUs
   p.splitk = splitk;
   if (splitk > 1) {
-    hipError_t e = hipMemsetAsync(p.y, 0, OV * p.Cout * sizeof(float), st);
-    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "conv3d halo: memset: %s", hipGetErrorString(e));
+    if (p.Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
+    const int rcz = zero_fill(p.y, OV * p.Cout, st);
+    if (rcz) return rcz;
   }
   hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
@@ -724,8 +773,9 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   p.splitk = pick_splitk(p, mb, nb, 512);   // >= 2 workgroups per CU
   hipStream_t st = (hipStream_t)stream;
   if (p.splitk > 1) {
-    hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
-    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_f32: memset: %s", hipGetErrorString(e));
+    if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
+    const int rcz = zero_fill(y, OV * Cout, st);
+    if (rcz) return rcz;
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (BM + bn) * LDK * sizeof(float);
@@ -771,8 +821,9 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
   p.splitk = pick_splitk(p, mb, nb, 512);
   if (p.splitk > 1) {
-    hipError_t e = hipMemsetAsync(y, 0, OV * Cout * sizeof(float), st);
-    if (e != hipSuccess) return set_error(SGC_ELAUNCH, "sgc_conv3d_cl_bf16x3: memset: %s", hipGetErrorString(e));
+    if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
+    const int rcz = zero_fill(y, OV * Cout, st);
+    if (rcz) return rcz;
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
@@ -792,4 +843,40 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   rc = check_launch("conv3d_igemm_bf16x3_kernel");
   if (rc) return rc;
   return conv_finish(p, OV, st);
+}
+
+// y[rows, Cout] = x[rows, Cin] @ W^T + shift with the row count on the DEVICE: the pair-list stages size their
+// GEMMs by the number of visible (camera, voxel) pairs, which sgc_compact_pairs leaves in totals[] -- reading it
+// back costs a host round trip per level.  The grid covers rows_cap; workgroups past *rows_dev exit at once.
+extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                      float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                                      sgc_stream_t stream) {
+  if (!x || !w_hi || !w_lo || !y) return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: null pointer");
+  if (rows_cap <= 0) return SGC_OK;
+  if (Cin % 32 || Cout % 4) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: needs Cin %% 32 == 0 and Cout %% 4 == 0");
+  ConvParamsB p = {};
+  p.x = x; p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
+  p.y = y; p.shift = shift;
+  p.Cin = Cin; p.Cout = Cout;
+  p.ix = rows_cap; p.iy = 1; p.iz = 1; p.gx = rows_cap; p.gy = 1; p.gz = 1;
+  p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1; p.splitk = 1; p.M = rows_cap; p.m_dev = rows_dev_or_null;
+  const bool narrow = Cout <= 64;
+  const int bn = narrow ? 64 : 128;
+  const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
+  const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
+    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    attr_set = true;
+  }
+  if (narrow)
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
+  else if (g_tune_conv_waves == 8)
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
+  else
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+  return check_launch("conv3d_igemm_bf16x3_kernel (linear rows)");
 }

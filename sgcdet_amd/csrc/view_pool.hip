@@ -12,7 +12,9 @@ namespace sgc {
 __global__ __launch_bounds__(256) void view_mean_kernel(const float *__restrict__ feat,
                                                         const int32_t *__restrict__ slot,
                                                         const int32_t *__restrict__ valid_index,
-                                                        float *__restrict__ mean, int N, int Nq, int C, int n_valid) {
+                                                        float *__restrict__ mean, int N, int Nq, int C, int n_valid,
+                                                        const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);     // row count produced on the device (no host read-back)
   const int C4 = C >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n_valid * C4;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void view_mean_kernel(const float *__restrict_
 
 __global__ void view_mean_scalar_kernel(const float *__restrict__ feat, const int32_t *__restrict__ slot,
                                         const int32_t *__restrict__ valid_index, float *__restrict__ mean,
-                                        int N, int Nq, int C, int n_valid) {
+                                        int N, int Nq, int C, int n_valid, const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n_valid * C;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / C), c = (int)(idx - (int64_t)i * C);
@@ -61,7 +64,10 @@ __global__ __launch_bounds__(256) void view_attend_kernel(const float *__restric
                                                           const int32_t *__restrict__ slot,
                                                           const int32_t *__restrict__ valid_index,
                                                           float *__restrict__ ctx, int N, int Nq, int C,
-                                                          int heads, int n_valid, int G, float scale) {
+                                                          int heads, int n_valid, int G, float scale,
+                                                          const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);
+  if (n_valid <= 0) return;
   const int hd = C / heads;
   const int64_t total = (int64_t)n_valid * heads * G;
   const int64_t span = (((int64_t)total + 63) / 64) * 64;
@@ -114,7 +120,9 @@ __global__ __launch_bounds__(256) void view_attend_kernel(const float *__restric
 }
 
 __global__ void scatter_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ idx,
-                                    const int32_t *__restrict__ idx2, float *__restrict__ vol, int n, int C, int VEC) {
+                                    const int32_t *__restrict__ idx2, float *__restrict__ vol, int n, int C, int VEC,
+                                    const int32_t *__restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);
   const int CV = C / VEC;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)n * CV;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -239,21 +247,25 @@ static int grid_for(int64_t work, int block) {
 }
 
 extern "C" int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
-                             float *mean, int N, int Nq, int C, int n_valid, sgc_stream_t stream) {
+                             float *mean, int N, int Nq, int C, const int32_t *n_valid_dev_or_null, int n_valid,
+                             sgc_stream_t stream) {
+  const int32_t *n_dev = n_valid_dev_or_null;
   if (!feat || !slot || !valid_index || !mean) return set_error(SGC_EINVAL, "sgc_view_mean: null pointer");
   if (n_valid <= 0) return SGC_OK;
   if (C % 4 == 0 && !((uintptr_t)feat & 15) && !((uintptr_t)mean & 15))
     hipLaunchKernelGGL(view_mean_kernel, dim3(grid_for((int64_t)n_valid * (C / 4), 256)), dim3(256), 0,
-                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid);
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid, n_dev);
   else
     hipLaunchKernelGGL(view_mean_scalar_kernel, dim3(grid_for((int64_t)n_valid * C, 256)), dim3(256), 0,
-                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid);
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid, n_dev);
   return check_launch("view_mean_kernel");
 }
 
 extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
                                const int32_t *valid_index, float *ctx,
-                               int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+                               int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                               sgc_stream_t stream) {
+  const int32_t *n_dev = n_valid_dev_or_null;
   if (!q || !kv || !slot || !valid_index || !ctx) return set_error(SGC_EINVAL, "sgc_view_attend: null pointer");
   if (heads <= 0 || C % heads) return set_error(SGC_EINVAL, "sgc_view_attend: C %% heads != 0");
   if (n_valid <= 0) return SGC_OK;
@@ -266,20 +278,20 @@ extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *s
   const int64_t work = (int64_t)n_valid * heads * G;
   if (vec == 4)
     hipLaunchKernelGGL(view_attend_kernel<4>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
-                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale);
+                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale, n_dev);
   else
     hipLaunchKernelGGL(view_attend_kernel<1>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
-                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale);
+                       slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale, n_dev);
   return check_launch("view_attend_kernel");
 }
 
 extern "C" int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
-                                float *vol, int n, int C, sgc_stream_t stream) {
+                                float *vol, const int32_t *n_dev_or_null, int n, int C, sgc_stream_t stream) {
   if (!rows || !idx || !vol) return set_error(SGC_EINVAL, "sgc_scatter_rows: null pointer");
   if (n <= 0) return SGC_OK;
   const int vec = (C % 4 == 0 && !((uintptr_t)rows & 15) && !((uintptr_t)vol & 15)) ? 4 : 1;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((int64_t)n * (C / vec), 256)), dim3(256), 0,
-                     (hipStream_t)stream, rows, idx, idx2_or_null, vol, n, C, vec);
+                     (hipStream_t)stream, rows, idx, idx2_or_null, vol, n, C, vec, n_dev_or_null);
   return check_launch("scatter_rows_kernel");
 }
 

@@ -111,10 +111,15 @@ class LinearSpec:
             self.shift[:cout] = bias.detach().float()
         self.cout, self.cout_p = cout, cout_p
 
-    def __call__(self, x, extra_zero_row=False):
+    def __call__(self, x, extra_zero_row=False, count=None):
         """``extra_zero_row``: the result is a view of an [M+1, out] buffer whose last row is zero (the
-        gather kernel points out-of-image corners at it)."""
+        gather kernel points out-of-image corners at it).  ``count``: int32 device tensor with the number of
+        live rows of ``x`` (its remaining rows are capacity): rows past it are neither read nor written."""
         M = x.shape[0]
+        if count is not None:
+            if CONV_MODE != "bf16x3" or self.cout_p != self.cout:
+                raise NotImplementedError("device-side row counts need the bf16x3 path and out_features % 4 == 0")
+            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count)
         if extra_zero_row and CONV_MODE == "bf16x3" and self.cout_p == self.cout:
             buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
             buf[M].zero_()

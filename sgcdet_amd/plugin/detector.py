@@ -96,8 +96,71 @@ class SGCDet(nn.Module):
         graph.replay()
         return outs
 
+    # ---- whole-scene hipGraph: voxel head + neck + head as ONE replay, no host read-backs ------------------
+    scene_graph = False      # opt-in: outputs live in the graph's static buffers until the next replay on it
+    scene_graph_capacity = 8
+
+    def _scene_graph_key(self, x, img_metas, dpt_dist):
+        from .conv_plan import CONV_MODE, module_fingerprint
+        meta = img_metas[0]
+        n_views = len(meta["lidar2img"]["extrinsic"])
+        return (tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride())) for t in list(x) + [dpt_dist]),
+                tuple(meta["img_shape"][:2]), tuple(meta["ori_shape"][:2]), n_views, CONV_MODE,
+                module_fingerprint(self.voxel_head), module_fingerprint(self.neck_3d), module_fingerprint(self.bbox_head),
+                torch.cuda.current_stream().cuda_stream)
+
+    def _forward_scene_graph(self, x, img_metas, dpt_dist):
+        """The launch sequence of a scene does not depend on its content once the pair / voxel counts stay on the
+        device (``static_counts``): it is captured once per (input buffers, shapes, stream) and replayed -- one
+        host call per scene instead of ~150 launches, three read-backs and their Python orchestration (2.2 ms of
+        host time per scene, more than the kernels need once two scenes overlap).  The graph reads the feature /
+        depth maps IN PLACE (keyed by their addresses: a producer that reuses its output buffers hits the cache,
+        new addresses capture a new graph, oldest evicted at ``scene_graph_capacity``); the only per-scene host
+        work is the 3x4 projection matrices of ``img_meta`` (one pinned 1.9 KB copy)."""
+        from .voxformer import scene_constants_host
+        key = self._scene_graph_key(x, img_metas, dpt_dist)
+        cache = self.__dict__.setdefault("_scene_graph_cache", {})
+        entry = cache.get(key)
+        if entry is None:
+            if len(cache) >= self.scene_graph_capacity:
+                torch.cuda.synchronize()               # never destroy a graph (and free its pool) under a replay
+                cache.pop(next(iter(cache)))
+            const_host = scene_constants_host(img_metas[0]).pin_memory()
+            const_dev = const_host.to(dpt_dist.device, non_blocking=True)
+            meta = dict(img_metas[0])
+            meta["_sgc_scene_const"] = const_dev
+            meta["_sgc_static"] = True
+
+            def body():
+                volume, valid, occ = self.build_volume_from_features(x, [meta], dpt_dist)
+                outs = self._neck_head_eager(volume)
+                return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])
+
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):              # warm-up outside capture (plans, attributes, allocator)
+                body()
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                result = body()
+            entry = cache[key] = dict(graph=graph, const_host=const_host, const_dev=const_dev, result=result,
+                                      copied=torch.cuda.Event())
+            entry["copied"].record()
+        else:
+            entry["copied"].synchronize()              # the previous upload has left the pinned staging buffer
+            entry["const_host"].copy_(scene_constants_host(img_metas[0]))
+        entry["const_dev"].copy_(entry["const_host"], non_blocking=True)
+        entry["copied"].record()
+        entry["graph"].replay()
+        return entry["result"]
+
     def forward_features(self, x, img_metas, dpt_dist):
         """FPN maps + depth distribution -> head tensors (the timed hot path)."""
+        if (self.scene_graph and not self.training and not torch.is_grad_enabled() and dpt_dist.is_cuda
+                and self.voxel_head is not None):
+            return self._forward_scene_graph(x, img_metas, dpt_dist)
         volume, valid, occ = self.build_volume_from_features(x, img_metas, dpt_dist)
         outs = self._neck_head(volume)
         return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])

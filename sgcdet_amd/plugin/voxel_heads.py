@@ -119,8 +119,10 @@ class AdaptiveSparseHead(nn.Module):
         outside the selection), no NCDHW <-> NDHWC copies, no dense zero volumes."""
         ops = ext.ops()
         C = self.embed_dims
+        # "_sgc_static": no host read-backs (device-side counts, worst-case buffers): whole-scene hipGraph capture
+        extra = dict(static_counts=True) if img_meta.get("_sgc_static") else {}
         feat, dpt = self._level_inputs(0, mlvl_feats, img_meta, mlvl_dpt_dists)
-        rows = self.base_heads[0].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt]).contiguous()
+        rows = self.base_heads[0].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt], **extra).contiguous()
         grid = tuple(int(v) for v in self.base_heads[0].n_voxels)
         occ_list, top = [], None
         for i in range(1, len(self.base_heads)):
@@ -132,11 +134,11 @@ class AdaptiveSparseHead(nn.Module):
             if (i - 1) < len(self.topk_list):
                 _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
                 idx = top.squeeze(0).sort().values                          # == nonzero(mask), no host sync
-                seed = self.base_heads[i].seed_rows([feat], img_meta, idx, mlvl_dpt_dists=[dpt])
+                seed = self.base_heads[i].seed_rows([feat], img_meta, idx, mlvl_dpt_dists=[dpt], **extra)
                 ops.scatter_add_rows(seed.contiguous(), idx, up)
             else:
                 top = None
-                up.add_(self.base_heads[i].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt]))
+                up.add_(self.base_heads[i].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt], **extra))
             rows = up
         nx, ny, nz = grid
         volume = rows.view(nx, ny, nz, C).permute(3, 0, 1, 2).unsqueeze(0)

@@ -176,8 +176,11 @@ class DeformCrossAttention_DFA3D(BaseModule):
         xavier_init(self.output_proj, distribution="uniform", bias=0.0)
 
     def _gemm_plan(self):
-        """The three large GEMMs of a level (value_proj over N*S rows, the fused offset/logit projection and
-        the K/V in-projection over the visible pairs) on the MFMA kernel; rebuilt when a parameter changes."""
+        """The Linears of a level on the MFMA kernel (value_proj over N*S rows; the fused offset/logit projection
+        and the K/V in-projection over the visible pairs; output_proj and the q / out projections of the view
+        attention over the visible voxels); rebuilt when a parameter changes.  One kernel for all of them keeps a
+        row's result independent of how many rows the call has, so the host-synchronised path and the
+        device-count path (``static_counts``) are bit-identical."""
         fp = module_fingerprint(self)
         if self.__dict__.get("_gemm_cache") is not None and self._gemm_cache[0] == fp:
             return self._gemm_cache[1]
@@ -188,50 +191,69 @@ class DeformCrossAttention_DFA3D(BaseModule):
                                       da.attention_weights.weight], 0),
                            torch.cat([da.sampling_offsets.bias, da.sampling_offsets_depth.bias,
                                       da.attention_weights.bias], 0)),
-            kv=LinearSpec(mha.in_proj_weight[C:], mha.in_proj_bias[C:]))
+            kv=LinearSpec(mha.in_proj_weight[C:], mha.in_proj_bias[C:]),
+            out=LinearSpec(self.output_proj.weight, self.output_proj.bias),
+            q=LinearSpec(mha.in_proj_weight[:C], mha.in_proj_bias[:C]),
+            o=LinearSpec(mha.out_proj.weight, mha.out_proj.bias))
         self.__dict__["_gemm_cache"] = (fp, plan)
         return plan
 
     # ---- inference: pair-list pipeline --------------------------------------------------
-    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False):
-        """query [1,Nq,C]; feat [N,S,C]; dist [N,S,D]; ref_cam [N,Nq,3]; mask_u8 [N,Nq]."""
+    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False, static_counts=False):
+        """query [1,Nq,C]; feat [N,S,C]; dist [N,S,D]; ref_cam [N,Nq,3]; mask_u8 [N,Nq].
+
+        ``static_counts``: nothing is read back to the host.  The pair / visible-voxel counts stay in the
+        ``totals`` tensor of ``compact_pairs``; buffers are sized for the worst case (N*Nq pairs, Nq voxels), every
+        kernel takes its row count from the device and workgroups past it exit at once.  The launch sequence is
+        then independent of the scene -- the precondition for replaying a whole scene as one hipGraph."""
         ops = _ops()
         C = self.embed_dims
         N, Nq = mask_u8.shape
+        from .conv_plan import CONV_MODE
+        use_mfma = self.deformable_attn and self.inter_view_aggregation == "attn" and C % 32 == 0
         pc = ops.compact_pairs(mask_u8)
-        n_pairs, n_valid, _, _ = pc["totals"].tolist()       # the one host sync of this level
+        if static_counts:
+            if not (use_mfma and CONV_MODE == "bf16x3"):
+                raise NotImplementedError("static_counts needs the bf16x3 GEMM path (attn aggregation, C % 32 == 0)")
+            n_pairs, n_valid = -1, Nq                      # capacities; the live counts stay on the device
+            totals, pairs_cnt, valid_cnt = pc["totals"], pc["totals"][0:1], pc["totals"][1:2]
+        else:
+            n_pairs, n_valid, _, _ = pc["totals"].tolist()       # the one host sync of this level
+            totals = pairs_cnt = valid_cnt = None
         out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
         if n_pairs == 0:
             return out if zero_query else self.dropout(out) + query
         pair_cam, pair_q = pc["pair_cam"], pc["pair_q"]
-        geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W)
+        geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=totals)
+        gemm = self._gemm_plan() if use_mfma else None
         if self.deformable_attn:
             da = self.deformable_attention
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
-            use_mfma = self.inter_view_aggregation == "attn" and C % 32 == 0
-            gemm = self._gemm_plan() if use_mfma else None
-            from .conv_plan import CONV_MODE
             zero_row = use_mfma and CONV_MODE == "bf16x3"
             value = gemm["value"](feat.view(N * H * W, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
-            raw = gemm["raw"](geo) if use_mfma else da.raw_projection(geo)
+            raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
             per_pair = ops.pairs_deform_gather(value.view(N, H * W, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
-                                               da.num_heads, da.num_points, dist_pairs=ops.depth_pairs(dist, H, W),
-                                               zero_row=zero_row)
+                                               da.num_heads, da.num_points, totals=totals,
+                                               dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
         else:
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]
-        mean = ops.view_mean(per_pair, slot, valid_index, n_valid)
-        pooled = self.output_proj(mean)
+        mean = ops.view_mean(per_pair, slot, valid_index, n_valid, count=valid_cnt)
+        pooled = gemm["out"](mean, count=valid_cnt) if use_mfma else self.output_proj(mean)
         if self.inter_view_aggregation == "attn":
             mha = self.attention_pooling
             w, b = mha.in_proj_weight, mha.in_proj_bias
-            q = F.linear(pooled, w[:C], b[:C])
-            kv = self._gemm_plan()["kv"](per_pair) if (self.deformable_attn and C % 32 == 0) else F.linear(per_pair, w[C:], b[C:])
-            ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads)
-            pooled = F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
-        ops.scatter_rows(pooled, valid_index, out.view(Nq, C))
+            if use_mfma:
+                q = gemm["q"](pooled, count=valid_cnt)
+                kv = gemm["kv"](per_pair, count=pairs_cnt)
+            else:
+                q = F.linear(pooled, w[:C], b[:C])
+                kv = F.linear(per_pair, w[C:], b[C:])
+            ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads, count=valid_cnt)
+            pooled = gemm["o"](ctx, count=valid_cnt) if use_mfma else F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
+        ops.scatter_rows(pooled, valid_index, out.view(Nq, C), count=valid_cnt)
         out = self.dropout(out)
         return out if zero_query else out + query
 
@@ -300,7 +322,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
         mask_u8 = bev_mask.reshape(N, Nq)
         mask_u8 = mask_u8 if mask_u8.dtype == torch.uint8 else mask_u8.to(torch.uint8)
         return self._forward_pairs(query, feat.contiguous(), dist.contiguous(), ref_cam.contiguous(),
-                                   mask_u8.contiguous(), hw[0], hw[1], zero_query=bool(kwargs.get("zero_query")))
+                                   mask_u8.contiguous(), hw[0], hw[1], zero_query=bool(kwargs.get("zero_query")),
+                                   static_counts=bool(kwargs.get("static_counts")))
 
 
 # ----------------------------------------------------------------------------------------
@@ -430,6 +453,13 @@ def compute_projection_loop(img_meta, stride=1):
     return torch.stack([intrinsic @ torch.tensor(e)[:3] for e in img_meta["lidar2img"]["extrinsic"]])
 
 
+def scene_constants_host(img_meta):
+    """CPU fp32 [N*12 + 3]: the N projection matrices (3x4, row-major) followed by the scene origin -- everything
+    the path needs from ``img_meta`` on the device (encoder.py:168-177,187,194 of the reference)."""
+    proj = compute_projection(img_meta, stride=1).float()
+    return torch.cat([proj.reshape(-1), torch.as_tensor(img_meta["lidar2img"]["origin"], dtype=torch.float32)])
+
+
 @TRANSFORMER_LAYER_SEQUENCE.register_module()
 class VoxFormerEncoder_DFA3D(TransformerLayerSequence):
     def __init__(self, *args, return_intermediate=False, dbound=None, **kwargs):
@@ -443,14 +473,17 @@ class VoxFormerEncoder_DFA3D(TransformerLayerSequence):
 
     def _scene_constants(self, img_meta, device):
         """(proj [N,3,4], origin [3]) on the device, composed once per scene (img_meta object)."""
+        pre = img_meta.get("_sgc_scene_const")
+        if pre is not None:          # device-resident [N*12 + 3] (see scene_constants_host): the static-graph input
+            n = (pre.numel() - 3) // 12
+            return pre[: n * 12].view(n, 3, 4), pre[n * 12:]
         c = self._scene_cache
         if c is not None and c[0] is img_meta and c[1] == device:
             return c[2], c[3]
         # one staging tensor -> one host->device copy for (proj, origin); (a fresh pinned buffer per scene
         # costs a ~50 ms hipHostMalloc -- measured -- so the small pageable copy is the cheaper choice)
-        proj = compute_projection(img_meta, stride=1).float()
-        n = proj.shape[0]
-        stage = torch.cat([proj.reshape(-1), torch.as_tensor(img_meta["lidar2img"]["origin"], dtype=torch.float32)])
+        stage = scene_constants_host(img_meta)
+        n = (stage.numel() - 3) // 12
         dev = stage.to(device)
         proj, origin = dev[: n * 12].view(n, 3, 4), dev[n * 12:]
         self._scene_cache = (img_meta, device, proj, origin)

@@ -272,22 +272,24 @@ class TensorOps:
         return out
 
     # ---- 5. inter-view aggregation ------------------------------------------
-    def view_mean(self, feat, slot, valid_index, n_valid):
-        self._check(feat=feat, slot=slot, valid_index=valid_index)
+    def view_mean(self, feat, slot, valid_index, n_valid, count=None):
+        """``count``: optional int32 device tensor holding the live row count (an element of compact_pairs'
+        totals); ``n_valid`` is then the capacity -- the result has n_valid rows, the first count of them written."""
+        self._check(feat=feat, slot=slot, valid_index=valid_index, count=count)
         self._f32(feat=feat)
-        self._i32(slot=slot, valid_index=valid_index)
+        self._i32(slot=slot, valid_index=valid_index, count=count)
         N, Nq = slot.shape
         Cc = feat.shape[1]
         mean = torch.empty((n_valid, Cc), dtype=torch.float32, device=feat.device)
         if n_valid == 0:
             return mean
-        self._call("sgc_view_mean", feat, slot, valid_index, mean, N, Nq, Cc, n_valid)
+        self._call("sgc_view_mean", feat, slot, valid_index, mean, N, Nq, Cc, count, n_valid)
         return mean
 
-    def view_attend(self, q, kv, slot, valid_index, heads):
-        self._check(q=q, kv=kv, slot=slot, valid_index=valid_index)
+    def view_attend(self, q, kv, slot, valid_index, heads, count=None):
+        self._check(q=q, kv=kv, slot=slot, valid_index=valid_index, count=count)
         self._f32(q=q, kv=kv)
-        self._i32(slot=slot, valid_index=valid_index)
+        self._i32(slot=slot, valid_index=valid_index, count=count)
         N, Nq = slot.shape
         n_valid, Cc = q.shape
         if kv.shape[1] != 2 * Cc:
@@ -295,20 +297,20 @@ class TensorOps:
         ctx = torch.empty_like(q)
         if n_valid == 0:
             return ctx
-        self._call("sgc_view_attend", q, kv, slot, valid_index, ctx, N, Nq, Cc, heads, n_valid)
+        self._call("sgc_view_attend", q, kv, slot, valid_index, ctx, N, Nq, Cc, heads, count, n_valid)
         return ctx
 
     # ---- 6. volume glue --------------------------------------------------------
-    def scatter_rows(self, rows, idx, vol, idx2=None):
-        self._check(rows=rows, idx=idx, vol=vol, idx2=idx2)
+    def scatter_rows(self, rows, idx, vol, idx2=None, count=None):
+        self._check(rows=rows, idx=idx, vol=vol, idx2=idx2, count=count)
         self._f32(rows=rows, vol=vol)
-        self._i32(idx=idx, idx2=idx2)
+        self._i32(idx=idx, idx2=idx2, count=count)
         n, Cc = rows.shape
         if vol.shape[-1] != Cc:
             raise RuntimeError("scatter_rows: channel mismatch")
         if n == 0:
             return vol
-        self._call("sgc_scatter_rows", rows, idx, idx2, vol, n, Cc)
+        self._call("sgc_scatter_rows", rows, idx, idx2, vol, count, n, Cc)
         return vol
 
     def nchw_to_nhwc_crop(self, src, H, W):
@@ -366,6 +368,27 @@ class TensorOps:
                    stride, 1 if transposed else 0, int(relu),
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
         return y, og
+
+    def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None):
+        """y[r] = x[r] @ W^T + shift for the first ``count`` rows (int32 device tensor; None = all rows) of
+        x [rows_cap, Cin]; W as the bf16 split [1, Cout, Cin] of ``split_bf16``.  Rows past the count are left
+        untouched (uninitialised in a fresh result)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, shift=shift, count=count, out=out)
+        self._f32(x=x, shift=shift, out=out)
+        self._i32(count=count)
+        if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape:
+            raise RuntimeError("linear_rows_bf16x3: w_hi / w_lo must be bfloat16 tensors of one shape")
+        rows, Cin = x.shape
+        Cout = w_hi.shape[-2]
+        if w_hi.shape[-1] != Cin or w_hi.numel() != Cout * Cin:
+            raise RuntimeError("linear_rows_bf16x3: inconsistent shapes")
+        if out is not None and (out.shape != (rows, Cout)):
+            raise RuntimeError("linear_rows_bf16x3: bad `out` tensor")
+        y = out if out is not None else torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
+        if rows:
+            self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout,
+                       _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
+        return y
 
     def conv3d_cl(self, x, wt, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
                   residual=None, relu=False):

@@ -130,3 +130,8 @@ def test_kernels_carry_no_packed_fp32_instructions(tmp_path):
     assert sum(d.count("v_mfma_f32_32x32x16_bf16") for d in dis) > 0      # the disassembly is the real thing
     packed = [ln.strip() for d in dis for ln in d.splitlines() if re.search(r"\bv_pk_\w+_f32\b", ln)]
     assert not packed, f"{len(packed)} packed-FP32 instructions, e.g. {packed[:3]}"
+
+
+def test_oracle_honours_device_side_row_counts(oracle_ops):
+    from count_contract import check_row_counts
+    check_row_counts(oracle_ops, oracle_ops, "cpu")

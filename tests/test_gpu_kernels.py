@@ -244,3 +244,8 @@ def test_upsample_occ_and_scatter_add(C, grid, oracle_ops, gpu_ops):
     oracle_ops.scatter_add_rows(rows, idx, want)
     got = gpu_ops.scatter_add_rows(rows.cuda(), idx.cuda(), up_g.clone())
     close(got, want, tol=1e-6)
+
+
+def test_row_counts_left_on_the_device(oracle_ops, gpu_ops):
+    from count_contract import check_row_counts
+    check_row_counts(gpu_ops, oracle_ops, "cuda")

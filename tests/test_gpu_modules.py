@@ -235,3 +235,41 @@ def test_overlapping_scenes_are_bit_exact_at_full_size(use_graph):
     wrong = [i for i, v, o, m in runs
              if not (torch.equal(v, serial[i % 3][0]) and torch.equal(o, serial[i % 3][1]) and torch.equal(m, serial[i % 3][2]))]
     assert not wrong, f"scene runs {wrong} differ from the serial result"
+
+
+@pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 4), ("cfg2_scannet", 40), ("cfg3_arkit", 6)])
+def test_scene_graph_replay_is_bit_identical_to_eager_launches(name, n_views):
+    """``SGCDet.scene_graph``: the whole scene as one hipGraph replay (pair / voxel counts left on the device,
+    worst-case buffers) == the eager path with its per-level host read-back, bit for bit on the voxel features,
+    masks and occupancy; replaying on new scene content through the same buffers follows the content."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload(name)
+    torch.manual_seed(3)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for _, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.03)
+    det = det.cuda()
+    scenes = [make_scene(n_views, w["embed_dims"], kind=w["kind"], seed=70 + s, device="cuda") for s in range(2)]
+    feats = [f.clone() for f in scenes[0][0]]
+    dpt = scenes[0][1].clone()
+    for s, (f_s, d_s, meta) in enumerate(scenes):
+        for dst, src in zip(feats, f_s):                 # same buffers, new content (and new cameras)
+            dst.copy_(src)
+        dpt.copy_(d_s)
+        with torch.no_grad():
+            det.scene_graph, det.use_graph = False, False
+            r0 = det.forward_features(feats, [meta], dpt)
+            want = {k: r0[k].clone() for k in ("volume", "valid", "occ")}
+            heads = [t.clone() for t in r0["centerness"] + r0["bbox_pred"] + r0["cls_score"]]
+            det.scene_graph = True
+            r1 = det.forward_features(feats, [meta], dpt)
+            torch.cuda.synchronize()
+        assert len(det._scene_graph_cache) == 1          # the second scene replays the graph captured for the first
+        for k in want:
+            assert torch.equal(r1[k], want[k]), (s, k)
+        for a, b in zip(r1["centerness"] + r1["bbox_pred"] + r1["cls_score"], heads):
+            assert max_err(a, b) < 1e-5 * max(1.0, b.abs().max().item()), (max_err(a, b), b.abs().max().item())
