@@ -116,15 +116,15 @@ class LinearSpec:
         gather kernel points out-of-image corners at it).  ``count``: int32 device tensor with the number of
         live rows of ``x`` (its remaining rows are capacity): rows past it are neither read nor written."""
         M = x.shape[0]
+        if CONV_MODE == "bf16x3" and self.cout_p == self.cout:
+            out = None
+            if extra_zero_row:
+                buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
+                buf[M].zero_()
+                out = buf[:M]
+            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count, out=out)
         if count is not None:
-            if CONV_MODE != "bf16x3" or self.cout_p != self.cout:
-                raise NotImplementedError("device-side row counts need the bf16x3 path and out_features % 4 == 0")
-            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count)
-        if extra_zero_row and CONV_MODE == "bf16x3" and self.cout_p == self.cout:
-            buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
-            buf[M].zero_()
-            ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, (M, 1, 1), 1, 1, False, None, self.shift, out=buf[:M])
-            return buf[:M]
+            raise NotImplementedError("device-side row counts need the bf16x3 path and out_features % 4 == 0")
         if CONV_MODE == "bf16x3":
             y, _ = ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, (M, 1, 1), 1, 1, False, None, self.shift)
         else:

@@ -56,16 +56,20 @@ def check_row_counts(ops, oracle_ops, dev):
     ops.scatter_rows(rows[:n_valid].contiguous(), pc["valid_index"][:n_valid].contiguous(), vol_a)
     ops.scatter_rows(rows, pc["valid_index"], vol_b, count=valid_cnt)
     assert torch.equal(vol_a, vol_b) and int((vol_b == sentinel).all(1).sum()) == Nq - n_valid
-    # linear over the pair list
-    wt = (torch.randn(1, 32, C, generator=g) * 0.1).to(dev)
-    shift = torch.randn(32, generator=g).to(dev)
-    w_hi, w_lo = ops.split_bf16(wt)
-    want, _ = ops.conv3d_cl_bf16x3(feat[:n_pairs].contiguous(), w_hi, w_lo, (n_pairs, 1, 1), 1, 1, False, None, shift)
-    out = torch.full((cap, 32), sentinel).to(dev)
-    got = ops.linear_rows_bf16x3(feat, w_hi, w_lo, shift, count=pairs_cnt, out=out)
-    assert torch.equal(got[:n_pairs], want) and bool((got[n_pairs:] == sentinel).all())
-    zero = torch.zeros(1, dtype=torch.int32, device=dev)           # a count of zero: nothing happens
-    out2 = torch.full((cap, 32), sentinel).to(dev)
-    ops.linear_rows_bf16x3(feat, w_hi, w_lo, shift, count=zero, out=out2)
-    ops.view_attend(q, kv, pc["slot"], pc["valid_index"], 8, count=zero)
-    assert bool((out2 == sentinel).all())
+    # linear over the pair list: bit for bit the 1x1x1 convolution entry point on the live rows
+    for cin, cout in ((C, 32), (128, 128), (256, 512), (256, 132)):
+        xin = torch.randn(cap, cin, generator=g).to(dev)
+        wt = (torch.randn(1, cout, cin, generator=g) * 0.1).to(dev)
+        shift = torch.randn(cout, generator=g).to(dev)
+        w_hi, w_lo = ops.split_bf16(wt)
+        want, _ = ops.conv3d_cl_bf16x3(xin[:n_pairs].contiguous(), w_hi, w_lo, (n_pairs, 1, 1), 1, 1, False, None, shift)
+        out = torch.full((cap, cout), sentinel).to(dev)
+        got = ops.linear_rows_bf16x3(xin, w_hi, w_lo, shift, count=pairs_cnt, out=out)
+        assert torch.equal(got[:n_pairs], want) and bool((got[n_pairs:] == sentinel).all()), (cin, cout)
+        full = ops.linear_rows_bf16x3(xin[:n_pairs].contiguous(), w_hi, w_lo, shift)        # host-side count
+        assert torch.equal(full, want), (cin, cout)
+        zero = torch.zeros(1, dtype=torch.int32, device=dev)       # a count of zero: nothing happens
+        out2 = torch.full((cap, cout), sentinel).to(dev)
+        ops.linear_rows_bf16x3(xin, w_hi, w_lo, shift, count=zero, out=out2)
+        assert bool((out2 == sentinel).all())
+    ops.view_attend(q, kv, pc["slot"], pc["valid_index"], 8, count=torch.zeros(1, dtype=torch.int32, device=dev))
