@@ -29,6 +29,9 @@
 #include "common.hpp"
 
 namespace sgc {
+int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
+int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -646,6 +649,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     }
 }
 
+// (A one-wave-per-SIMD form of this kernel -- 4 waves of 64 x 128 outputs, up to 512 registers, the fragments of
+//  the next k-half and of the next tap read ahead of the MFMAs that precede them in program order -- was built,
+//  bit-identical, and measured: 309 us against 251 us on the 256 -> 256 layer at 40x40x16 (427 VGPRs, no spills).
+//  With the compiler's schedule a single wave exposes every s_waitcnt it takes; two waves per SIMD hide more than the
+//  read-ahead buys.  A hand-scheduled loop body is what that design needs; not adopted in this form.)
+
 // Zero-fill of a split-K accumulation target as a KERNEL, not hipMemsetAsync: a memset captured into a large
 // hipGraph (the whole-scene graph) is not ordered with the kernel nodes around it on ROCm 7.2 -- from the second
 // replay on the accumulators started from whatever earlier nodes had left in the recycled pool memory
@@ -708,7 +717,7 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 
 using namespace sgc;
 
-namespace sgc { int g_tune_conv_waves = 8; int g_tune_conv_halo = 1; }
+
 
 static int conv_setup(ConvParams &p, const char *who, const float *x, const void *w1, const void *w2, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride, int transposed, int relu,
