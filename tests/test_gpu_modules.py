@@ -273,3 +273,28 @@ def test_scene_graph_replay_is_bit_identical_to_eager_launches(name, n_views):
             assert torch.equal(r1[k], want[k]), (s, k)
         for a, b in zip(r1["centerness"] + r1["bbox_pred"] + r1["cls_score"], heads):
             assert max_err(a, b) < 1e-5 * max(1.0, b.abs().max().item()), (max_err(a, b), b.abs().max().item())
+
+
+def test_scene_graph_with_fresh_input_buffers_falls_back_to_copies():
+    """A producer that hands over new buffers every scene must not trigger a capture per scene: past
+    ``scene_graph_capacity`` aliased graphs one input-copying graph serves every further address set."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(3)
+    det = build_detector(model_config(w)).eval().cuda()
+    det.scene_graph_capacity = 2
+    for s in range(6):
+        feats, dpt, meta = make_scene(4, w["embed_dims"], kind=w["kind"], seed=90 + s, device="cuda")   # new tensors
+        with torch.no_grad():
+            det.scene_graph, det.use_graph = False, False
+            want = det.forward_features(feats, [meta], dpt)
+            want = {k: want[k].clone() for k in ("volume", "valid", "occ")}
+            det.scene_graph = True
+            got = det.forward_features(feats, [meta], dpt)
+            torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(got[k], want[k]), (s, k)
+    kinds = [e["inputs"] is None for e in det._scene_graph_cache.values()]
+    assert kinds.count(True) == 2 and kinds.count(False) == 1      # 2 aliased graphs + ONE copying graph for the rest
