@@ -305,6 +305,21 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
                            float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
                            sgc_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * 8. Post-processing
+ * ------------------------------------------------------------------------- */
+
+/* Greedy NMS of axis-aligned 3D boxes == mmdet3d `aligned_3d_nms`
+ * (packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:131-178; called by
+ * ScanNetImVoxelHeadV2._nms, mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py:437-443):
+ *   boxes [n,6] (x1,y1,z1,x2,y2,z2) fp32, labels [n] int64, order [n] int64 = argsort(scores) ASCENDING (the
+ *   reference's `torch.argsort(scores)`; the best box is order[n-1]);  a lower-scored box is dropped when, against a
+ *   kept box, NOT (iou * (same class) <= iou_thr) -- exactly the reference's comparison, NaN IoU included.
+ *   keep [n] int64 OUT: indices of the kept boxes in descending score (the reference's return value),
+ *   n_keep [1] int32 OUT (device), workspace >= n * ceil(n/64) uint64.  n <= 4096.                       */
+int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *labels, float iou_thr,
+                      int64_t *keep, int32_t *n_keep, uint64_t *workspace, int n, sgc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

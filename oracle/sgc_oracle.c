@@ -764,3 +764,43 @@ int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int 
     for (int c = 0; c < C; ++c) vol[idx[i] * C + c] += rows[(int64_t)i * C + c];
   return SGC_OK;
 }
+
+
+/* ---- 8. post-processing: mmdet3d aligned_3d_nms (box3d_nms.py:131-178), restated loop for loop -------------- */
+int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *labels, float iou_thr,
+                      int64_t *keep, int32_t *n_keep, uint64_t *workspace, int n, sgc_stream_t stream) {
+  (void)stream; (void)workspace;
+  if (!n_keep) return fail(SGC_EINVAL, "null pointer");
+  *n_keep = 0;
+  if (n <= 0) return SGC_OK;
+  if (!boxes || !order || !labels || !keep) return fail(SGC_EINVAL, "null pointer");
+  int64_t *sorted = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);      /* `score_sorted`, ascending */
+  if (!sorted) return fail(SGC_EINVAL, "out of memory");
+  memcpy(sorted, order, sizeof(int64_t) * (size_t)n);
+  int len = n, cnt = 0;
+  while (len != 0) {
+    const int64_t i = sorted[len - 1];
+    keep[cnt++] = i;                                                     /* pick.append(i) */
+    const float *a = boxes + i * 6;
+    const volatile float area_i = (a[3] - a[0]) * (a[4] - a[1]) * (a[5] - a[2]);
+    int out = 0;
+    for (int t = 0; t < len - 1; ++t) {                                  /* score_sorted[:last - 1] */
+      const int64_t j = sorted[t];
+      const float *b = boxes + j * 6;
+      const volatile float area_j = (b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]);
+      const float xx1 = a[0] > b[0] ? a[0] : b[0], yy1 = a[1] > b[1] ? a[1] : b[1], zz1 = a[2] > b[2] ? a[2] : b[2];
+      const float xx2 = a[3] < b[3] ? a[3] : b[3], yy2 = a[4] < b[4] ? a[4] : b[4], zz2 = a[5] < b[5] ? a[5] : b[5];
+      float il = xx2 - xx1, iw = yy2 - yy1, ih = zz2 - zz1;
+      il = il > 0.f ? il : 0.f; iw = iw > 0.f ? iw : 0.f; ih = ih > 0.f ? ih : 0.f;
+      const volatile float inter = il * iw * ih;
+      const volatile float denom = area_i + area_j - inter;
+      volatile float iou = inter / denom;
+      iou = iou * (labels[i] == labels[j] ? 1.f : 0.f);
+      if (iou <= iou_thr) sorted[out++] = j;                             /* nonzero(iou <= thresh) */
+    }
+    len = out;
+  }
+  free(sorted);
+  *n_keep = cnt;
+  return SGC_OK;
+}

@@ -50,11 +50,11 @@ struct FwdParams {
                             // appended to the map; corners outside the image are pointed at it (no select needed)
   int n_items;              // < 0: read totals[0]
   int TP;                   // items per tile
-#if defined(SGC_DIAG_DESC)
+#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
   float *dbg;               // diagnostic build: [2][items][M*P][12] produced / consumed descriptors
 #endif
 };
-#if defined(SGC_DIAG_DESC)
+#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
 static float *g_dbg = nullptr;
 extern "C" int sgc_debug_buffer(void *ptr) { g_dbg = (float *)ptr; return 0; }
 #endif
@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       if (item >= n_items) item = n_items - 1;
 #if defined(SGC_DIAG_NO_PAIR_LOADS)
       bb[j] = item % 40; x[j] = 0.3f + 1e-6f * item; y[j] = 0.4f; z[j] = 0.5f;
+#elif defined(SGC_DIAG_PAIR_REF)
+      { const float4 pr = reinterpret_cast<const float4 *>(p.dbg)[item];
+        bb[j] = __float_as_int(pr.w); x[j] = pr.x; y[j] = pr.y; z[j] = pr.z; }
 #else
       bb[j] = p.pair_cam[item];
       const int q = p.pair_q[item];
@@ -627,7 +630,7 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
   p.value_bytes = ((int64_t)N * H * W + 1) * M * Cm * 4;
   p.zero_row = value_has_zero_row ? N * H * W : -1;
-#if defined(SGC_DIAG_DESC)
+#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
   p.dbg = g_dbg;
 #endif
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;

@@ -7,13 +7,15 @@ Parameter names (``centerness_conv``, ``reg_conv``, ``cls_conv``, ``scales.i.sca
 the reference's.  Target assignment and losses (:95-235, :361-435, :485-561) are the
 "next" row f-3 of SURVEY.md section 8 and are not part of this path yet.
 
-NMS: the reference calls mmdet3d's ``aligned_3d_nms`` (ScanNet) / ``box3d_multiclass_nms``
-with mmcv's ``nms_rotated`` (ARKit); those are row f-4.  ``_nms`` here returns the
+NMS (row f-4): ScanNet's ``aligned_3d_nms`` (mmdet3d, a Python while-loop in the reference) runs on the GPU
+(``sgc_aligned_nms3d``: one mask kernel + one sweep, same keep/drop arithmetic); ARKit's
+``box3d_multiclass_nms`` + mmcv ``nms_rotated`` is not built: ``SunRgbdImVoxelHeadV2._nms`` returns the
 score-thresholded candidates unless an ``nms_fn`` is injected.
 """
 import torch
 from torch import nn
 
+from .. import ext
 from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
 from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
 
@@ -169,6 +171,10 @@ class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
         bboxes, scores, labels = bboxes[keep], scores[keep], labels[keep]
         if self.nms_fn is not None:
             ids = self.nms_fn(bboxes, scores, labels, self.test_cfg["iou_thr"])
+            bboxes, scores, labels = bboxes[ids], scores[ids], labels[ids]
+        elif bboxes.is_cuda:      # mmdet3d aligned_3d_nms on the GPU (sgc_aligned_nms3d): mask kernel + one sweep
+            ids = ext.ops().aligned_nms3d(bboxes.float().contiguous(), scores.float().contiguous(), labels,
+                                          self.test_cfg["iou_thr"])
             bboxes, scores, labels = bboxes[ids], scores[ids], labels[ids]
         centers = (bboxes[:, :3] + bboxes[:, 3:6]) / 2.0
         bboxes = torch.cat([centers, bboxes[:, 3:6] - bboxes[:, :3]], dim=1)

@@ -390,6 +390,25 @@ class TensorOps:
                        _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
         return y
 
+    # ---- 8. post-processing ----------------------------------------------------------------
+    def aligned_nms3d(self, boxes, scores, labels, iou_thr):
+        """mmdet3d ``aligned_3d_nms(boxes [n,6], scores [n], classes [n], thresh)`` -> kept indices (int64,
+        descending score).  One host read-back (the number of kept boxes) -- this is post-processing."""
+        self._check(boxes=boxes, scores=scores, labels=labels)
+        self._f32(boxes=boxes, scores=scores)
+        n = boxes.shape[0]
+        if boxes.shape != (n, 6) or scores.shape != (n,) or labels.shape != (n,):
+            raise RuntimeError("aligned_nms3d: boxes [n,6], scores [n], labels [n] expected")
+        labels = labels.to(torch.int64)
+        keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
+        n_keep = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+        if n == 0:
+            return keep
+        order = torch.argsort(scores)                              # the reference's call: ascending
+        ws = torch.empty(n * ((n + 63) // 64), dtype=torch.int64, device=boxes.device)
+        self._call("sgc_aligned_nms3d", boxes, order, labels, float(iou_thr), keep, n_keep, ws, n)
+        return keep[: int(n_keep.item())]
+
     def conv3d_cl(self, x, wt, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
                   residual=None, relu=False):
         """x [X*Y*Z, Cin] channels-last; wt [taps, Cout, Cin]; grid = (X, Y, Z) of the input;

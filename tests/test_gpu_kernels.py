@@ -249,3 +249,27 @@ def test_upsample_occ_and_scatter_add(C, grid, oracle_ops, gpu_ops):
 def test_row_counts_left_on_the_device(oracle_ops, gpu_ops):
     from count_contract import check_row_counts
     check_row_counts(gpu_ops, oracle_ops, "cuda")
+
+
+def test_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
+    import numpy as np
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "nms_aligned.npz"))
+    for k in range(int(d["n_cases"])):
+        boxes, scores, labels = (torch.from_numpy(d[f"{n}{k}"]) for n in ("boxes", "scores", "labels"))
+        keep = gpu_ops.aligned_nms3d(boxes.cuda(), scores.cuda(), labels.cuda(), float(d[f"thr{k}"]))
+        assert torch.equal(keep.cpu(), torch.from_numpy(d[f"keep{k}"])), k
+    g = torch.Generator().manual_seed(21)
+    for n in (3000, 4096):                                  # the head's 3 x nms_pre candidates; the size limit
+        c = (torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([6.4, 6.4, 2.5])
+        c = c[torch.randint(0, n // 20, (n,), generator=g)] + torch.randn(n, 3, generator=g) * 0.05
+        s = 0.4 + torch.rand(n, 3, generator=g)
+        boxes = torch.cat([c - s / 2, c + s / 2], 1)
+        scores = torch.rand(n, generator=g)
+        labels = torch.randint(0, 18, (n,), generator=g)
+        want = oracle_ops.aligned_nms3d(boxes, scores, labels, 0.25)
+        got = gpu_ops.aligned_nms3d(boxes.cuda(), scores.cuda(), labels.cuda(), 0.25)
+        assert torch.equal(got.cpu(), want) and 0 < want.numel() < n
+    assert gpu_ops.aligned_nms3d(torch.zeros(0, 6).cuda(), torch.zeros(0).cuda(), torch.zeros(0, dtype=torch.int64).cuda(), 0.25).numel() == 0
+    with pytest.raises(Exception):
+        gpu_ops.aligned_nms3d(torch.zeros(5000, 6).cuda(), torch.zeros(5000).cuda(), torch.zeros(5000, dtype=torch.int64).cuda(), 0.25)

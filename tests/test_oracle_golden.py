@@ -71,3 +71,16 @@ def test_head_restatement_matches_reference(tag, n_cls):
     assert boxes.shape == d["boxes"].shape
     assert max_err(scores, d["scores"]) < 1e-6
     assert max_err(boxes, d["boxes"]) < 1e-4
+
+
+def test_oracle_nms_reproduces_reference_aligned_3d_nms(oracle_ops):
+    """tests/golden/nms_aligned.npz: kept indices of the reference's own aligned_3d_nms (make_golden_nms.py),
+    including zero-volume / inverted boxes (NaN IoU) -- the oracle follows the same loop, bit-exact indices."""
+    import numpy as np
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "nms_aligned.npz"))
+    for k in range(int(d["n_cases"])):
+        boxes, scores, labels = (torch.from_numpy(d[f"{n}{k}"]) for n in ("boxes", "scores", "labels"))
+        keep = oracle_ops.aligned_nms3d(boxes, scores, labels, float(d[f"thr{k}"]))
+        assert torch.equal(keep, torch.from_numpy(d[f"keep{k}"])), k
+    assert oracle_ops.aligned_nms3d(torch.zeros(0, 6), torch.zeros(0), torch.zeros(0, dtype=torch.int64), 0.25).numel() == 0

@@ -48,6 +48,11 @@ print(f"pairs {n_pairs}  algorithmic bytes deform {alg / 1e6:.1f} MB  geom {alg_
 
 
 dp = ops.depth_pairs(dist, H, W) if os.environ.get("SGC_DP", "1") == "1" else None
+if os.environ.get("SGC_PAIR_REF"):      # diagnostic build -DSGC_DIAG_PAIR_REF: per-pair (x, y, z, camera) precomputed
+    pcam, pq = pc["pair_cam"][:n_pairs].long(), pc["pair_q"][:n_pairs].long()
+    pref = torch.cat([ref_cam[pcam, pq], pc["pair_cam"][:n_pairs].view(torch.float32)[:, None]], 1).contiguous()
+    ops.lib._dll.sgc_debug_buffer.argtypes = [ctypes.c_void_p]
+    ops.lib._dll.sgc_debug_buffer(ctypes.c_void_p(pref.data_ptr()))
 
 
 def run(kind):
