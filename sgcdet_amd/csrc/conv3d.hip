@@ -249,6 +249,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     ay[i] = (mm / p.gz) % p.gy;
     ax[i] = mm / (p.gz * p.gy);
   }
+  // (a second register stage -- loads of step s + 2 issued before the MFMAs of step s -- was tried: 156 VGPRs and
+  //  one workgroup per CU, or 128 with spills; 404 -> 507 us on the per-tap 90 GF layer, 143 -> 180-200 us on the
+  //  split-K layers.  Two resident workgroups at 88 VGPRs hide more latency than the deeper prefetch.)
   float4 ra[ACH];
   uint4 rbh[BCH], rbl[BCH];
   auto load_step = [&](int s) {
