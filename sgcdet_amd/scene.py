@@ -43,8 +43,12 @@ def camera_ring(n_views, rng, radius=2.2, height=1.4):
     return ext, np.stack(pos)
 
 
-def make_img_meta(n_views, kind="scannet", seed=0):
+def make_img_meta(n_views, kind="scannet", seed=0, img_hw=None):
+    """``img_hw``: override the resized image size (the unpadded ``img_shape``); BASELINE.json's north star quotes
+    256x320 inputs where the reference's ScanNet config resizes to 239x320 (padded 240x320)."""
     spec = SCANNET if kind == "scannet" else ARKIT
+    if img_hw is not None:
+        spec = dict(spec, img_shape=(int(img_hw[0]), int(img_hw[1]), 3))
     rng = np.random.RandomState(seed)
     ext, pos = camera_ring(n_views, rng)
     K = np.eye(4, dtype=np.float32)
@@ -59,7 +63,7 @@ def make_img_meta(n_views, kind="scannet", seed=0):
 
 
 def make_scene(n_views, channels, kind="scannet", n_depth=12, seed=0, device="cpu", n_levels=3,
-               dtype=torch.float32, pad_shape=None):
+               dtype=torch.float32, pad_shape=None, img_hw=None):
     """Returns (mlvl_feats, dpt_dist, img_meta).
 
     mlvl_feats[l]: [1, N, C, Hp/(4*2^l), Wp/(4*2^l)] standard normal (n_levels + 1 maps like
@@ -67,6 +71,8 @@ def make_scene(n_views, channels, kind="scannet", n_depth=12, seed=0, device="cp
     softmax(2 * randn) over D."""
     spec = SCANNET if kind == "scannet" else ARKIT
     hp, wp = pad_shape or spec["pad_shape"]
+    if img_hw is not None and pad_shape is None:          # pad to the FPN's size divisor like the reference's pipeline
+        hp, wp = (-(-int(img_hw[0]) // 32)) * 32, (-(-int(img_hw[1]) // 32)) * 32
     g = torch.Generator().manual_seed(seed)
     feats = []
     for l in range(n_levels + 1):
@@ -74,7 +80,7 @@ def make_scene(n_views, channels, kind="scannet", n_depth=12, seed=0, device="cp
         h, w = math.ceil(hp / ds), math.ceil(wp / ds)
         feats.append(torch.randn(1, n_views, channels, h, w, generator=g, dtype=torch.float32).to(device=device, dtype=dtype))
     dpt = torch.randn(1, n_views, n_depth, hp // 4, wp // 4, generator=g).mul(2).softmax(2).to(device=device, dtype=dtype)
-    return feats, dpt, make_img_meta(n_views, kind, seed)
+    return feats, dpt, make_img_meta(n_views, kind, seed, img_hw=img_hw)
 
 
 # BASELINE.json configs as concrete hot-path shapes
