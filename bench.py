@@ -254,7 +254,8 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_gather_pmc_v2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_gather_pmc_v5.json" if args.img == "256x320" else
+                                "r01_gather_pmc_v2.json" if args.img == "config" else "none")
         if args.workload == "cfg2_scannet" and args.views in (None, 40) and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
