@@ -200,13 +200,17 @@ def main():
         det.scene_graph = False
         ops.event_log = []
         ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather"}
-        for i in range(max(6, min(args.steps, 20))):
-            step(i)
-        torch.cuda.synchronize()
+        with torch.no_grad():
+            for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
+                feats, dpt, metas = scenes[i % n_scenes]
+                det.forward_features(feats, metas, dpt)
+                torch.cuda.synchronize()
         log, ops.event_log = ops.event_log, None
         det.scene_graph = True
-        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes right after the timed "
-                         "region (the timed region replays one hipGraph per scene)")
+        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
+                         "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
+                         "events; inside it the kernel shares the chip with two other scenes and runs ~3 % longer, see "
+                         "profiles/r01_gather_finest_from_trace_v7.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
     self_check = None
