@@ -58,6 +58,10 @@ def parse():
                          "tail: eager view transform with a host read-back per level + hipGraph replay of neck/head; "
                          "none: everything launched eagerly")
     ap.add_argument("--no-graph", action="store_true", help="same as --graph none")
+    ap.add_argument("--input-layout", default="nchw", choices=["nchw", "nhwc"],
+                    help="memory layout of the FPN / depth maps handed to the path: nchw = the reference's producer "
+                         "(default, what the metric is quoted on); nhwc = channels-last producer contract "
+                         "(SURVEY.md 8 f-1): consumed in place, no transpose pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     return ap.parse_args()
@@ -151,6 +155,9 @@ def main():
     for s in range(n_scenes):
         feats, dpt, meta = make_scene(n_views, w["embed_dims"], kind=w["kind"], seed=1000 * rank + s, device=device,
                                       img_hw=img_hw)
+        if args.input_layout == "nhwc":     # same logical [1,N,C,H,W] tensors, channels-last in memory
+            cl = lambda t: t[0].contiguous(memory_format=torch.channels_last).unsqueeze(0)   # noqa: E731
+            feats, dpt = [cl(f) for f in feats], cl(dpt)
         scenes.append((feats, dpt, [meta]))
 
     ops = ext.ops()
@@ -297,7 +304,7 @@ def main():
                                    f"{'/'.join(f'{f.shape[-2]}x{f.shape[-1]}' for f in scenes[0][0][:3])}, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
-                       "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams,
+                       "input_layout": args.input_layout, "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams,
                        "launch": {"scene": "one hipGraph replay per scene (device-side pair counts, no host read-back)",
                                   "tail": "eager view transform (one host read-back per level) + hipGraph replay of neck/head",
                                   "none": "eager"}[args.graph],

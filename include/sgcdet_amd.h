@@ -185,7 +185,7 @@ int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
 int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
                               const int32_t *pair_cam, const int32_t *pair_q,
                               const int32_t *totals, float *out,
-                              int N, int Nq, int H, int W, int C, int D,
+                              int N, int Nq, int H, int W, int C, int D, int cam_stride_or_0,
                               int n_pairs_or_neg, int cap, sgc_stream_t stream);
 
 /* Context-aware deformable gather == the DFA3D call of MSDeformableAttention3D_DFA3D
@@ -204,11 +204,18 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
                             const float *ref_cam,
                             const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                             const int32_t *totals, float *out,
-                            int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                            int N, int Nq, int H, int W, int M, int Cm, int D, int P, int cam_stride_or_0,
                             int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream);
 
 /* dp [N,H,W+1,D,2]: dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0); dist [N,H*W,D]. */
-int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream);
+int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, int cam_stride_or_0,
+                    sgc_stream_t stream);
+
+/* `cam_stride_or_0` (the three entry points above): number of pixels between consecutive cameras in the
+ * channels-last maps (feat / value / dist); 0 = H*W (compact).  A producer that emits channels-last FPN and depth
+ * maps hands them over without the NCHW -> NHWC pass: the maps keep the rows that
+ * AdaptiveSparseHead.py:53-59 crops away, i.e. cam_stride = Hs*Ws >= H*W with W == Ws, and `value` holds
+ * N*cam_stride (+1 zero) rows.                                                                         */
 
 /* ------------------------------------------------------------------------- *
  * 5. Inter-view aggregation (TU/deformable_cross_attention.py:815-837)

@@ -463,13 +463,14 @@ int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
 int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
                               const int32_t *pair_cam, const int32_t *pair_q,
                               const int32_t *totals, float *out,
-                              int N, int Nq, int H, int W, int C, int D,
+                              int N, int Nq, int H, int W, int C, int D, int cam_stride_or_0,
                               int n_pairs_or_neg, int cap, sgc_stream_t stream) {
   (void)stream; (void)N;
   if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
   int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);
   if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
-  const int64_t S = (int64_t)H * W;
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
+  const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;   /* pixels between cameras */
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < np; ++i) {
     const int n = pair_cam[i], q = pair_q[i];
@@ -488,16 +489,21 @@ int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float 
   return SGC_OK;
 }
 
-int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream) {
+int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, int cam_stride_or_0,
+                    sgc_stream_t stream) {
   (void)stream;
   if (!dist || !dp) return fail(SGC_EINVAL, "null pointer");
-  for (int64_t nh = 0; nh < (int64_t)N * H; ++nh)
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
+  const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;
+  for (int64_t nh = 0; nh < (int64_t)N * H; ++nh) {
+    const float *row = dist + ((nh / H) * S + (nh % H) * W) * D;
     for (int wq = 0; wq <= W; ++wq)
       for (int d = 0; d < D; ++d) {
         float *o = dp + ((nh * (W + 1) + wq) * D + d) * 2;
-        o[0] = wq > 0 ? dist[(nh * W + wq - 1) * D + d] : 0.f;
-        o[1] = wq < W ? dist[(nh * W + wq) * D + d] : 0.f;
+        o[0] = wq > 0 ? row[(wq - 1) * D + d] : 0.f;
+        o[1] = wq < W ? row[wq * D + d] : 0.f;
       }
+  }
   return SGC_OK;
 }
 
@@ -505,14 +511,15 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
                             const float *ref_cam,
                             const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                             const int32_t *totals, float *out,
-                            int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                            int N, int Nq, int H, int W, int M, int Cm, int D, int P, int cam_stride_or_0,
                             int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
   (void)stream; (void)N; (void)dist_pairs_or_null; (void)value_has_zero_row;   /* the oracle always samples the plain map */
   if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out) return fail(SGC_EINVAL, "null pointer");
   if (P > 64) return fail(SGC_EUNSUP, "P > 64");
   int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);
   if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
-  const int64_t S = (int64_t)H * W;
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
+  const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;   /* pixels between cameras */
   const int MC = M * Cm, MP = M * P;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < np; ++i) {

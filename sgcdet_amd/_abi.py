@@ -21,9 +21,9 @@ SIGNATURES = {
     "sgc_dfa3d_backward": [_p] * 11 + [_i] * 9 + [_p],
     "sgc_project_points": [_p] * 5 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
-    "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 8 + [_p],
-    "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 11 + [_p],
-    "sgc_depth_pairs": [_p, _p] + [_i] * 4 + [_p],
+    "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 12 + [_p],
+    "sgc_depth_pairs": [_p, _p] + [_i] * 5 + [_p],
     "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],

@@ -540,12 +540,13 @@ __global__ __launch_bounds__(256) void wms_fwd_kernel(const float *__restrict__ 
 }
 
 // dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0), wq in [0, W]
-__global__ void depth_pairs_kernel(const float *__restrict__ dist, float2 *__restrict__ dp, int64_t total, int H, int W, int D) {
+__global__ void depth_pairs_kernel(const float *__restrict__ dist, float2 *__restrict__ dp, int64_t total, int H, int W, int D,
+                                   int64_t cam_stride) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int d = (int)(i % D);
     const int wq = (int)((i / D) % (W + 1));
     const int64_t nh = i / ((int64_t)D * (W + 1));
-    const float *row = dist + nh * W * D;
+    const float *row = dist + ((nh / H) * cam_stride + (nh % H) * W) * D;
     dp[i] = make_float2(wq > 0 ? row[(wq - 1) * D + d] : 0.f, wq < W ? row[wq * D + d] : 0.f);
   }
 }
@@ -554,13 +555,16 @@ __global__ void depth_pairs_kernel(const float *__restrict__ dist, float2 *__res
 
 using namespace sgc;
 
-extern "C" int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, sgc_stream_t stream) {
+extern "C" int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, int cam_stride_or_0,
+                               sgc_stream_t stream) {
   if (!dist || !dp) return set_error(SGC_EINVAL, "sgc_depth_pairs: null pointer");
+  const int64_t cam_stride = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;
+  if (cam_stride < (int64_t)H * W) return set_error(SGC_EINVAL, "sgc_depth_pairs: cam_stride < H*W");
   const int64_t total = (int64_t)N * H * (W + 1) * D;
   if (total <= 0) return set_error(SGC_EINVAL, "sgc_depth_pairs: bad size");
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(depth_pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dist,
-                     reinterpret_cast<float2 *>(dp), total, H, W, D);
+                     reinterpret_cast<float2 *>(dp), total, H, W, D, cam_stride);
   return check_launch("depth_pairs_kernel");
 }
 
@@ -594,7 +598,7 @@ extern "C" int sgc_dfa3d_forward(const float *value, const float *dist, const in
 extern "C" int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float *ref_cam,
                                          const int32_t *pair_cam, const int32_t *pair_q,
                                          const int32_t *totals, float *out,
-                                         int N, int Nq, int H, int W, int C, int D,
+                                         int N, int Nq, int H, int W, int C, int D, int cam_stride_or_0,
                                          int n_pairs_or_neg, int cap, sgc_stream_t stream) {
   if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !out)
     return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: null pointer");
@@ -604,7 +608,9 @@ extern "C" int sgc_pairs_geometry_sample(const float *feat, const float *dist, c
   FwdParams p = {};
   p.value = feat; p.dist = dist; p.ref_cam = ref_cam; p.pair_cam = pair_cam; p.pair_q = pair_q;
   p.totals = totals; p.out = out;
-  p.S = H * W; p.M = 1; p.Cm = C; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = 1; p.Nq = Nq;
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return set_error(SGC_EINVAL, "sgc_pairs_geometry_sample: cam_stride < H*W");
+  p.S = cam_stride_or_0 > 0 ? cam_stride_or_0 : H * W;       // pixels between consecutive cameras in feat / dist
+  p.M = 1; p.Cm = C; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = 1; p.Nq = Nq;
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
   return launch_fwd<kPairsGeom>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }
@@ -613,7 +619,7 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
                                        const float *ref_cam,
                                        const float *raw, const int32_t *pair_cam, const int32_t *pair_q,
                                        const int32_t *totals, float *out,
-                                       int N, int Nq, int H, int W, int M, int Cm, int D, int P,
+                                       int N, int Nq, int H, int W, int M, int Cm, int D, int P, int cam_stride_or_0,
                                        int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
   if (!value || !dist || !ref_cam || !raw || !pair_cam || !pair_q || !out)
     return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: null pointer");
@@ -627,9 +633,11 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   p.value = value; p.dist = dist; p.dist_pairs = dist_pairs_or_null; p.ref_cam = ref_cam; p.raw = raw;
   p.pair_cam = pair_cam; p.pair_q = pair_q;
   p.totals = totals; p.out = out;
-  p.S = H * W; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
-  p.value_bytes = ((int64_t)N * H * W + 1) * M * Cm * 4;
-  p.zero_row = value_has_zero_row ? N * H * W : -1;
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return set_error(SGC_EINVAL, "sgc_pairs_deform_gather: cam_stride < H*W");
+  p.S = cam_stride_or_0 > 0 ? cam_stride_or_0 : H * W;       // pixels between consecutive cameras in value / dist
+  p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
+  p.value_bytes = ((int64_t)N * p.S + 1) * M * Cm * 4;
+  p.zero_row = value_has_zero_row ? N * p.S : -1;
 #if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
   p.dbg = g_dbg;
 #endif

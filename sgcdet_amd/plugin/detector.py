@@ -39,6 +39,13 @@ class SGCDet(nn.Module):
     @staticmethod
     def depth_pyramid(dpt_dist):
         """nearest x1/2, x1/4 copies of the depth distribution (SGCDet.py:83-85)."""
+        if dpt_dist.dim() == 5 and dpt_dist.shape[0] == 1 and dpt_dist[0].is_contiguous(memory_format=torch.channels_last) \
+                and not dpt_dist[0].is_contiguous():
+            # channels-last producer (SURVEY.md 8 f-1): the 2-D nearest resize picks the same elements and keeps
+            # the memory format, so the coarse levels stay zero-copy for the gathers too
+            return [dpt_dist,
+                    F.interpolate(dpt_dist[0], scale_factor=0.5, mode="nearest").unsqueeze(0),
+                    F.interpolate(dpt_dist[0], scale_factor=0.25, mode="nearest").unsqueeze(0)]
         return [dpt_dist,
                 F.interpolate(dpt_dist, scale_factor=(1, 0.5, 0.5), mode="nearest"),
                 F.interpolate(dpt_dist, scale_factor=(1, 0.25, 0.25), mode="nearest")]

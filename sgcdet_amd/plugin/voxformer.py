@@ -231,9 +231,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
             zero_row = use_mfma and CONV_MODE == "bf16x3"
-            value = gemm["value"](feat.view(N * H * W, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
+            S = feat.shape[1]          # == H*W, or the camera stride of channels-last maps that kept the cropped rows
+            value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
             raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
-            per_pair = ops.pairs_deform_gather(value.view(N, H * W, da.num_heads, C // da.num_heads), dist,
+            per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
                                                da.num_heads, da.num_points, totals=totals,
                                                dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
@@ -524,6 +525,17 @@ class VoxFormerEncoder_DFA3D(TransformerLayerSequence):
         return torch.stack(intermediate) if self.return_intermediate else output
 
 
+def _channels_last_rows(t4, h, w):
+    """[N, C, h, w] top-rows crop of a map stored channels-last ([N, Hs, Ws, C] in memory, Ws == w) -> zero-copy
+    [N, Hs*Ws, C] rows (the kernels take Hs*Ws as the camera stride and never address the cropped rows); None when
+    the memory layout is anything else."""
+    N, C, hh, ww = t4.shape
+    st = t4.stride()
+    if hh != h or ww != w or st[1] != 1 or st[3] != C or st[2] != w * C or st[0] % (w * C) or st[0] < h * w * C:
+        return None
+    return torch.as_strided(t4, (N, st[0] // C, C), (st[0], C, 1))
+
+
 @TRANSFORMER.register_module()
 class PerceptionTransformer_DFA3D(BaseModule):
     def __init__(self, encoder=None, embed_dims=256, **kwargs):
@@ -571,9 +583,14 @@ class PerceptionTransformer_DFA3D(BaseModule):
             if torch.is_grad_enabled() and (feat.requires_grad or dpt.requires_grad):
                 feats.append(feat[0].flatten(2).permute(0, 2, 1))
                 dists.append(dpt[0].flatten(2).permute(0, 2, 1))
-            else:   # one crop+transpose launch each instead of flatten/permute/cat copies
-                feats.append(ops.nchw_to_nhwc_crop(feat[0].float(), h, w))
-                dists.append(ops.nchw_to_nhwc_crop(dpt[0].float(), h, w))
+            else:   # channels-last producers: no copy; otherwise one crop+transpose launch each
+                f_rows = _channels_last_rows(feat[0], h, w) if feat.dtype == torch.float32 else None
+                d_rows = _channels_last_rows(dpt[0], h, w) if dpt.dtype == torch.float32 else None
+                if f_rows is None or d_rows is None or f_rows.shape[1] != d_rows.shape[1]:
+                    f_rows = ops.nchw_to_nhwc_crop(feat[0].float(), h, w)
+                    d_rows = ops.nchw_to_nhwc_crop(dpt[0].float(), h, w)
+                feats.append(f_rows)
+                dists.append(d_rows)
         feat_flatten = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
         dist_flatten = dists[0] if len(dists) == 1 else torch.cat(dists, 1)
         spatial_shapes, level_start_index = self._shape_tensors(tuple(shapes), queries.device)

@@ -219,10 +219,10 @@ class TensorOps:
         self._check(feat=feat, dist=dist, ref_cam=ref_cam, pair_cam=pair_cam, pair_q=pair_q, totals=totals)
         self._f32(feat=feat, dist=dist, ref_cam=ref_cam)
         self._i32(pair_cam=pair_cam, pair_q=pair_q, totals=totals)
-        N, S, Cc = feat.shape
-        D = dist.shape[-1]
+        N, S, Cc = feat.shape          # S >= H*W: pixels between consecutive cameras (channels-last maps that kept
+        D = dist.shape[-1]             # the rows the reference crops away, include/sgcdet_amd.h `cam_stride_or_0`)
         Nq = ref_cam.shape[1]
-        if S != H * W or dist.shape[:2] != (N, S) or ref_cam.shape != (N, Nq, 3):
+        if S < H * W or dist.shape[:2] != (N, S) or ref_cam.shape != (N, Nq, 3):
             raise RuntimeError("pairs_geometry_sample: inconsistent shapes")
         cap = pair_cam.numel()
         rows = n_pairs if n_pairs >= 0 else cap
@@ -230,19 +230,19 @@ class TensorOps:
         if rows == 0:
             return out
         self._call("sgc_pairs_geometry_sample", feat, dist, ref_cam, pair_cam, pair_q, totals, out,
-                   N, Nq, H, W, Cc, D, n_pairs, cap,
+                   N, Nq, H, W, Cc, D, S, n_pairs, cap,
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, n_pairs=rows))
         return out
 
     def depth_pairs(self, dist, H, W):
-        """dist [N, H*W, D] -> pair-interleaved copy [N, H, W+1, D, 2] for ``pairs_deform_gather``."""
+        """dist [N, S >= H*W, D] -> pair-interleaved copy [N, H, W+1, D, 2] for ``pairs_deform_gather``."""
         self._check(dist=dist)
         self._f32(dist=dist)
         N, S, D = dist.shape
-        if S != H * W:
+        if S < H * W:
             raise RuntimeError("depth_pairs: inconsistent shapes")
         dp = torch.empty((N, H, W + 1, D, 2), dtype=torch.float32, device=dist.device)
-        self._call("sgc_depth_pairs", dist, dp, N, H, W, D)
+        self._call("sgc_depth_pairs", dist, dp, N, H, W, D, S)
         return dp
 
     def pairs_deform_gather(self, value, dist, ref_cam, raw, pair_cam, pair_q, n_pairs, H, W, M, P,
@@ -259,7 +259,7 @@ class TensorOps:
         Nq = ref_cam.shape[1]
         cap = pair_cam.numel()
         rows = n_pairs if n_pairs >= 0 else cap
-        if S != H * W or raw.shape[-1] != M * P * 4 or raw.shape[0] < rows:
+        if S < H * W or dist.shape[:2] != (N, S) or raw.shape[-1] != M * P * 4 or raw.shape[0] < rows:
             raise RuntimeError("pairs_deform_gather: inconsistent shapes")
         out = torch.empty((rows, Cc), dtype=torch.float32, device=value.device)
         if rows == 0:
@@ -267,7 +267,7 @@ class TensorOps:
         if dist_pairs is not None and dist_pairs.shape != (N, H, W + 1, D, 2):
             raise RuntimeError("pairs_deform_gather: dist_pairs must be [N, H, W+1, D, 2]")
         self._call("sgc_pairs_deform_gather", value, dist, dist_pairs, ref_cam, raw, pair_cam, pair_q, totals, out,
-                   N, Nq, H, W, M, Cm, D, P, 1 if zero_row else 0, n_pairs, cap,
+                   N, Nq, H, W, M, Cm, D, P, S, 1 if zero_row else 0, n_pairs, cap,
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, M=M, P=P, n_pairs=rows))
         return out
 

@@ -73,3 +73,31 @@ def check_row_counts(ops, oracle_ops, dev):
         ops.linear_rows_bf16x3(xin, w_hi, w_lo, shift, count=zero, out=out2)
         assert bool((out2 == sentinel).all())
     ops.view_attend(q, kv, pc["slot"], pc["valid_index"], 8, count=torch.zeros(1, dtype=torch.int32, device=dev))
+
+
+def check_camera_stride(ops, oracle_ops, dev):
+    """`cam_stride_or_0` of the pair-list gathers and sgc_depth_pairs: maps that keep rows past the H x W crop
+    (channels-last producer contract) give exactly the results of the compact maps."""
+    N, Nq, C, H, W, Hs, D, M, P = 4, 200, 64, 7, 10, 9, 12, 8, 4
+    ref3d, origin, proj = _scene(N, Nq, 13)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = {k: v.to(dev) for k, v in oracle_ops.compact_pairs(mk).items()}
+    rc = rc.to(dev)
+    n_pairs = int(pc["totals"][0])
+    g = torch.Generator().manual_seed(6)
+    feat_full = torch.randn(N, Hs * W, C, generator=g).to(dev)           # Hs rows kept, the crop uses the first H
+    dist_full = torch.randn(N, Hs * W, D, generator=g).mul(2).softmax(-1).contiguous().to(dev)
+    feat, dist = feat_full[:, :H * W].contiguous(), dist_full[:, :H * W].contiguous()
+    raw = (torch.randn(n_pairs, M * P * 4, generator=g) * 2).to(dev)
+    a = ops.pairs_geometry_sample(feat, dist, rc, pc["pair_cam"], pc["pair_q"], n_pairs, H, W)
+    b = ops.pairs_geometry_sample(feat_full, dist_full, rc, pc["pair_cam"], pc["pair_q"], n_pairs, H, W)
+    assert torch.equal(a, b)
+    assert torch.equal(ops.depth_pairs(dist, H, W), ops.depth_pairs(dist_full, H, W))
+    for use_dp in (False, True):
+        dp_c = ops.depth_pairs(dist, H, W) if use_dp else None
+        dp_f = ops.depth_pairs(dist_full, H, W) if use_dp else None
+        a = ops.pairs_deform_gather(feat.view(N, H * W, M, C // M), dist, rc, raw, pc["pair_cam"], pc["pair_q"], n_pairs,
+                                    H, W, M, P, dist_pairs=dp_c)
+        b = ops.pairs_deform_gather(feat_full.view(N, Hs * W, M, C // M), dist_full, rc, raw, pc["pair_cam"], pc["pair_q"],
+                                    n_pairs, H, W, M, P, dist_pairs=dp_f)
+        assert torch.equal(a, b), use_dp

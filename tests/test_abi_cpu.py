@@ -135,3 +135,8 @@ def test_kernels_carry_no_packed_fp32_instructions(tmp_path):
 def test_oracle_honours_device_side_row_counts(oracle_ops):
     from count_contract import check_row_counts
     check_row_counts(oracle_ops, oracle_ops, "cpu")
+
+
+def test_oracle_honours_the_camera_stride(oracle_ops):
+    from count_contract import check_camera_stride
+    check_camera_stride(oracle_ops, oracle_ops, "cpu")

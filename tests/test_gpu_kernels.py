@@ -273,3 +273,8 @@ def test_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
     assert gpu_ops.aligned_nms3d(torch.zeros(0, 6).cuda(), torch.zeros(0).cuda(), torch.zeros(0, dtype=torch.int64).cuda(), 0.25).numel() == 0
     with pytest.raises(Exception):
         gpu_ops.aligned_nms3d(torch.zeros(5000, 6).cuda(), torch.zeros(5000).cuda(), torch.zeros(5000, dtype=torch.int64).cuda(), 0.25)
+
+
+def test_camera_stride_of_channels_last_maps(oracle_ops, gpu_ops):
+    from count_contract import check_camera_stride
+    check_camera_stride(gpu_ops, oracle_ops, "cuda")

@@ -298,3 +298,43 @@ def test_scene_graph_with_fresh_input_buffers_falls_back_to_copies():
             assert torch.equal(got[k], want[k]), (s, k)
     kinds = [e["inputs"] is None for e in det._scene_graph_cache.values()]
     assert kinds.count(True) == 2 and kinds.count(False) == 1      # 2 aliased graphs + ONE copying graph for the rest
+
+
+@pytest.mark.parametrize("scene_graph", [False, True])
+def test_channels_last_inputs_skip_the_transpose_and_change_nothing(scene_graph):
+    """FPN / depth maps handed over channels-last in memory (same logical [1,N,C,H,W] shape) are
+    consumed in place -- no NCHW->NHWC pass, the cropped-away last row stays in the buffers -- with bit-identical
+    results (config-2 shapes at the reference's 239x320, i.e. maps 60x80 cropped to 59x80)."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd import ext
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg2_scannet")
+    torch.manual_seed(5)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for _, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.03)
+    det = det.cuda()
+    feats, dpt, meta = make_scene(8, w["embed_dims"], kind=w["kind"], seed=33, device="cuda")
+    cl = lambda t: t[0].contiguous(memory_format=torch.channels_last).unsqueeze(0)     # [1,N,C,H,W], NHWC memory
+    feats_cl, dpt_cl = [cl(f) for f in feats], cl(dpt)
+    assert feats_cl[0].shape == feats[0].shape and feats_cl[0].stride() != feats[0].stride()
+    det.scene_graph, det.use_graph = scene_graph, scene_graph
+    ops = ext.ops()
+    calls = []
+    orig = ops.nchw_to_nhwc_crop
+    ops.nchw_to_nhwc_crop = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            want = det.forward_features(feats, [meta], dpt)
+            want = {k: want[k].clone() for k in ("volume", "valid", "occ")}
+            n_transposes = len(calls)
+            got = det.forward_features(feats_cl, [meta], dpt_cl)
+            torch.cuda.synchronize()
+    finally:
+        ops.nchw_to_nhwc_crop = orig
+    assert n_transposes > 0 and len(calls) == n_transposes        # the channels-last call launched no transpose
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
