@@ -338,3 +338,39 @@ def test_channels_last_inputs_skip_the_transpose_and_change_nothing(scene_graph)
     assert n_transposes > 0 and len(calls) == n_transposes        # the channels-last call launched no transpose
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_get_bboxes_end_to_end_with_gpu_nms_matches_oracle_decode_and_nms(oracle_ops):
+    """SGCDet.simple_test_from_features (SGCDet.py:119-129): head tensors -> decode -> aligned_3d_nms on the GPU ==
+    the oracle's decode followed by the oracle's NMS, fed the SAME head tensors (boxes 1e-4, kept set identical)."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from oracle.ref_path import RefPath
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(9)
+    cfg = model_config(w)
+    det = build_detector(cfg).eval()
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for _, p in list(det.voxel_head.named_parameters()) + list(det.bbox_head.named_parameters()):
+            p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+    det = det.cuda()
+    det.bbox_head.test_cfg = dict(nms_pre=200, iou_thr=0.25, score_thr=0.05)
+    feats, dpt, meta = make_scene(4, w["embed_dims"], kind=w["kind"], seed=12, device="cuda")
+    with torch.no_grad():
+        r = det.forward_features(feats, [meta], dpt)
+        (boxes, scores, labels), = det.bbox_head.get_bboxes(r["centerness"], r["bbox_pred"], r["cls_score"],
+                                                            r["valid"].float(), [meta])
+    rp = RefPath({}, dict(head="scannet", n_classes=w["n_classes"], nms_pre=200))
+    cpu = lambda ts: [t.cpu() for t in ts]
+    b_c, s_c = rp.decode(cpu(r["centerness"]), cpu(r["bbox_pred"]), cpu(r["cls_score"]), r["valid"].float().cpu(), meta,
+                         det.bbox_head.voxel_size)
+    sc, lb = s_c.max(dim=1)
+    keep = sc > 0.05
+    b_c, sc, lb = b_c[keep], sc[keep], lb[keep]
+    ids = oracle_ops.aligned_nms3d(b_c.contiguous(), sc.contiguous(), lb, 0.25)
+    want = torch.cat([(b_c[ids, :3] + b_c[ids, 3:6]) / 2, b_c[ids, 3:6] - b_c[ids, :3]], 1)
+    assert boxes.shape[0] == want.shape[0] and 0 < want.shape[0] < int(keep.sum())     # NMS removed something
+    assert max_err(boxes, want) < 1e-4 and max_err(scores, sc[ids]) < 1e-5
+    assert torch.equal(labels.cpu(), lb[ids])
