@@ -327,6 +327,21 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
 int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *labels, float iou_thr,
                       int64_t *keep, int32_t *n_keep, uint64_t *workspace, int n, sgc_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * 9. Upstream of the path: plane-sweep matching cost of DepthNet_Fusion
+ * ------------------------------------------------------------------------- */
+
+/* corr[n,d,y,x] = (1/K) sum_k ( sum_c warp_k(feat[nbr[n,k]])[c,d,y,x] * feat[n,(y,x),c] ) / sqrt(C)
+ * == homo_warping + the cost-volume loop of DepthNet_Fusion.forward
+ * (mmdet3d_plugin/models/im2voxel/depth_utils/depth_est_fusion.py:87-126, :233-240) without materialising the
+ * warped features [N,C,D,H,W]:
+ *   feat [N, H*W, C] channels-last matching features (f_mvs), C <= 256;  nbr [N,K] int32 neighbour view ids
+ *   (get_closest_frame_ids, :53-64);  rt [N,K,12]: rows of (nei_proj @ inverse(ref_proj))[:3,:4] (:97-99);
+ *   depth [D] plane depths (D <= 32);  corr [N,D,H,W] fully written.  Sampling = F.grid_sample(bilinear, zeros
+ *   padding, align_corners=False) at the reference's (W-1)/2, (H-1)/2 normalised coordinates.              */
+int sgc_plane_sweep_corr(const float *feat, const int32_t *nbr, const float *rt, const float *depth,
+                         float *corr, int N, int K, int H, int W, int C, int D, sgc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -811,3 +811,48 @@ int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *l
   *n_keep = cnt;
   return SGC_OK;
 }
+
+
+/* ---- 9. plane-sweep matching cost (depth_est_fusion.py:87-126 homo_warping, :233-240 cost volume) ----------- */
+int sgc_plane_sweep_corr(const float *feat, const int32_t *nbr, const float *rt, const float *depth,
+                         float *corr, int N, int K, int H, int W, int C, int D, sgc_stream_t stream) {
+  (void)stream;
+  if (!feat || !nbr || !rt || !depth || !corr) return fail(SGC_EINVAL, "null pointer");
+  const int64_t HW = (int64_t)H * W;
+  const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+  const float half_w = (float)(W - 1) / 2.0f, half_h = (float)(H - 1) / 2.0f;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int64_t pix = 0; pix < HW; ++pix) {
+      const float fx = (float)(pix % W), fy = (float)(pix / W);
+      const float *own = feat + (n * HW + pix) * C;
+      for (int d = 0; d < D; ++d) {
+        float total = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float *m = rt + ((int64_t)n * K + k) * 12;
+          const float rx = m[0] * fx + m[1] * fy + m[2], ry = m[4] * fx + m[5] * fy + m[6], rz = m[8] * fx + m[9] * fy + m[10];
+          const float px = rx * depth[d] + m[3], py = ry * depth[d] + m[7], pz = rz * depth[d] + m[11];
+          const float gx = (px / pz) / half_w - 1.0f, gy = (py / pz) / half_h - 1.0f;
+          const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+          float dot = 0.f;
+          if (ix > -1.0f && iy > -1.0f && ix < (float)W && iy < (float)H) {
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+            const float lx = ix - x0f, ly = iy - y0f, hx = 1.0f - lx, hy = 1.0f - ly;
+            const float *src = feat + (int64_t)nbr[n * K + k] * HW * C;
+            for (int c = 0; c < C; ++c) {
+              float s = 0.f;
+              if (y0 >= 0 && x0 >= 0) s += src[((int64_t)y0 * W + x0) * C + c] * (hx * hy);
+              if (y0 >= 0 && x1 <= W - 1) s += src[((int64_t)y0 * W + x1) * C + c] * (lx * hy);
+              if (y1 <= H - 1 && x0 >= 0) s += src[((int64_t)y1 * W + x0) * C + c] * (hx * ly);
+              if (y1 <= H - 1 && x1 <= W - 1) s += src[((int64_t)y1 * W + x1) * C + c] * (lx * ly);
+              dot += s * own[c];
+            }
+          }
+          total += dot * inv_sqrt_c;
+        }
+        corr[((int64_t)n * D + d) * HW + pix] = total / (float)K;
+      }
+    }
+  return SGC_OK;
+}

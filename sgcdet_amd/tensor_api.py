@@ -409,6 +409,21 @@ class TensorOps:
         self._call("sgc_aligned_nms3d", boxes, order, labels, float(iou_thr), keep, n_keep, ws, n)
         return keep[: int(n_keep.item())]
 
+    # ---- 9. upstream: plane-sweep matching cost ------------------------------------------------
+    def plane_sweep_corr(self, feat, nbr, rt, depth, H, W):
+        """feat [N, H*W, C] channels-last; nbr [N,K] int32; rt [N,K,12]; depth [D] -> corr [N,D,H,W]."""
+        self._check(feat=feat, nbr=nbr, rt=rt, depth=depth)
+        self._f32(feat=feat, rt=rt, depth=depth)
+        self._i32(nbr=nbr)
+        N, S, Cc = feat.shape
+        K = nbr.shape[1]
+        if S != H * W or nbr.shape != (N, K) or rt.shape != (N, K, 12):
+            raise RuntimeError("plane_sweep_corr: inconsistent shapes")
+        D = depth.numel()
+        corr = torch.empty((N, D, H, W), dtype=torch.float32, device=feat.device)
+        self._call("sgc_plane_sweep_corr", feat, nbr, rt, depth, corr, N, K, H, W, Cc, D)
+        return corr
+
     def conv3d_cl(self, x, wt, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
                   residual=None, relu=False):
         """x [X*Y*Z, Cin] channels-last; wt [taps, Cout, Cin]; grid = (X, Y, Z) of the input;

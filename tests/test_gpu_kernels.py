@@ -278,3 +278,33 @@ def test_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
 def test_camera_stride_of_channels_last_maps(oracle_ops, gpu_ops):
     from count_contract import check_camera_stride
     check_camera_stride(gpu_ops, oracle_ops, "cuda")
+
+
+def test_plane_sweep_cost_volume_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
+    import numpy as np
+    import os
+    from test_oracle_golden import _plane_sweep_case
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "plane_sweep.npz"))
+    for k in range(int(d["n_cases"])):
+        f_mvs, rows, nbr, rt, depth, (H, W) = _plane_sweep_case(d, k)
+        corr = gpu_ops.plane_sweep_corr(rows.cuda(), nbr.cuda(), rt.cuda(), depth.cuda(), H, W)
+        want = torch.from_numpy(d[f"corr{k}"])
+        assert float((corr.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), k
+    # DepthNet shapes (128-channel matching features at 1/4 resolution), a few views, against the oracle
+    from sgcdet_amd.scene import make_img_meta
+    from sgcdet_amd.plugin.plane_sweep import plane_sweep_correlation, closest_frame_ids, relative_projections
+    N, C, H, W = 6, 128, 60, 80
+    meta = make_img_meta(N, "scannet", 4)
+    g = torch.Generator().manual_seed(4)
+    f_mvs = torch.randn(N, C, H, W, generator=g)
+    depth = np.arange(0.2, 5.0, 0.4, dtype=np.float32) + 0.2
+    got = plane_sweep_correlation(f_mvs.cuda(), meta, 4, depth, neighbor_img_num=2)
+    w2c = torch.tensor(np.array(meta["lidar2img"]["extrinsic"]))
+    intr = torch.tensor(np.array(meta["lidar2img"]["intrinsic"])).clone()
+    intr[:2] /= meta["ori_shape"][0] / (meta["img_shape"][0] / 4)
+    nbr = closest_frame_ids(N, 2)
+    rt = relative_projections(w2c, intr, nbr).reshape(N, 2, 12).contiguous()
+    want = oracle_ops.plane_sweep_corr(f_mvs.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous(), nbr.to(torch.int32).contiguous(),
+                                       rt, torch.from_numpy(depth), H, W)
+    assert float((got.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((want != 0).float().mean()) > 0.3

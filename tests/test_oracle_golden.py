@@ -84,3 +84,40 @@ def test_oracle_nms_reproduces_reference_aligned_3d_nms(oracle_ops):
         keep = oracle_ops.aligned_nms3d(boxes, scores, labels, float(d[f"thr{k}"]))
         assert torch.equal(keep, torch.from_numpy(d[f"keep{k}"])), k
     assert oracle_ops.aligned_nms3d(torch.zeros(0, 6), torch.zeros(0), torch.zeros(0, dtype=torch.int64), 0.25).numel() == 0
+
+
+def _plane_sweep_case(d, k):
+    f_mvs = torch.from_numpy(d[f"f_mvs{k}"])
+    N, C, H, W = f_mvs.shape
+    rows = f_mvs.permute(0, 2, 3, 1).reshape(N, H * W, C).contiguous()
+    rel = torch.from_numpy(d[f"rel{k}"])
+    nbr = torch.from_numpy(d[f"nbr{k}"]).to(torch.int32).contiguous()
+    return f_mvs, rows, nbr, rel.reshape(N, rel.shape[1], 12).contiguous(), torch.from_numpy(d[f"depth{k}"]), (H, W)
+
+
+def test_oracle_plane_sweep_reproduces_reference_cost_volume(oracle_ops):
+    """tests/golden/plane_sweep.npz: correlation volume of the reference's own homo_warping + cost-volume loop
+    (make_golden_planesweep.py) -- the oracle never builds the warped features and agrees to 1e-5."""
+    import numpy as np
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "plane_sweep.npz"))
+    for k in range(int(d["n_cases"])):
+        f_mvs, rows, nbr, rt, depth, (H, W) = _plane_sweep_case(d, k)
+        corr = oracle_ops.plane_sweep_corr(rows, nbr, rt, depth, H, W)
+        want = torch.from_numpy(d[f"corr{k}"])
+        assert corr.shape == want.shape
+        assert float((corr - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), k
+
+
+def test_plane_sweep_host_glue_matches_reference_neighbours_and_projections():
+    """closest_frame_ids / relative_projections (product host code) == the reference's get_closest_frame_ids /
+    collect_proj + homo_warping's matmul-inverse, from the golden fixture."""
+    import numpy as np
+    import os
+    from sgcdet_amd.plugin.plane_sweep import closest_frame_ids, relative_projections
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "plane_sweep.npz"))
+    for k in range(int(d["n_cases"])):
+        nbr = torch.from_numpy(d[f"nbr{k}"])
+        assert torch.equal(closest_frame_ids(nbr.shape[0], nbr.shape[1]), nbr)
+        rel = relative_projections(torch.from_numpy(d[f"w2c{k}"]), torch.from_numpy(d[f"intr{k}"]), nbr)
+        assert float((rel - torch.from_numpy(d[f"rel{k}"])).abs().max()) < 1e-4
