@@ -151,6 +151,16 @@ def main():
     img_hw = tuple(int(v) for v in args.img.lower().split("x")) if args.img not in (None, "config") else None
     # a few distinct scenes per rank, resident in HBM before the timed region
     n_scenes = 3
+    if args.graph == "scene":
+        # every (scene buffers, stream) pair owns a graph whose pair-list buffers are sized for the worst case
+        # (N * Nq pairs x 3C floats live at once): keep the total under ~1/3 of the 288 GB
+        nq = max(w["topk_list"] + [w["n_voxels_list"][0][0] * w["n_voxels_list"][0][1] * w["n_voxels_list"][0][2]])
+        per_graph = n_views * nq * 3 * w["embed_dims"] * 4 * 1.5
+        while n_scenes * args.streams * per_graph > 96e9 and (n_scenes > 1 or args.streams > 1):
+            if n_scenes > 2 or args.streams == 1:
+                n_scenes -= 1
+            else:
+                args.streams -= 1
     scenes = []
     for s in range(n_scenes):
         feats, dpt, meta = make_scene(n_views, w["embed_dims"], kind=w["kind"], seed=1000 * rank + s, device=device,

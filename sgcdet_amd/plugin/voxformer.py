@@ -234,10 +234,12 @@ class DeformCrossAttention_DFA3D(BaseModule):
             S = feat.shape[1]          # == H*W, or the camera stride of channels-last maps that kept the cropped rows
             value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
             raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
+            del geo                                   # capacity-sized in static mode: let the allocator reuse it
             per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,
                                                ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
                                                da.num_heads, da.num_points, totals=totals,
                                                dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
+            del raw, value
         else:
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]
