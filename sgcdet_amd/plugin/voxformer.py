@@ -193,7 +193,11 @@ class DeformCrossAttention_DFA3D(BaseModule):
                                       da.attention_weights.bias], 0)),
             kv=LinearSpec(mha.in_proj_weight[C:], mha.in_proj_bias[C:]),
             out=LinearSpec(self.output_proj.weight, self.output_proj.bias),
-            q=LinearSpec(mha.in_proj_weight[:C], mha.in_proj_bias[:C]),
+            # the pooled feature only feeds the query projection (:826-833): q = W_q (W_out mean + b_out) + b_q as ONE
+            # Linear with the composed weights (fp32 composition; one GEMM launch less per level)
+            qo=LinearSpec(mha.in_proj_weight[:C].detach().float() @ self.output_proj.weight.detach().float(),
+                          mha.in_proj_weight[:C].detach().float() @ self.output_proj.bias.detach().float()
+                          + mha.in_proj_bias[:C].detach().float()),
             o=LinearSpec(mha.out_proj.weight, mha.out_proj.bias))
         self.__dict__["_gemm_cache"] = (fp, plan)
         return plan
@@ -244,12 +248,13 @@ class DeformCrossAttention_DFA3D(BaseModule):
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]
         mean = ops.view_mean(per_pair, slot, valid_index, n_valid, count=valid_cnt)
-        pooled = gemm["out"](mean, count=valid_cnt) if use_mfma else self.output_proj(mean)
+        if self.inter_view_aggregation != "attn" or not use_mfma:
+            pooled = gemm["out"](mean, count=valid_cnt) if use_mfma else self.output_proj(mean)
         if self.inter_view_aggregation == "attn":
             mha = self.attention_pooling
             w, b = mha.in_proj_weight, mha.in_proj_bias
             if use_mfma:
-                q = gemm["q"](pooled, count=valid_cnt)
+                q = gemm["qo"](mean, count=valid_cnt)
                 kv = gemm["kv"](per_pair, count=pairs_cnt)
             else:
                 q = F.linear(pooled, w[:C], b[:C])
@@ -414,7 +419,7 @@ class VoxFormerLayer(MyCustomBaseTransformerLayer):
                 attn_i += 1
                 identity = query
             elif op == "ffn":
-                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                query = _ffn_forward(self.ffns[ffn_i], query, identity if self.pre_norm else None)
                 ffn_i += 1
             else:
                 raise NotImplementedError(f"{op} is not used by any SGCDet config")
@@ -461,6 +466,33 @@ def scene_constants_host(img_meta):
     the path needs from ``img_meta`` on the device (encoder.py:168-177,187,194 of the reference)."""
     proj = compute_projection(img_meta, stride=1).float()
     return torch.cat([proj.reshape(-1), torch.as_tensor(img_meta["lidar2img"]["origin"], dtype=torch.float32)])
+
+
+def _ffn_forward(ffn, x, identity=None):
+    """mmcv ``FFN`` (Linear - ReLU - Linear + identity) of a transformer layer.  Inference on the GPU in the bf16x3
+    conv mode: two launches of the MFMA kernel with ReLU and the residual add in their epilogues instead of two
+    library GEMMs and two elementwise kernels; anything else goes through the module."""
+    from .conv_plan import CONV_MODE
+    lin1 = ffn.layers[0][0] if len(ffn.layers) == 3 else None
+    fast = (not torch.is_grad_enabled() and x.is_cuda and CONV_MODE == "bf16x3" and ffn.num_fcs == 2 and ffn.add_identity
+            and lin1 is not None and isinstance(ffn.layers[0][1], nn.ReLU) and x.dtype == torch.float32
+            and ffn.embed_dims % 32 == 0 and ffn.feedforward_channels % 32 == 0)
+    if not fast:
+        return ffn(x, identity)
+    fp = module_fingerprint(ffn)
+    plan = ffn.__dict__.get("_sgc_plan")
+    if plan is None or plan[0] != fp:
+        lin2 = ffn.layers[1]
+        plan = (fp, LinearSpec(lin1.weight, lin1.bias), LinearSpec(lin2.weight, lin2.bias))
+        ffn.__dict__["_sgc_plan"] = plan
+    _, s1, s2 = plan
+    ops = _ops()
+    rows = x.reshape(-1, ffn.embed_dims).contiguous()
+    idn = rows if identity is None else identity.reshape(-1, ffn.embed_dims).contiguous()
+    M = rows.shape[0]
+    h, _ = ops.conv3d_cl_bf16x3(rows, s1.w_hi, s1.w_lo, (M, 1, 1), 1, 1, False, None, s1.shift, None, 2)    # relu(t)
+    y, _ = ops.conv3d_cl_bf16x3(h, s2.w_hi, s2.w_lo, (M, 1, 1), 1, 1, False, None, s2.shift, idn, 0)          # t + identity
+    return y.view(x.shape)
 
 
 @TRANSFORMER_LAYER_SEQUENCE.register_module()

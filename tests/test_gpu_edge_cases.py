@@ -85,7 +85,7 @@ def test_no_camera_sees_any_voxel():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     lvl0_t = head.base_heads[0]([feats[2].cuda()[:, :, :, :3, :5]], meta, mlvl_dpt_dists=[dpts[2].cuda()[:, :, :, :3, :5]])
-    assert lvl0_t.requires_grad and (lvl0_t - lvl0).abs().max() < 1e-6
+    assert lvl0_t.requires_grad and (lvl0_t - lvl0).abs().max() < 1e-4     # inference FFN: bf16x3 MFMA (~5e-6), training: torch fp32
 
 
 def test_kernel_level_empty_and_outside(gpu_ops, oracle_ops):
