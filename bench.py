@@ -199,7 +199,7 @@ def main():
     eager_events = not det.scene_graph      # kernels inside a replayed scene graph cannot carry host-side events
     if eager_events:
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather"}
+        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -215,15 +215,16 @@ def main():
         # same scenes, same streams, same kernels launched eagerly right after the timed region: the deformable
         # gather is bracketed by HIP events on its launch stream (its pair count comes back to the host here)
         det.scene_graph = False
+        tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather"}
+        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
         with torch.no_grad():
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
                 det.forward_features(feats, metas, dpt)
                 torch.cuda.synchronize()
         log, ops.event_log = ops.event_log, None
-        det.scene_graph = True
+        det.scene_graph, det.use_graph = True, tail_graph
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with two other scenes and runs ~3 % longer, see "
@@ -290,6 +291,27 @@ def main():
                         kernel="sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8, Cm=32> (finest level)",
                         measured=roofline_pass,
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
+    # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
+    roofline_mfma = None
+    cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode == "bf16x3" else "sgc_conv3d_cl_f32", [])
+    cv = [(t, m) for t, m in cv if m.get("taps") == 27]
+    if cv:
+        flops = lambda m: 2.0 * m["taps"] * m["Cin"] * m["Cout"] * m["OV"]      # noqa: E731
+        top = max(flops(m) for _, m in cv)
+        big_c = [(t, m) for t, m in cv if flops(m) >= 0.99 * top]
+        t_c = sum(t for t, _ in big_c) / len(big_c)
+        bf = args.conv_mode == "bf16x3"
+        peak = 2500.0 if bf else 157.0      # dense bf16 / fp32 MFMA peak (MI355X_MICROARCH.md)
+        issued = top * (3 if bf else 1) / t_c / 1e12
+        m0 = big_c[0][1]
+        roofline_mfma = dict(bound="mfma", achieved=round(issued, 1), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
+                             kernel=("sgc::conv3d_halo_bf16x3_kernel" if bf else "sgc::conv3d_igemm_f32_kernel") +
+                                    f" ({m0['Cin']}->{m0['Cout']} ch, 3x3x3, {m0['OV']} voxels)",
+                             algorithmic_gflop=round(top / 1e9, 1), fp32_equivalent_tflops=round(top / t_c / 1e12, 1),
+                             avg_launch_us=round(t_c * 1e6, 1), launches=len(big_c),
+                             note=("achieved = MFMA work actually issued (three bf16 products per fp32 multiply-add: lo*hi + "
+                                   "hi*lo + hi*hi); fp32_equivalent_tflops = algorithmic FLOPs of the fp32 convolution / time")
+                             if bf else "exact fp32 products on v_mfma_f32_32x32x2_f32")
     if args.breakdown and rank == 0:
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
             tot = sum(t for t, _ in items)
@@ -320,6 +342,7 @@ def main():
                                   "none": "eager"}[args.graph],
                        "sharding": "scenes across ranks, no collective"},
             "roofline": roofline,
+            "roofline_mfma": roofline_mfma,
             "self_check": self_check,
         }
         if not args.no_cpu_baseline and world == 1:
