@@ -439,6 +439,8 @@ static int launch_fwd(FwdParams p, int grid_items, hipStream_t stream) {
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32, 1, true>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 32)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 32>), dim3(grid), dim3(256), 0, stream, p);
+    else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 16 && p.zero_row >= 0)
+      hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 16, 1, true>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4 && p.M == 8 && p.Cm == 16)
       hipLaunchKernelGGL((dfa3d_fwd_wave_kernel<kPairsDeform, 4, 8, 16>), dim3(grid), dim3(256), 0, stream, p);
     else if (MODE == kPairsDeform && p.P == 4)
