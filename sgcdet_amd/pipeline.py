@@ -5,8 +5,10 @@ with three host round trips (one per level, to size the pair list), and the big 
 neck cannot start before it ends.  Scenes are independent (the reference processes one scene per GPU per
 step, mmdet3d_plugin/models/im2voxel/AdaptiveSparseHead.py:45), so consecutive scenes are issued on
 alternating streams: while the host waits for scene A's pair count, scene B's kernels keep the CUs busy,
-and A's small kernels run beside B's convolutions.  Measured on config 2: 219 -> 326 scenes/s with two
-streams (three are slower: the scenes start to fight for L2 and LDS).
+and A's small kernels run beside B's convolutions.  Measured on config 2 (eager launches): 219 -> 326 scenes/s
+with two streams; with ``detector.scene_graph = True`` (one hipGraph replay per scene) 272 -> 350-365 with two and
+373-382 with three streams -- the third only pays once the streams stop sharing hardware queues: set
+``GPU_MAX_HW_QUEUES=8`` in the environment before the HIP runtime initialises (bench.py does).
 """
 import torch
 
