@@ -289,7 +289,8 @@ int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int 
 int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
                       const float *residual_or_null, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                      int transposed, int relu, sgc_stream_t stream);
+                      int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                      sgc_stream_t stream);
 
 /* Same contract on the bf16 matrix cores with fp32-faithful results: every fp32 operand is split
  * as v = hi + lo (two bf16); the products hi*hi + hi*lo + lo*hi run on v_mfma_f32_32x32x16_bf16 with
@@ -300,7 +301,16 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
 int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                         int transposed, int relu, sgc_stream_t stream);
+                         int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                         sgc_stream_t stream);
+
+/* Layers with few output voxels split their reduction over several workgroups (split-K).  With a workspace of
+ * sgc_conv3d_workspace_floats(...) floats every split stores its partial tile and a second kernel adds them in a
+ * fixed order: results are bit-identical from run to run (and to any other launch order).  Without it
+ * (workspace_or_null = NULL or too small) the partial tiles meet in `y` through float atomics -- same values up to
+ * the rounding of a different summation order.  The query returns 0 for layers that are not split.            */
+int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                    int transposed, int bf16x3);
 
 /* nn.Linear over a row list whose length lives on the device (the Linears of
  * MSDeformableAttention3D_DFA3D / nn.MultiheadAttention applied to the visible pairs,

@@ -653,7 +653,9 @@ int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, in
 int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
                       const float *residual_or_null, float *y,
                       int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                      int transposed, int relu, sgc_stream_t stream) {
+                      int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                      sgc_stream_t stream) {
+  (void)workspace_or_null; (void)workspace_floats;      /* the oracle never splits a reduction */
   (void)stream;
   if (!x || !wt || !y) return fail(SGC_EINVAL, "null pointer");
   const int pad = ksize / 2;
@@ -697,10 +699,18 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
  * the naive fp32 convolution above. */
 #include <stdlib.h>
 static float bf16_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
+int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                    int transposed, int bf16x3) {
+  (void)ix; (void)iy; (void)iz; (void)Cin; (void)Cout; (void)ksize; (void)stride; (void)transposed; (void)bf16x3;
+  return 0;
+}
+
 int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                         int transposed, int relu, sgc_stream_t stream) {
+                         int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                         sgc_stream_t stream) {
+  (void)workspace_or_null; (void)workspace_floats;
   if (!w_hi || !w_lo) return fail(SGC_EINVAL, "null pointer");
   const int taps = transposed ? 8 : ksize * ksize * ksize;
   const size_t n = (size_t)taps * Cout * Cin;
@@ -708,7 +718,7 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   if (!w) return fail(SGC_EINVAL, "out of memory");
   for (size_t i = 0; i < n; ++i) w[i] = bf16_to_f32(w_hi[i]) + bf16_to_f32(w_lo[i]);
   const int rc = sgc_conv3d_cl_f32(x, w, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride,
-                                   transposed, relu, stream);
+                                   transposed, relu, NULL, 0, stream);
   free(w);
   return rc;
 }
@@ -722,7 +732,7 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
   int rows = rows_cap;
   if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
   if (rows <= 0) return SGC_OK;
-  return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, stream);
+  return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, NULL, 0, stream);
 }
 
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */

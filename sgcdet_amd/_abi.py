@@ -11,7 +11,7 @@ _p = C.c_void_p
 _i = C.c_int
 _f = C.c_float
 
-# name -> argtypes (restype is int for all but the three introspection calls)
+# name -> argtypes (restype is int for all but the introspection / query calls)
 SIGNATURES = {
     "sgc_depth_score_forward": [_p, _p, _p, _p, _p] + [_i] * 7 + [_p],
     "sgc_wms_forward": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p],
@@ -28,8 +28,8 @@ SIGNATURES = {
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
-    "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p],
-    "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
+    "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
     "sgc_aligned_nms3d": [_p] * 3 + [_f] + [_p] * 3 + [_i] + [_p],
     "sgc_plane_sweep_corr": [_p] * 5 + [_i] * 6 + [_p],
@@ -42,6 +42,7 @@ INTROSPECTION = {
     "sgc_abi_version": (C.c_int, []),
     "sgc_last_error": (C.c_char_p, []),
     "sgc_backend": (C.c_char_p, []),
+    "sgc_conv3d_workspace_floats": (C.c_int64, [_i] * 9),
 }
 
 ABI_VERSION = 1

@@ -51,6 +51,9 @@ struct ConvParams {
   int taps;               // ksize^3
   int splitk;             // number of tap groups (divides taps); >1 -> atomic accumulate, no epilogue
   int M;                  // gx*gy*gz
+  float *ws;              // optional split-K workspace [splitk][OV][Cout]: every split stores its partial tile there and
+  int64_t ws_stride;      // the epilogue kernel sums them in split order (deterministic); null: float atomics into y
+  int64_t ws_floats;      // capacity of ws
   const int32_t *m_dev;   // optional: the live row count lives on the device (sgc_linear_rows_*); rows >= *m_dev
                           // are neither read nor written and workgroups past it exit at once
 };
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
         }
         float *dst = p.y + orow * p.Cout + col;
         if (p.splitk > 1) {
-          atomicAdd(dst, acc[i][j][k]);
+          if (p.ws) p.ws[(int64_t)zid * p.ws_stride + orow * p.Cout + col] = acc[i][j][k];
+          else atomicAdd(dst, acc[i][j][k]);
         } else {
           float v = acc[i][j][k] * sc + sh;
           if (p.relu == 2) v = fmaxf(v, 0.f);
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
         }
         float *dst = p.y + orow * p.Cout + col;
         if (p.splitk > 1) {
-          atomicAdd(dst, acc[i][j][k]);
+          if (p.ws) p.ws[(int64_t)zid * p.ws_stride + orow * p.Cout + col] = acc[i][j][k];
+          else atomicAdd(dst, acc[i][j][k]);
         } else {
           float v = acc[i][j][k] * sc + sh;
           if (p.relu == 2) v = fmaxf(v, 0.f);
@@ -640,7 +645,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
         float *dst = p.y + orow * p.Cout + col;
         if (p.splitk > 1) {
-          atomicAdd(dst, acc[i][j][k]);
+          if (p.ws) p.ws[(int64_t)blockIdx.z * p.ws_stride + orow * p.Cout + col] = acc[i][j][k];
+          else atomicAdd(dst, acc[i][j][k]);
         } else {
           float v = acc[i][j][k] * sc + sh;
           if (p.relu == 2) v = fmaxf(v, 0.f);
@@ -673,6 +679,14 @@ static int zero_fill(float *y, int64_t n, hipStream_t st) {      // n floats, n 
   return check_launch("zero_fill_kernel");
 }
 
+// channel-chunk splits of the halo kernel: enough workgroups for 3/4 of the CUs, and no empty split
+static int halo_splitk(int bricks, int nb, int nchunks) {
+  int splitk = 1;
+  while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;
+  const int per = (nchunks + splitk - 1) / splitk;
+  return (nchunks + per - 1) / per;
+}
+
 template <int BX, int BY, int BZ>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
@@ -685,13 +699,17 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, 128);
   const int nchunks = p.Cin / BK;
-  int splitk = 1;
-  while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;   // fill >= 3/4 of the CUs
+  const int splitk = halo_splitk(bricks, nb, nchunks);
   p.splitk = splitk;
   if (splitk > 1) {
     if (p.Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
-    const int rcz = zero_fill(p.y, OV * p.Cout, st);
-    if (rcz) return rcz;
+    if (p.ws && p.ws_floats >= (int64_t)splitk * OV * p.Cout) {
+      p.ws_stride = OV * p.Cout;
+    } else {
+      p.ws = nullptr;
+      const int rcz = zero_fill(p.y, OV * p.Cout, st);
+      if (rcz) return rcz;
+    }
   }
   hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
@@ -699,10 +717,19 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
 
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
                                      const float *__restrict__ shift, const float *__restrict__ residual,
-                                     int64_t total4, int C4, int relu) {
+                                     int64_t total4, int C4, int relu, const float *__restrict__ ws, int splits) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
-    float4 v = reinterpret_cast<float4 *>(y)[i];
+    float4 v;
+    if (ws) {                      // partial tiles of the splits, summed in split order: same bits every run
+      v = reinterpret_cast<const float4 *>(ws)[i];
+      for (int sidx = 1; sidx < splits; ++sidx) {
+        const float4 t = reinterpret_cast<const float4 *>(ws)[(int64_t)sidx * total4 + i];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    } else {
+      v = reinterpret_cast<float4 *>(y)[i];
+    }
     const float4 sc = scale ? reinterpret_cast<const float4 *>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 sh = shift ? reinterpret_cast<const float4 *>(shift)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -762,7 +789,7 @@ static int conv_finish(const ConvParams &p, int64_t OV, hipStream_t st) {
   const int64_t total4 = OV * p.Cout / 4;
   const int g = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(conv_epilogue_kernel, dim3(g), dim3(256), 0, st, p.y, p.scale, p.shift, p.residual, total4,
-                     p.Cout / 4, p.relu);
+                     p.Cout / 4, p.relu, (const float *)p.ws, p.splitk);
   return check_launch("conv_epilogue_kernel");
 }
 
@@ -772,12 +799,14 @@ static int conv_finish(const ConvParams &p, int64_t OV, hipStream_t st) {
 extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
                                  const float *residual_or_null, float *y,
                                  int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                                 int transposed, int relu, sgc_stream_t stream) {
+                                 int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                                 sgc_stream_t stream) {
   ConvParams p = {};
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_f32", x, wt, wt, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
   if (rc) return rc;
   p.w = wt; p.scale = scale; p.shift = shift; p.residual = residual_or_null;
+  p.ws = workspace_or_null; p.ws_floats = workspace_or_null ? workspace_floats : 0;
   const int64_t OV = (int64_t)ox * oy * oz;
   const bool narrow = Cout <= 32;
   const int bn = narrow ? 32 : 128;
@@ -786,8 +815,13 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   hipStream_t st = (hipStream_t)stream;
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
-    const int rcz = zero_fill(y, OV * Cout, st);
-    if (rcz) return rcz;
+    if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
+      p.ws_stride = OV * Cout;                 // partial tiles -> workspace, summed in order by the epilogue kernel
+    } else {
+      p.ws = nullptr;                          // no (or too small a) workspace: float atomics into a zeroed y
+      const int rcz = zero_fill(y, OV * Cout, st);
+      if (rcz) return rcz;
+    }
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (BM + bn) * LDK * sizeof(float);
@@ -811,13 +845,15 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
 extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                                     const float *shift, const float *residual_or_null, float *y,
                                     int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                                    int transposed, int relu, sgc_stream_t stream) {
+                                    int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                                    sgc_stream_t stream) {
   ConvParamsB p = {};
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
   if (rc) return rc;
   p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.scale = scale; p.shift = shift; p.residual = residual_or_null;
+  p.ws = workspace_or_null; p.ws_floats = workspace_or_null ? workspace_floats : 0;
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
@@ -834,8 +870,13 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   p.splitk = pick_splitk(p, mb, nb, 512);
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
-    const int rcz = zero_fill(y, OV * Cout, st);
-    if (rcz) return rcz;
+    if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
+      p.ws_stride = OV * Cout;                 // partial tiles -> workspace, summed in order by the epilogue kernel
+    } else {
+      p.ws = nullptr;                          // no (or too small a) workspace: float atomics into a zeroed y
+      const int rcz = zero_fill(y, OV * Cout, st);
+      if (rcz) return rcz;
+    }
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
@@ -857,6 +898,32 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   return conv_finish(p, OV, st);
 }
 
+
+// Split-K workspace (floats) the convolution above would use for a deterministic reduction; 0 = the layer is not
+// split.  Mirrors the dispatch of sgc_conv3d_cl_f32 (bf16x3 = 0) / sgc_conv3d_cl_bf16x3 (bf16x3 = 1).
+extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                               int transposed, int bf16x3) {
+  if (ix <= 0 || iy <= 0 || iz <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  int ox, oy, oz, gx, gy, gz;
+  if (transposed) { ox = 2 * ix; oy = 2 * iy; oz = 2 * iz; gx = ix; gy = iy; gz = iz; }
+  else {
+    const int pad = ksize / 2;
+    ox = (ix + 2 * pad - ksize) / stride + 1; oy = (iy + 2 * pad - ksize) / stride + 1; oz = (iz + 2 * pad - ksize) / stride + 1;
+    gx = ox; gy = oy; gz = oz;
+  }
+  const int64_t OV = (int64_t)ox * oy * oz, M = (int64_t)gx * gy * gz;
+  int splitk = 1;
+  if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= 64 && M >= 2048) {
+    const int bx = gz >= 16 ? 4 : (gz >= 8 ? 4 : 8), by = gz >= 16 ? 4 : 8, bz = gz >= 16 ? 16 : (gz >= 8 ? 8 : 4);
+    splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, 128), Cin / BK);
+  } else {
+    ConvParams p = {};
+    p.transposed = transposed; p.taps = transposed ? 8 : ksize * ksize * ksize;
+    const int bn = bf16x3 ? (Cout <= 64 ? 64 : 128) : (Cout <= 32 ? 32 : 128);
+    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), 512);
+  }
+  return splitk > 1 ? (int64_t)splitk * OV * Cout : 0;
+}
 
 // y[rows, Cout] = x[rows, Cin] @ W^T + shift with the row count on the DEVICE: the pair-list stages size their
 // GEMMs by the number of visible (camera, voxel) pairs, which sgc_compact_pairs leaves in totals[] -- reading it

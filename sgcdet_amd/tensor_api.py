@@ -364,8 +364,9 @@ class TensorOps:
         y = out if out is not None else torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError("conv3d_cl_bf16x3: residual shape mismatch")
+        ws, ws_n = self._conv_workspace(x.device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, 1)
         self._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize,
-                   stride, 1 if transposed else 0, int(relu),
+                   stride, 1 if transposed else 0, int(relu), ws, ws_n,
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
         return y, og
 
@@ -389,6 +390,14 @@ class TensorOps:
             self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout,
                        _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
         return y
+
+    def _conv_workspace(self, device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, bf16x3):
+        """Split-K layers get a workspace so that their partial sums are added in a fixed order (bit-identical
+        results from run to run); (None, 0) for layers that are not split."""
+        n = int(self.lib._dll.sgc_conv3d_workspace_floats(ix, iy, iz, Cin, Cout, ksize, stride, 1 if transposed else 0, bf16x3))
+        if n <= 0:
+            return None, 0
+        return torch.empty(n, dtype=torch.float32, device=device), n
 
     # ---- 8. post-processing ----------------------------------------------------------------
     def aligned_nms3d(self, boxes, scores, labels, iou_thr):
@@ -444,8 +453,9 @@ class TensorOps:
         y = torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError("conv3d_cl: residual shape mismatch")
+        ws, ws_n = self._conv_workspace(x.device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, 0)
         self._call("sgc_conv3d_cl_f32", x, wt, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize, stride,
-                   1 if transposed else 0, int(relu),
+                   1 if transposed else 0, int(relu), ws, ws_n,
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
         return y, og
 

@@ -69,3 +69,34 @@ def test_conv3d_bf16x3_is_fp32_faithful(case, oracle_ops, gpu_ops):
     # and the oracle's own bf16x3 entry point (hi + lo recombined) agrees with its fp32 one
     y_c2, _ = oracle_ops.conv3d_cl_bf16x3(x, w_hi.cpu(), w_lo.cpu(), grid, k, s, tr, sc, sh, res, relu)
     assert (y_c2 - y_c).abs().max().item() < 1e-4 * max(1.0, y_c.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,grid,stride", [(1024, 1024, (10, 10, 4), 1), (256, 512, (40, 40, 16), 2),
+                                                    (512, 128, (20, 20, 8), 1)])
+def test_split_k_layers_are_bitwise_reproducible(cin, cout, grid, stride, gpu_ops):
+    """Layers with few output voxels split their reduction over workgroups; with the workspace TensorOps hands
+    over, the partial tiles are summed in a fixed order: identical bits on every launch, also while another
+    stream keeps the chip busy.  (Without a workspace the library falls back to float atomics: same values to
+    rounding.)"""
+    g = torch.Generator().manual_seed(17)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g).cuda()
+    wt = (torch.randn(27, cout, cin, generator=g) * 0.02).cuda()
+    w_hi, w_lo = gpu_ops.split_bf16(wt)
+    n_ws = int(gpu_ops.lib._dll.sgc_conv3d_workspace_floats(*grid, cin, cout, 3, stride, 0, 1))
+    assert n_ws > 0                                   # the layer IS split
+    ref, og = gpu_ops.conv3d_cl_bf16x3(x, w_hi, w_lo, grid, 3, stride, False)
+    ref = ref.clone()
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(5):
+        with torch.cuda.stream(side):
+            busy @ busy
+        y, _ = gpu_ops.conv3d_cl_bf16x3(x, w_hi, w_lo, grid, 3, stride, False)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    # the atomics fallback (no workspace) agrees to rounding
+    y2 = torch.empty_like(ref)
+    gpu_ops._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, None, None, None, y2, *grid, cin, cout, 3, stride, 0, 0, None, 0)
+    torch.cuda.synchronize()
+    assert float((y2 - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))

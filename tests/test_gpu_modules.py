@@ -190,7 +190,7 @@ def test_two_scenes_in_flight_give_the_same_results():
             assert torch.equal(a["volume"], b["volume"])
             for k in ("centerness", "bbox_pred", "cls_score"):
                 for x, y in zip(a[k], b[k]):
-                    assert max_err(x, y) < 1e-5 * max(1.0, x.abs().max().item())   # split-K atomics reorder sums
+                    assert torch.equal(x, y)            # split-K layers reduce in a fixed order (workspace)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
@@ -272,7 +272,7 @@ def test_scene_graph_replay_is_bit_identical_to_eager_launches(name, n_views):
         for k in want:
             assert torch.equal(r1[k], want[k]), (s, k)
         for a, b in zip(r1["centerness"] + r1["bbox_pred"] + r1["cls_score"], heads):
-            assert max_err(a, b) < 1e-5 * max(1.0, b.abs().max().item()), (max_err(a, b), b.abs().max().item())
+            assert torch.equal(a, b)                    # split-K layers reduce in a fixed order (workspace)
 
 
 def test_scene_graph_with_fresh_input_buffers_falls_back_to_copies():

@@ -82,12 +82,13 @@ __global__ __launch_bounds__(256) void aggressor(float *sink, int iters) {
 
 static float *g_x, *g_y; static void *g_wh, *g_wl;
 typedef int (*conv_fn)(const float *, const uint16_t *, const uint16_t *, const float *, const float *, const float *, float *,
-                       int, int, int, int, int, int, int, int, int, sgc_stream_t);
+                       int, int, int, int, int, int, int, int, int, float *, int64_t, sgc_stream_t);
 static conv_fn sgc_conv3d_cl_bf16x3 = nullptr;
 static const char *(*sgc_last_error)() = nullptr;
 static void launch_igemm(hipStream_t st) {
   // 25600 x 256 -> 256, 1x1x1: the bf16x3 implicit-GEMM kernel (8 waves, 80 KiB LDS, v_mfma_f32_32x32x16_bf16)
-  int rc = sgc_conv3d_cl_bf16x3(g_x, (const uint16_t *)g_wh, (const uint16_t *)g_wl, nullptr, nullptr, nullptr, g_y, 25600, 1, 1, 256, 256, 1, 1, 0, 0, (sgc_stream_t)st);
+  int rc = sgc_conv3d_cl_bf16x3(g_x, (const uint16_t *)g_wh, (const uint16_t *)g_wl, nullptr, nullptr, nullptr, g_y, 25600, 1, 1, 256, 256, 1, 1, 0, 0,
+                                nullptr, 0, (sgc_stream_t)st);
   if (rc) { printf("conv rc %d %s\n", rc, sgc_last_error()); exit(1); }
 }
 
