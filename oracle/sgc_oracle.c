@@ -17,7 +17,11 @@
  * (1) the independent closed form  grid_sample(value (x) dist)  evaluated with
  * torch on the CPU (tests/test_oracle_identity.py) and (2) golden vectors made
  * by running the reference's Python glue in the build container with this
- * oracle injected as `dfa3D._ext` (tests/golden/make_golden.py).
+ * oracle injected as `dfa3D._ext` (tests/golden/make_golden.py).  The two widened
+ * rows are pinned directly: sgc_aligned_nms3d against kept indices of the reference's
+ * own aligned_3d_nms (tests/golden/make_golden_nms.py), sgc_plane_sweep_corr against the
+ * correlation volume of the reference's own homo_warping loop
+ * (tests/golden/make_golden_planesweep.py).
  *
  * Reference files restated (paths relative to /root/reference; CS = packages/
  * 3D-deformable-attention/DFA3D/dfa3D/ops/csrc):
@@ -25,6 +29,8 @@
  *   depth score bwd  CS/common/cuda/ms_depth_score_sample_cuda_kernel.cuh:150-327
  *   weighted attn fwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:24-80,240-303
  *   weighted attn bwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:82-159,305-419
+ *   aligned 3D NMS   packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:131-178
+ *   plane sweep      mmdet3d_plugin/models/im2voxel/depth_utils/depth_est_fusion.py:87-126,233-240
  *
  * All arithmetic is fp32 in the reference's operation order; compile with
  * -ffp-contract=off so gcc does not fuse multiply-adds the reference's nvcc
