@@ -374,3 +374,28 @@ def test_get_bboxes_end_to_end_with_gpu_nms_matches_oracle_decode_and_nms(oracle
     assert boxes.shape[0] == want.shape[0] and 0 < want.shape[0] < int(keep.sum())     # NMS removed something
     assert max_err(boxes, want) < 1e-4 and max_err(scores, sc[ids]) < 1e-5
     assert torch.equal(labels.cpu(), lb[ids])
+
+
+def test_scene_graph_follows_weight_updates():
+    """A parameter changed in place (optimizer step, checkpoint load) must not be served by a stale graph or a stale
+    prepared plan: the graph cache is keyed by (address, version) of every parameter / buffer of the path."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(3)
+    det = build_detector(model_config(w)).eval().cuda()
+    feats, dpt, meta = make_scene(4, w["embed_dims"], kind=w["kind"], seed=5, device="cuda")
+    det.scene_graph = True
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in det.forward_features(feats, [meta], dpt).items() if torch.is_tensor(v)}
+        for p in list(det.voxel_head.parameters())[:6] + list(det.neck_3d.parameters())[:4]:
+            p.mul_(1.05).add_(0.01)
+        b = det.forward_features(feats, [meta], dpt)
+        det.scene_graph, det.use_graph = False, False
+        want = det.forward_features(feats, [meta], dpt)
+        torch.cuda.synchronize()
+    assert not torch.equal(a["volume"], b["volume"])
+    assert torch.equal(b["volume"], want["volume"]) and torch.equal(b["occ"], want["occ"])
+    for x, y in zip(b["centerness"] + b["cls_score"], want["centerness"] + want["cls_score"]):
+        assert torch.equal(x, y)
