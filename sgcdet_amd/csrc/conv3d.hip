@@ -393,6 +393,57 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   if (acc[0][0][0] != 123.456f) return;
 #endif
 
+  // Epilogue through LDS: in the MFMA layout a lane owns ONE column and 16 rows of a tile, i.e. 4-byte stores, 32 per
+  // lane -- store-issue bound (PMC on the K = 256 Linears: waves parked 54 % of their cycles, matrix pipe busy 20 %).
+  // The staging buffers are free now: the tile goes to LDS once and leaves as 16-byte row-contiguous stores (and the
+  // partial tiles of a split reduction, the residual and the scale / shift vectors move 16 bytes at a time too).
+  if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
+    constexpr int LDC = BN + 4;                              // floats per staged row: 16-byte aligned, odd in 16-B units
+    float *cs = reinterpret_cast<float *>(smem_b);           // [BM][LDC] <= the 2 x (A + B) staging buffers
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          cs[(wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * (BN / WN) + j * 32 + (lane & 31)] =
+              acc[i][j][k];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    for (int e = tid; e < BM * C4; e += NT) {
+      const int rl = e / C4, c4 = e - rl * C4;
+      const int m = m0 + rl, col = n0 + c4 * 4;
+      if (m >= Mrows || col >= p.Cout) continue;
+      int64_t orow = m;
+      if (p.transposed) {
+        const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
+        const int px = parity >> 2, py = (parity >> 1) & 1, pz = parity & 1;
+        orow = ((int64_t)(2 * x + px) * (2 * p.gy) + (2 * y + py)) * (2 * p.gz) + (2 * z + pz);
+      }
+      float4 v = *reinterpret_cast<const float4 *>(cs + rl * LDC + c4 * 4);
+      if (p.splitk > 1) {
+        *reinterpret_cast<float4 *>(p.ws + (int64_t)zid * p.ws_stride + orow * p.Cout + col) = v;
+        continue;
+      }
+      if (p.scale) {
+        const float4 sc4 = *reinterpret_cast<const float4 *>(p.scale + col);
+        v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
+      }
+      if (p.shift) {
+        const float4 sh4 = *reinterpret_cast<const float4 *>(p.shift + col);
+        v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
+      }
+      if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.residual) {
+        const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + orow * p.Cout + col);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
+      if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4 *>(p.y + orow * p.Cout + col) = v;
+    }
+    return;
+  }
+
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -628,6 +679,52 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       __syncthreads();
       read_A0(0);
     }
+  }
+
+  // Epilogue through LDS (as in the implicit-GEMM kernel): the halo / weight buffers are free, the 256 x 128 tile
+  // leaves as 16-byte row-contiguous stores instead of 64 four-byte stores per lane.
+  if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
+    constexpr int LDC = BNV + 4;
+    float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 135 KB <= A planes + B buffers
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          cs[(wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][k];
+    __syncthreads();
+    constexpr int C4 = BNV / 4;
+    for (int e = tid; e < 256 * C4; e += NT) {
+      const int rl = e / C4, c4 = e - rl * C4;
+      const int col = n0 + c4 * 4;
+      if (col >= p.Cout) continue;
+      const int r = vox_tab[rl];
+      const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
+      if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
+      const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
+      float4 v = *reinterpret_cast<const float4 *>(cs + rl * LDC + c4 * 4);
+      if (p.splitk > 1) {
+        *reinterpret_cast<float4 *>(p.ws + (int64_t)blockIdx.z * p.ws_stride + orow * p.Cout + col) = v;
+        continue;
+      }
+      if (p.scale) {
+        const float4 sc4 = *reinterpret_cast<const float4 *>(p.scale + col);
+        v.x *= sc4.x; v.y *= sc4.y; v.z *= sc4.z; v.w *= sc4.w;
+      }
+      if (p.shift) {
+        const float4 sh4 = *reinterpret_cast<const float4 *>(p.shift + col);
+        v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
+      }
+      if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.residual) {
+        const float4 r4 = *reinterpret_cast<const float4 *>(p.residual + orow * p.Cout + col);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
+      if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4 *>(p.y + orow * p.Cout + col) = v;
+    }
+    return;
   }
 
 #pragma unroll
