@@ -240,8 +240,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   const int ksteps_c = p.Cin / BK;
   const int nsteps = taps_per * ksteps_c;
 
-  const int c4 = tid & 7, r0 = tid >> 3;        // A: row r0 + AROWS i, 4 floats at c4*4
-  const int bc = tid & 3, br0 = tid >> 2;       // B: row br0 + BROWS_ i, 8 bf16 at bc*8
+  // Staging rows are dealt so that the lanes one LDS write pass covers (32 lanes x 8 B for A, 16 lanes x 16 B for B)
+  // sit in rows {r, r+4, r+8, r+12}: with the 20-dword row pitch those start 16 banks apart and tile all 64 banks;
+  // consecutive rows (the plain tid >> 3 deal) overlap by 12 banks and every pass took two turns.
+  const int c4 = tid & 7, rs8 = (tid >> 3) & 7;
+  const int r0 = 16 * (wid >> 1) + 2 * (wid & 1) + (rs8 >> 2) + 4 * (rs8 & 3);   // A: row r0 + AROWS i, 4 floats at c4*4
+  const int bc = tid & 3, rs16 = (tid >> 2) & 15;
+  const int br0 = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);                        // B: row br0 + BROWS_ i, 8 bf16 at bc*8
   int ax[ACH], ay[ACH], az[ACH];
   bool arow_ok[ACH];
 #pragma unroll
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   // The staging buffers are free now: the tile goes to LDS once and leaves as 16-byte row-contiguous stores (and the
   // partial tiles of a split reduction, the residual and the scale / shift vectors move 16 bytes at a time too).
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
-    constexpr int LDC = BN + 4;                              // floats per staged row: 16-byte aligned, odd in 16-B units
+    constexpr int LDC = BN + 8;                              // floats per staged row: rows r and r + 4 (lane halves) 32 banks apart
     float *cs = reinterpret_cast<float *>(smem_b);           // [BM][LDC] <= the 2 x (A + B) staging buffers
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -492,6 +497,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 // of the brick holds each halo-row residue mod 16 exactly twice (checked offline for the three brick shapes:
 // 18 for BZ = 16, 12 for BZ = 8, 6 for BZ = 4) -- the precondition of the conflict-free lane assignment.
 __host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ + 2; }
+__host__ __device__ constexpr size_t halo_tab_offset(int lrows) {
+  const size_t planes = (size_t)(2 * lrows + 4 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
+  const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                    // epilogue tile [256][BNV + 8]
+  return planes > stage ? planes : stage;
+}
 
 template <int BX, int BY, int BZ>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
@@ -503,7 +513,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
-  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(Bbase + 4 * B_PLANE);   // [8 tiles][32 lanes]
+  // [8 tiles][32 lanes], behind both the staging planes and the epilogue's output tile that later overlays them
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -549,8 +560,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
     arow[i] = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
   }
-  // B staging slot of this thread: row n = tid>>2, 8 bf16 at (tid&3)*8
-  const int bn = tid >> 2, bc = tid & 3;
+  // B staging slot of this thread: 8 bf16 at (tid&3)*8 of row bn; the 16 lanes of one ds_write_b128 pass take rows
+  // {r, r+4, r+8, r+12} (16 banks apart at the 20-dword pitch) instead of 4 consecutive rows that overlap by 12 banks
+  const int bc = tid & 3, rs16 = (tid >> 2) & 15;
+  const int bn = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);
   const bool bn_ok = n0 + bn < p.Cout;
 
   float4 ra[NA];
@@ -684,8 +697,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // Epilogue through LDS (as in the implicit-GEMM kernel): the halo / weight buffers are free, the 256 x 128 tile
   // leaves as 16-byte row-contiguous stores instead of 64 four-byte stores per lane.
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
-    constexpr int LDC = BNV + 4;
-    float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 135 KB <= A planes + B buffers
+    constexpr int LDC = BNV + 8;
+    float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 139 KB (launch_halo sizes LDS for it)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -787,7 +800,7 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
 template <int BX, int BY, int BZ>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
-  const size_t smem = (size_t)(2 * LROWS + 4 * 128) * LDKH * sizeof(uint16_t) + 256 * sizeof(uint16_t);
+  const size_t smem = halo_tab_offset(LROWS) + 256 * sizeof(uint16_t);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
