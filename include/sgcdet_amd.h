@@ -337,6 +337,25 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
 int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *labels, float iou_thr,
                       int64_t *keep, int32_t *n_keep, uint64_t *workspace, int n, sgc_stream_t stream);
 
+/* Rotated BEV NMS of every class in one call == the loop of mmdet3d `box3d_multiclass_nms`
+ * (packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:52-68) over `nms_bev` (:231-268), i.e.
+ * mmcv.ops.nms_rotated on BEV rectangles (mmcv-full 1.5.3, pip dependency docs/install.md:6, not vendored:
+ * mmcv/ops/csrc/common/box_iou_rotated_utils.hpp + cuda/nms_rotated_cuda.cuh, T = float); called by
+ * SunRgbdImVoxelHeadV2._nms, mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py:565-584 (ARKit configs):
+ *   boxes  [K,5] fp32 (x1, y1, x2, y2, ry) = `mlvl_bboxes_for_nms`; converted to (xc, yc, w, h, ry) as :256-262;
+ *   order  [C,K] int64: row c = box indices by DESCENDING score of class c (`_scores.sort(0, descending=True)`);
+ *   counts [C] int32 (device): only the first counts[c] entries of row c are candidates (score > score_thr);
+ *   a candidate is dropped when a kept, better-scored one of the same class has IoU > iou_thr (exact
+ *   intersection polygon of the two rotated rectangles, fp32, the reference kernel's operation order);
+ *   keep [C,K] int64 OUT: row c = kept box indices in descending score (= `_bboxes[selected]` order),
+ *   n_keep [C] int32 OUT (device), workspace >= C * K * ceil(K/64) uint64.  K <= 4096.                     */
+int sgc_nms_rotated_bev(const float *boxes, const int64_t *order, const int32_t *counts, float iou_thr,
+                        int64_t *keep, int32_t *n_keep, uint64_t *workspace, int K, int C, sgc_stream_t stream);
+
+/* mmcv.ops.box_iou_rotated(a, b, mode='iou', aligned=False) -- the IoU the NMS above thresholds:
+ * a [n,5], b [m,5] fp32 (xc, yc, w, h, angle in radians) -> iou [n,m] fp32.                                */
+int sgc_box_iou_rotated(const float *a, const float *b, float *iou, int n, int m, sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 9. Upstream of the path: plane-sweep matching cost of DepthNet_Fusion
  * ------------------------------------------------------------------------- */

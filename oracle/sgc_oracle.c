@@ -21,7 +21,11 @@
  * rows are pinned directly: sgc_aligned_nms3d against kept indices of the reference's
  * own aligned_3d_nms (tests/golden/make_golden_nms.py), sgc_plane_sweep_corr against the
  * correlation volume of the reference's own homo_warping loop
- * (tests/golden/make_golden_planesweep.py).
+ * (tests/golden/make_golden_planesweep.py).  sgc_nms_rotated_bev / sgc_box_iou_rotated
+ * restate mmcv-full 1.5.3's nms_rotated, a pip dependency that is neither vendored in
+ * the reference nor installed here: PARITY UNPINNED against mmcv; the class-loop glue
+ * around it is pinned to the reference's own box3d_multiclass_nms / nms_bev and the IoU
+ * is cross-checked against a float64 polygon clip (tests/golden/make_golden_nms_rotated.py).
  *
  * Reference files restated (paths relative to /root/reference; CS = packages/
  * 3D-deformable-attention/DFA3D/dfa3D/ops/csrc):
@@ -30,6 +34,8 @@
  *   weighted attn fwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:24-80,240-303
  *   weighted attn bwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:82-159,305-419
  *   aligned 3D NMS   packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:131-178
+ *   rotated BEV NMS  packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:52-68,231-268
+ *                    (+ mmcv-full 1.5.3 box_iou_rotated_utils.hpp / nms_rotated_cuda.cuh, published algorithm)
  *   plane sweep      mmdet3d_plugin/models/im2voxel/depth_utils/depth_est_fusion.py:87-126,233-240
  *
  * All arithmetic is fp32 in the reference's operation order; compile with
@@ -825,6 +831,169 @@ int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *l
   }
   free(sorted);
   *n_keep = cnt;
+  return SGC_OK;
+}
+
+
+/* ---- 8b. rotated BEV NMS: mmdet3d nms_bev (box3d_nms.py:231-268) -> mmcv.ops.nms_rotated -------------------
+ * mmcv-full 1.5.3 is a pip dependency of the reference (docs/install.md:6) and is NOT vendored: what follows
+ * restates its published algorithm (mmcv/ops/csrc/common/box_iou_rotated_utils.hpp: get_rotated_vertices,
+ * get_intersection_points, convex_hull_graham [device branch: O(n^2) exchange sort], polygon_area,
+ * single_box_iou_rotated; mmcv/ops/csrc/common/cuda/nms_rotated_cuda.cuh: mask = IoU(row, col) > thr for
+ * col after row in descending score; host sweep) in T = float exactly as the CUDA kernel instantiates it.
+ * PARITY UNPINNED against mmcv itself (not importable here); cross-checked in tests/ against an independent
+ * float64 polygon clip.                                                                                    */
+typedef struct { float x, y; } rpt_t;
+static inline float rcross(rpt_t a, rpt_t b) { return a.x * b.y - b.x * a.y; }
+static inline float rdot(rpt_t a, rpt_t b) { return a.x * b.x + a.y * b.y; }
+static inline rpt_t rsub(rpt_t a, rpt_t b) { rpt_t r = {a.x - b.x, a.y - b.y}; return r; }
+
+static void rot_vertices(float xc, float yc, float w, float h, float a, rpt_t *pts) {
+  const double theta = (double)a;
+  const float cos2 = (float)cos(theta) * 0.5f, sin2 = (float)sin(theta) * 0.5f;
+  pts[0].x = xc - sin2 * h - cos2 * w;
+  pts[0].y = yc + cos2 * h - sin2 * w;
+  pts[1].x = xc + sin2 * h - cos2 * w;
+  pts[1].y = yc - cos2 * h - sin2 * w;
+  pts[2].x = 2 * xc - pts[0].x;
+  pts[2].y = 2 * yc - pts[0].y;
+  pts[3].x = 2 * xc - pts[1].x;
+  pts[3].y = 2 * yc - pts[1].y;
+}
+
+static int rot_intersections(const rpt_t *p1, const rpt_t *p2, rpt_t *out) {
+  rpt_t v1[4], v2[4];
+  for (int i = 0; i < 4; ++i) { v1[i] = rsub(p1[(i + 1) % 4], p1[i]); v2[i] = rsub(p2[(i + 1) % 4], p2[i]); }
+  int num = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const float det = rcross(v2[j], v1[i]);
+      if (fabs((double)det) <= 1e-14) continue;                  /* parallel edges */
+      const rpt_t v12 = rsub(p2[j], p1[i]);
+      const float t1 = rcross(v2[j], v12) / det, t2 = rcross(v1[i], v12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        out[num].x = p1[i].x + v1[i].x * t1;
+        out[num].y = p1[i].y + v1[i].y * t1;
+        ++num;
+      }
+    }
+  {                                                              /* vertices of rect 1 inside rect 2 */
+    const rpt_t AB = v2[0], DA = v2[3];
+    const float ABdotAB = rdot(AB, AB), ADdotAD = rdot(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const rpt_t AP = rsub(p1[i], p2[0]);
+      const float APdotAB = rdot(AP, AB), APdotAD = -rdot(AP, DA);
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) out[num++] = p1[i];
+    }
+  }
+  {                                                              /* and the reverse */
+    const rpt_t AB = v1[0], DA = v1[3];
+    const float ABdotAB = rdot(AB, AB), ADdotAD = rdot(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const rpt_t AP = rsub(p2[i], p1[0]);
+      const float APdotAB = rdot(AP, AB), APdotAD = -rdot(AP, DA);
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) out[num++] = p2[i];
+    }
+  }
+  return num;
+}
+
+static int rot_hull(const rpt_t *p, int n, rpt_t *q) {            /* convex_hull_graham(..., shift_to_zero = true) */
+  int t = 0;
+  for (int i = 1; i < n; ++i)
+    if (p[i].y < p[t].y || (p[i].y == p[t].y && p[i].x < p[t].x)) t = i;
+  const rpt_t start = p[t];
+  for (int i = 0; i < n; ++i) q[i] = rsub(p[i], start);
+  { const rpt_t tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
+  float dist[24];
+  for (int i = 0; i < n; ++i) dist[i] = rdot(q[i], q[i]);
+  for (int i = 1; i < n - 1; ++i)                                /* device branch: exchange sort by polar angle */
+    for (int j = i + 1; j < n; ++j) {
+      const float cp = rcross(q[i], q[j]);
+      if (((double)cp < -1e-6) || (fabs((double)cp) < 1e-6 && dist[i] > dist[j])) {
+        const rpt_t qt = q[i]; q[i] = q[j]; q[j] = qt;
+        const float dt = dist[i]; dist[i] = dist[j]; dist[j] = dt;
+      }
+    }
+  int k;
+  for (k = 1; k < n; ++k)
+    if ((double)dist[k] > 1e-8) break;
+  if (k == n) return 1;                                          /* all points coincide */
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < n; ++i) {
+    while (m > 1 && rcross(rsub(q[i], q[m - 2]), rsub(q[m - 1], q[m - 2])) >= 0) --m;
+    q[m++] = q[i];
+  }
+  return m;
+}
+
+static float rot_iou(const float *b1, const float *b2) {          /* single_box_iou_rotated(box1, box2, mode 0); xywhr */
+  const float sx = (b1[0] + b2[0]) * 0.5f, sy = (b1[1] + b2[1]) * 0.5f;   /* "/ 2.0" in double == exact halving */
+  const float x1 = b1[0] - sx, y1 = b1[1] - sy, x2 = b2[0] - sx, y2 = b2[1] - sy;
+  const float area1 = b1[2] * b1[3], area2 = b2[2] * b2[3];
+  if ((double)area1 < 1e-14 || (double)area2 < 1e-14) return 0.f;
+  rpt_t p1[4], p2[4], ip[24], hull[24];
+  rot_vertices(x1, y1, b1[2], b1[3], b1[4], p1);
+  rot_vertices(x2, y2, b2[2], b2[3], b2[4], p2);
+  const int num = rot_intersections(p1, p2, ip);
+  float inter = 0.f;
+  if (num > 2) {
+    const int m = rot_hull(ip, num, hull);
+    if (m > 2) {
+      float area = 0.f;
+      for (int i = 1; i < m - 1; ++i) area += fabsf(rcross(rsub(hull[i], hull[0]), rsub(hull[i + 1], hull[0])));
+      inter = area * 0.5f;
+    }
+  }
+  return inter / (area1 + area2 - inter);
+}
+
+/* mmcv.ops.box_iou_rotated(a, b, mode='iou', aligned=False): boxes (xc, yc, w, h, angle in radians) */
+int sgc_box_iou_rotated(const float *a, const float *b, float *iou, int n, int m, sgc_stream_t stream) {
+  (void)stream;
+  if (n <= 0 || m <= 0) return SGC_OK;
+  if (!a || !b || !iou) return fail(SGC_EINVAL, "null pointer");
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) iou[(int64_t)i * m + j] = rot_iou(a + (int64_t)i * 5, b + (int64_t)j * 5);
+  return SGC_OK;
+}
+
+/* per class c: nms_bev(boxes[order[c][:counts[c]]], thr) -- xyxyr -> xywhr (box3d_nms.py:256-262), then the
+ * nms_rotated mask + sweep over the already sorted boxes */
+int sgc_nms_rotated_bev(const float *boxes, const int64_t *order, const int32_t *counts, float iou_thr,
+                        int64_t *keep, int32_t *n_keep, uint64_t *workspace, int K, int C, sgc_stream_t stream) {
+  (void)stream; (void)workspace;
+  if (C <= 0) return SGC_OK;
+  if (!counts || !n_keep) return fail(SGC_EINVAL, "null pointer");
+  if (K > 4096) return fail(SGC_EUNSUP, "at most 4096 candidates");
+  for (int c = 0; c < C; ++c) {
+    const int n = counts[c] < K ? counts[c] : K;
+    n_keep[c] = 0;
+    if (n <= 0) continue;
+    if (!boxes || !order || !keep) return fail(SGC_EINVAL, "null pointer");
+    float *xywhr = (float *)malloc(sizeof(float) * 5 * (size_t)n);
+    unsigned char *removed = (unsigned char *)calloc((size_t)n, 1);
+    if (!xywhr || !removed) { free(xywhr); free(removed); return fail(SGC_EINVAL, "out of memory"); }
+    const int64_t *ord = order + (int64_t)c * K;
+    for (int p = 0; p < n; ++p) {
+      const float *b = boxes + ord[p] * 5;
+      xywhr[p * 5 + 0] = (b[0] + b[2]) / 2;
+      xywhr[p * 5 + 1] = (b[1] + b[3]) / 2;
+      xywhr[p * 5 + 2] = b[2] - b[0];
+      xywhr[p * 5 + 3] = b[3] - b[1];
+      xywhr[p * 5 + 4] = b[4];
+    }
+    int cnt = 0;
+    for (int p = 0; p < n; ++p) {
+      if (removed[p]) continue;
+      keep[(int64_t)c * K + cnt++] = ord[p];
+      for (int q = p + 1; q < n; ++q)
+        if (!removed[q] && rot_iou(xywhr + p * 5, xywhr + q * 5) > iou_thr) removed[q] = 1;
+    }
+    n_keep[c] = cnt;
+    free(xywhr); free(removed);
+  }
   return SGC_OK;
 }
 

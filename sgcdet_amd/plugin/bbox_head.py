@@ -9,8 +9,9 @@ the reference's.  Target assignment and losses (:95-235, :361-435, :485-561) are
 
 NMS (row f-4): ScanNet's ``aligned_3d_nms`` (mmdet3d, a Python while-loop in the reference) runs on the GPU
 (``sgc_aligned_nms3d``: one mask kernel + one sweep, same keep/drop arithmetic); ARKit's
-``box3d_multiclass_nms`` + mmcv ``nms_rotated`` is not built: ``SunRgbdImVoxelHeadV2._nms`` returns the
-score-thresholded candidates unless an ``nms_fn`` is injected.
+``box3d_multiclass_nms`` + mmcv ``nms_rotated`` runs all classes in two launches (``sgc_nms_rotated_bev``: exact
+rotated-rectangle intersection in the reference kernel's fp32 operation order; mmcv is not vendored in the
+reference, so that restatement is unpinned against mmcv itself -- see the oracle's header).
 """
 import torch
 from torch import nn
@@ -206,8 +207,42 @@ class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
         return torch.cat((points + shift, size, bbox_pred[:, 6:7]), dim=-1)
 
     def _nms(self, bboxes, scores, img_meta):
+        """box3d_multiclass_nms on BEV rectangles with rotated IoU (:565-584).  The reference appends a dummy
+        background column only because mmdet3d's loop runs over ``shape[1] - 1`` classes; here every column of
+        ``scores`` is a class."""
         if self.nms_fn is not None:
             return self.nms_fn(bboxes, scores, self.test_cfg, img_meta)
-        max_scores, labels = scores.max(dim=1)
-        keep = max_scores > self.test_cfg["score_thr"]
-        return bboxes[keep], max_scores[keep], labels[keep]
+        cfg = self.test_cfg
+        if not cfg.get("use_rotate_nms", True):
+            raise NotImplementedError("SunRgbdImVoxelHeadV2: nms_normal_bev (use_rotate_nms=False) is not built; "
+                                      "pass nms_fn= (the reference's ARKit configs use rotated NMS)")
+        bboxes, scores, labels = box3d_multiclass_nms_rotated(
+            ext.ops(), bboxes.float().contiguous(), scores.float().contiguous(), cfg["score_thr"], cfg["nms_pre"],
+            cfg["nms_thr"])
+        box_type = img_meta.get("box_type_3d") if isinstance(img_meta, dict) else None
+        if box_type is not None:
+            bboxes = box_type(bboxes, origin=(0.5, 0.5, 0.5))
+        return bboxes, scores, labels
+
+
+def box3d_multiclass_nms_rotated(ops, bboxes, scores, score_thr, max_num, nms_thr):
+    """mmdet3d ``box3d_multiclass_nms`` (box3d_nms.py:8-128) with ``cfg.use_rotate_nms`` as the ARKit head calls it:
+    bboxes [K,7] (cx,cy,cz,w,l,h,yaw), scores [K,C] -> (boxes [n,7], scores [n], labels [n]) concatenated class by
+    class, each class in descending score; more than ``max_num`` survivors: the best ``max_num`` by score.
+    ``ops``: a TensorOps (the HIP library in the product, the CPU oracle in tests).  One host read-back (the
+    per-class survivor counts) -- the outputs are variable-length."""
+    K, C = scores.shape
+    if K == 0:
+        return bboxes.new_zeros((0, bboxes.shape[-1])), scores.new_zeros((0,)), scores.new_zeros((0,), dtype=torch.long)
+    bev = torch.stack((bboxes[:, 0] - bboxes[:, 3] / 2, bboxes[:, 1] - bboxes[:, 4] / 2,
+                       bboxes[:, 0] + bboxes[:, 3] / 2, bboxes[:, 1] + bboxes[:, 4] / 2, bboxes[:, 6]), dim=1)
+    keep, n_keep = ops.nms_rotated_bev(bev.contiguous(), scores, score_thr, nms_thr)
+    live = torch.arange(K, device=keep.device)[None, :] < n_keep[:, None]        # [C,K], row-major = class order
+    sel = keep[live]
+    labels = torch.arange(C, device=keep.device)[:, None].expand(C, K)[live]
+    out_boxes, out_scores = bboxes[sel], scores[sel, labels]
+    if out_boxes.shape[0] > max_num:
+        _, inds = out_scores.sort(descending=True)
+        inds = inds[:max_num]
+        out_boxes, out_scores, labels = out_boxes[inds], out_scores[inds], labels[inds]
+    return out_boxes, out_scores, labels

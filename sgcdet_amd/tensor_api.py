@@ -418,6 +418,40 @@ class TensorOps:
         self._call("sgc_aligned_nms3d", boxes, order, labels, float(iou_thr), keep, n_keep, ws, n)
         return keep[: int(n_keep.item())]
 
+    def nms_rotated_bev(self, boxes, scores, score_thr, iou_thr):
+        """The class loop of mmdet3d ``box3d_multiclass_nms`` (box3d_nms.py:52-68) with ``use_rotate_nms``: for
+        every class c, ``nms_bev(boxes[scores[:, c] > score_thr], ...)``.  boxes [K,5] (x1,y1,x2,y2,ry), scores
+        [K,C].  Returns (keep [C,K] int64: kept box indices per class in descending score, n_keep [C] int32);
+        nothing is read back to the host here."""
+        self._check(boxes=boxes, scores=scores)
+        self._f32(boxes=boxes, scores=scores)
+        K, C = scores.shape
+        if boxes.shape != (K, 5):
+            raise RuntimeError("nms_rotated_bev: boxes [K,5] (x1,y1,x2,y2,ry) and scores [K,C] expected")
+        keep = torch.zeros((C, K), dtype=torch.int64, device=boxes.device)
+        n_keep = torch.zeros(C, dtype=torch.int32, device=boxes.device)
+        if K == 0 or C == 0:
+            return keep, n_keep
+        st = scores.t()
+        cand = st > score_thr
+        counts = cand.sum(dim=1).to(torch.int32)
+        # candidates first, by descending score (stable: ties keep ascending box index); the rest of a row is unused
+        order = torch.where(cand, st, torch.full_like(st, float("-inf"))).sort(dim=1, descending=True, stable=True)[1]
+        ws = torch.empty(C * K * ((K + 63) // 64), dtype=torch.int64, device=boxes.device)
+        self._call("sgc_nms_rotated_bev", boxes, order.contiguous(), counts, float(iou_thr), keep, n_keep, ws, K, C)
+        return keep, n_keep
+
+    def box_iou_rotated(self, a, b):
+        """mmcv ``box_iou_rotated(a [n,5], b [m,5])`` (xc, yc, w, h, radians) -> [n,m] IoU."""
+        self._check(a=a, b=b)
+        self._f32(a=a, b=b)
+        n, m = a.shape[0], b.shape[0]
+        if a.shape != (n, 5) or b.shape != (m, 5):
+            raise RuntimeError("box_iou_rotated: [n,5] and [m,5] boxes expected")
+        iou = torch.empty((n, m), dtype=torch.float32, device=a.device)
+        self._call("sgc_box_iou_rotated", a, b, iou, n, m)
+        return iou
+
     # ---- 9. upstream: plane-sweep matching cost ------------------------------------------------
     def plane_sweep_corr(self, feat, nbr, rt, depth, H, W):
         """feat [N, H*W, C] channels-last; nbr [N,K] int32; rt [N,K,12]; depth [D] -> corr [N,D,H,W]."""

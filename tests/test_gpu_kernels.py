@@ -275,6 +275,45 @@ def test_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
         gpu_ops.aligned_nms3d(torch.zeros(5000, 6).cuda(), torch.zeros(5000).cuda(), torch.zeros(5000, dtype=torch.int64).cuda(), 0.25)
 
 
+def test_rotated_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
+    """ARKit post-processing (row f-4): golden of the reference's multiclass glue, the float64 clip table, the
+    textbook loop, and -- at the head's real size, 3 x nms_pre candidates x 17 classes, score_thr 0 -- the CPU
+    oracle: same survivors in the same order for every class."""
+    from nms_rotated_contract import (arkit_like, bev_of, check_iou_against_float64_clip, check_mask_sweep_equals_textbook_loop,
+                                      check_multiclass_golden)
+    check_multiclass_golden(gpu_ops, "cuda")
+    check_iou_against_float64_clip(gpu_ops, "cuda")
+    check_mask_sweep_equals_textbook_loop(gpu_ops, "cuda")
+    # pairwise IoU: the same fp32 operation order on both sides (cos / sin evaluated in double as the reference does)
+    boxes, scores = arkit_like(700, 3, seed=8)
+    bev = bev_of(boxes)
+    xywhr = torch.stack(((bev[:, 0] + bev[:, 2]) / 2, (bev[:, 1] + bev[:, 3]) / 2, bev[:, 2] - bev[:, 0],
+                         bev[:, 3] - bev[:, 1], bev[:, 4]), 1).contiguous()
+    iou_c = oracle_ops.box_iou_rotated(xywhr, xywhr)
+    iou_g = gpu_ops.box_iou_rotated(xywhr.cuda(), xywhr.cuda()).cpu()
+    assert (iou_c > 0.15).sum() > 5000
+    assert (iou_g - iou_c).abs().max() < 1e-6
+    assert (iou_g != iou_c).float().mean() < 1e-3, (iou_g != iou_c).float().mean()
+    for n, n_cls, seed in ((3000, 17, 9), (4096, 2, 10), (65, 3, 11)):
+        boxes, scores = arkit_like(n, n_cls, seed)
+        bev = bev_of(boxes)
+        keep_c, nk_c = oracle_ops.nms_rotated_bev(bev, scores, 0.0, 0.15)
+        keep_g, nk_g = gpu_ops.nms_rotated_bev(bev.cuda(), scores.cuda(), 0.0, 0.15)
+        assert torch.equal(nk_g.cpu(), nk_c), (n, nk_g.cpu(), nk_c)
+        for c in range(n_cls):
+            k = int(nk_c[c])
+            assert 0 < k < n and torch.equal(keep_g[c, :k].cpu(), keep_c[c, :k]), (n, c)
+    # empty inputs, classes without candidates, the size limit
+    keep, nk = gpu_ops.nms_rotated_bev(torch.zeros(0, 5).cuda(), torch.zeros(0, 4).cuda(), 0.0, 0.15)
+    assert keep.shape == (4, 0) and nk.tolist() == [0, 0, 0, 0]
+    boxes, scores = arkit_like(100, 3, seed=12)
+    scores[:, 1] = 0.0
+    keep, nk = gpu_ops.nms_rotated_bev(bev_of(boxes).cuda(), scores.cuda(), 0.0, 0.15)
+    assert nk[1].item() == 0 and nk[0].item() > 0
+    with pytest.raises(Exception):
+        gpu_ops.nms_rotated_bev(torch.zeros(5000, 5).cuda(), torch.zeros(5000, 2).cuda(), 0.0, 0.15)
+
+
 def test_camera_stride_of_channels_last_maps(oracle_ops, gpu_ops):
     from count_contract import check_camera_stride
     check_camera_stride(gpu_ops, oracle_ops, "cuda")

@@ -376,6 +376,39 @@ def test_get_bboxes_end_to_end_with_gpu_nms_matches_oracle_decode_and_nms(oracle
     assert torch.equal(labels.cpu(), lb[ids])
 
 
+def test_arkit_head_get_bboxes_runs_rotated_multiclass_nms_on_the_gpu(oracle_ops):
+    """SunRgbdImVoxelHeadV2.get_bboxes (imvoxel_head_v2.py:248-317, :565-584) end to end on the GPU with the ARKit
+    test_cfg (score_thr 0, rotated BEV NMS at 0.15, max_num = nms_pre): the survivors equal the reference's
+    multiclass glue run through the CPU oracle on the same decoded candidates."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin.bbox_head import box3d_multiclass_nms_rotated
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg1_plumbing")
+    w.update(kind="arkit", head="SunRgbdImVoxelHeadV2", n_classes=17, n_reg_outs=7)
+    torch.manual_seed(19)
+    det = build_detector(model_config(w, nms_pre=150)).eval()
+    gen = torch.Generator().manual_seed(18)
+    with torch.no_grad():
+        for _, p in list(det.voxel_head.named_parameters()) + list(det.bbox_head.named_parameters()):
+            p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+    det = det.cuda()
+    assert det.bbox_head.test_cfg["use_rotate_nms"] and det.bbox_head.test_cfg["score_thr"] == 0.0
+    feats, dpt, meta = make_scene(4, w["embed_dims"], kind="arkit", seed=13, device="cuda")
+    with torch.no_grad():
+        r = det.forward_features(feats, [meta], dpt)
+        head = det.bbox_head
+        (boxes, scores, labels), = head.get_bboxes(r["centerness"], r["bbox_pred"], r["cls_score"], r["valid"].float(), [meta])
+        valids = [torch.nn.Upsample(size=x.shape[-3:], mode="trilinear")(r["valid"].float()).round().bool() for x in r["centerness"]]
+        cand_b, cand_s = head.decode_candidates([x[0] for x in r["centerness"]], [x[0] for x in r["bbox_pred"]],
+                                                [x[0] for x in r["cls_score"]], [v[0] for v in valids], meta)
+    assert cand_b.shape == (350, 7) and cand_s.shape == (350, 17)              # 150 + 150 + all 50 coarse voxels
+    wb, ws, wl = box3d_multiclass_nms_rotated(oracle_ops, cand_b.cpu().contiguous(), cand_s.cpu().contiguous(), 0.0, 150, 0.15)
+    assert boxes.shape == (150, 7)                                   # more than max_num survive over 17 classes: cut
+    assert torch.equal(labels.cpu(), wl) and torch.equal(scores.cpu(), ws) and torch.equal(boxes.cpu(), wb)
+    assert len(set(labels.tolist())) > 3
+
+
 def test_scene_graph_follows_weight_updates():
     """A parameter changed in place (optimizer step, checkpoint load) must not be served by a stale graph or a stale
     prepared plan: the graph cache is keyed by (address, version) of every parameter / buffer of the path."""

@@ -95,6 +95,17 @@ def _plane_sweep_case(d, k):
     return f_mvs, rows, nbr, rel.reshape(N, rel.shape[1], 12).contiguous(), torch.from_numpy(d[f"depth{k}"]), (H, W)
 
 
+def test_oracle_rotated_nms_reproduces_reference_multiclass_glue(oracle_ops):
+    from nms_rotated_contract import check_multiclass_golden
+    check_multiclass_golden(oracle_ops, "cpu")
+
+
+def test_oracle_rotated_iou_matches_float64_polygon_clip(oracle_ops):
+    from nms_rotated_contract import check_iou_against_float64_clip, check_mask_sweep_equals_textbook_loop
+    check_iou_against_float64_clip(oracle_ops, "cpu")
+    check_mask_sweep_equals_textbook_loop(oracle_ops, "cpu")
+
+
 def test_oracle_plane_sweep_reproduces_reference_cost_volume(oracle_ops):
     """tests/golden/plane_sweep.npz: correlation volume of the reference's own homo_warping + cost-volume loop
     (make_golden_planesweep.py) -- the oracle never builds the warped features and agrees to 1e-5."""

@@ -69,4 +69,18 @@ def reference_loop():      # the reference's algorithm, torch ops on the GPU (on
 t_r, keep_r = timeit(reference_loop, 2, 1)
 out["aligned_nms3d"] = dict(candidates=n, kept=int(keep.numel()), hip_ms=round(t_n * 1e3, 3), reference_loop_in_torch_ms=round(t_r * 1e3, 1),
                             identical_indices=bool(torch.equal(keep, keep_r)))
+# ---- f-4: rotated BEV NMS of the ARKit head: 3 x nms_pre candidates, 17 classes, score_thr 0 ----
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from nms_rotated_contract import arkit_like, bev_of
+from sgcdet_amd.plugin.bbox_head import box3d_multiclass_nms_rotated
+rb, rs = arkit_like(3000, 17, seed=9)
+rb, rs = rb.cuda(), rs.cuda()
+bev = bev_of(rb)
+t_k, (keep, nk) = timeit(lambda: ops.nms_rotated_bev(bev, rs, 0.0, 0.15), 10)
+t_g, res = timeit(lambda: box3d_multiclass_nms_rotated(ops, rb, rs, 0.0, 1000, 0.15), 10)
+cand = int((rs > 0).sum())
+pairs = int(((rs > 0).sum(0).double() ** 2 / 2).sum())
+out["nms_rotated_bev"] = dict(candidates_per_class=3000, classes=17, candidates_total=cand, pairs=pairs, kept=int(nk.sum()),
+                              sort_mask_sweep_ms=round(t_k * 1e3, 3), with_glue_and_readback_ms=round(t_g * 1e3, 3),
+                              note="reference: 17 x (sort + mmcv nms_rotated mask kernel + bit-matrix copy to the host + CPU sweep)")
 print(json.dumps(out))
