@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void dfa3d_bwd_kernel(const BwdParams p) {
           for (int v = 0; v < VEC; ++v) {
             ghw[v] += sg[k] * dh_c[k] * vv[v];
             gww[v] += sg[k] * dw_c[k] * vv[v];
-            atomicAdd(gbase + o + v, ak * tgv[v]);
+            if (VEC == 1) atomicAdd(gbase + o + v, ak * tgv[v]);        // VEC == 4: phase 2b scatters whole rows
             gsk += vv[v] * bil[k] * tgv[v];
             val[v] += ak * vv[v];
           }
@@ -202,9 +202,43 @@ __global__ __launch_bounds__(256) void dfa3d_bwd_kernel(const BwdParams p) {
         part[k] = x;
       }
       if (in_tile && ((r - m * CV) % RW) == 0) {
+        if (RW == CV) {                 // the whole (item, head) group sits in this wave: the only writer
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
-          if (part[k] != 0.f) atomicAdd(&R.res[k], part[k]);
+          for (int k = 0; k < 7; ++k) R.res[k] = part[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 7; ++k)
+            if (part[k] != 0.f) atomicAdd(&R.res[k], part[k]);
+        }
+      }
+    }
+  }
+  // ---- phase 2b: grad_value scatter, one wave per item, lanes along the channels of the pixel row ----
+  // Device-scope float atomics are served memory-side in 64-byte requests (the L2s of the 8 XCDs are not coherent
+  // with each other); with the lane = (head, 4 channels) deal of phase 2 every wave instruction touched 4 dwords
+  // of each of its 16 requests.  Here instruction j of a lane adds channel 64 j + lane: 16 useful dwords per
+  // request, a quarter of the requests (measured on the config-2 finest level: 4.9 -> see DESIGN.md 4.3).
+  if (VEC == 4) {
+    const int lane = tid & (kWave - 1), wv = tid / kWave, nwv = blockDim.x / kWave;
+    for (int il = wv; il < p.TP; il += nwv) {
+      const int item = item0 + il;
+      if (item >= p.n_items) break;
+      float *grow = p.grad_value + (int64_t)lds_b[il] * p.S * MC;
+      for (int c = lane; c < MC; c += kWave) {
+        const float t = p.grad_out[(int64_t)item * MC + c];
+        if (!__builtin_amdgcn_ballot_w64(t != 0.f)) continue;      // padded rows of the rebatch: nothing to add
+        const int m = c / p.Cm;
+        for (int s2 = 0; s2 < LP; ++s2) {
+          const SampleRec &R = rec[il * SPI + m * LP + s2];
+          if (R.misc.w == 0.f) continue;
+          const float lh = R.misc.x, lw = R.misc.y, tg = t * R.misc.z;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          const int ok[4] = {R.off.x, R.off.y, R.off.z, R.off.w};
+          const float ak[4] = {hh * hw * R.sg.x, hh * lw * R.sg.y, lh * hw * R.sg.z, lh * lw * R.sg.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ok[k] >= 0) atomicAdd(grow + (int64_t)ok[k] * MC + c, ak[k] * tg);
+        }
       }
     }
   }

@@ -92,7 +92,7 @@ class ImVoxelHeadV2(nn.Module):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled() and x[0].is_cuda and x[0].shape[0] == 1:
             return self._forward_hip(x)
-        return multi_apply(self.forward_single, x, self.scales)
+        return multi_apply(self.forward_single, [t.contiguous() for t in x], self.scales)   # packed NCDHW for MIOpen
 
     def _reg_activation(self, reg, scale):
         raise NotImplementedError

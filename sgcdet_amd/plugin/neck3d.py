@@ -113,6 +113,9 @@ class FastIndoorImVoxelNeck(nn.Module):
         """[1,C,nx,ny,nz] -> [out@1x, out@1/2, out@1/4], finest first (imvoxelnet.py:22-34)."""
         if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.shape[0] == 1:
             return self._forward_hip(x)
+        # library convolutions (training / autograd): the voxel head hands over a channels-last strided view, for which
+        # MIOpen has only its naive_conv_*_nonpacked kernels (2.6 s per config-2 step instead of ~0.1 s)
+        x = x.contiguous()
         skips = []
         for i in range(self.n_scales):
             x = getattr(self, f"down_layer_{i}")(x)

@@ -1,0 +1,45 @@
+"""Forward + backward of the path (voxel head -> neck -> head convolutions, a dummy quadratic loss on every head
+tensor) at a BASELINE workload, training mode: ms per step and, under `rocprofv3 --kernel-trace --stats`, the kernel
+breakdown (row a11b: what the DFA3D backward costs at scale next to the library convolutions)."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sgcdet_amd.plugin  # noqa: F401
+from sgcdet_amd.mmcv_lite import build_detector
+from sgcdet_amd.scene import make_scene, model_config, workload
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="cfg2_scannet")
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--no-neck", action="store_true", help="stop at the volume (view transform only)")
+args = ap.parse_args()
+w = workload(args.workload)
+torch.manual_seed(0)
+det = build_detector(model_config(w)).cuda().train()
+feats, dpt, meta = make_scene(w["n_views"], w["embed_dims"], kind=w["kind"], seed=1, device="cuda", img_hw=(256, 320))
+feats = [f.requires_grad_(True) for f in feats]
+dpt = dpt.requires_grad_(True)
+params = [p for p in det.parameters() if p.requires_grad]
+
+def step():
+    for p in params:
+        p.grad = None
+    if args.no_neck:
+        import torch.nn.functional as F
+        dpts = [dpt, F.interpolate(dpt, scale_factor=(1, 0.5, 0.5), mode="nearest"), F.interpolate(dpt, scale_factor=(1, 0.25, 0.25), mode="nearest")]
+        vol, valid, occ = det.voxel_head(feats, meta, dpts)
+        loss = (vol ** 2).mean() + occ.mean()
+    else:
+        r = det.forward_features(feats, [meta], dpt)
+        loss = sum((t ** 2).mean() for k in ("centerness", "bbox_pred", "cls_score") for t in r[k]) + r["occ"].mean()
+    loss.backward()
+    return float(loss.detach())
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(args.steps):
+    l = step()
+torch.cuda.synchronize()
+print(json.dumps(dict(workload=args.workload, ms_per_step=round((time.perf_counter() - t) / args.steps * 1e3, 2), loss=l,
+                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck)))
