@@ -356,6 +356,22 @@ int sgc_nms_rotated_bev(const float *boxes, const int64_t *order, const int32_t 
  * a [n,5], b [m,5] fp32 (xc, yc, w, h, angle in radians) -> iou [n,m] fp32.                                */
 int sgc_box_iou_rotated(const float *a, const float *b, float *iou, int n, int m, sgc_stream_t stream);
 
+/* Target assignment of the FCOS3D-style head == `ImVoxelHeadV2.get_targets`
+ * (mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py:361-435 for ScanNetImVoxelHeadV2, :485-561 for
+ * SunRgbdImVoxelHeadV2) without its dense [n_points, n_boxes(, 6)] intermediates:
+ *   points [n_points,3] fp32 (all scales concatenated, finest first), scales [n_points] int32 (scale id of a point),
+ *   boxes [n_boxes,7] fp32 (gravity centre x,y,z, dx,dy,dz, yaw; yaw ignored unless `rotated`), gt_labels [n_boxes] int64.
+ *   A point is assigned to the box of minimal volume among those it lies strictly inside of, whose best scale
+ *   (smallest scale with >= `limit` inside points, :390-407) is the point's scale, and for which its centerness
+ *   exceeds the box's (centerness_topk + 1)-th largest (:413-417).
+ *   centerness_t [n_points] fp32, bbox_t [n_points,6] (x0,y0,z0,x1,y1,z1; rotated: [n_points,7] the assigned gt row),
+ *   labels [n_points] int64 (-1 = background), geo_occ [n_points] uint8 (inside any box) OUT;
+ *   workspace >= n_boxes * (n_scales + 2) int32.  n_boxes >= 1, centerness_topk + 1 <= n_points.             */
+int sgc_assign_targets(const float *points, const int32_t *scales, const float *boxes, const int64_t *gt_labels,
+                       int rotated, int n_scales, int limit, int centerness_topk, float *centerness_t, float *bbox_t,
+                       int64_t *labels, uint8_t *geo_occ, int32_t *workspace, int n_points, int n_boxes,
+                       sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 9. Upstream of the path: plane-sweep matching cost of DepthNet_Fusion
  * ------------------------------------------------------------------------- */

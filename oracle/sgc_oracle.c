@@ -34,6 +34,8 @@
  *   weighted attn fwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:24-80,240-303
  *   weighted attn bwd CS/common/cuda/wms_deform_attn_cuda_kernel.cuh:82-159,305-419
  *   aligned 3D NMS   packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:131-178
+ *   target assignment mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py:334-343,361-435,485-561
+ *                    (pinned: tests/golden/make_golden_targets.py runs the reference's own get_targets)
  *   rotated BEV NMS  packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:52-68,231-268
  *                    (+ mmcv-full 1.5.3 box_iou_rotated_utils.hpp / nms_rotated_cuda.cuh, published algorithm)
  *   plane sweep      mmdet3d_plugin/models/im2voxel/depth_utils/depth_est_fusion.py:87-126,233-240
@@ -994,6 +996,121 @@ int sgc_nms_rotated_bev(const float *boxes, const int64_t *order, const int32_t 
     n_keep[c] = cnt;
     free(xywhr); free(removed);
   }
+  return SGC_OK;
+}
+
+
+/* ---- 8c. head target assignment: ImVoxelHeadV2.get_targets (imvoxel_head_v2.py:361-435 axis-aligned,
+ * :485-561 rotated) restated with loops over the reference's dense [n_points, n_boxes] tensors -------------- */
+static void target_faces(const float *pt, const float *b, int rotated, float *t /*[6]*/) {
+  if (!rotated) {                                             /* :379-384 */
+    t[0] = pt[0] - b[0] + b[3] / 2; t[1] = b[0] + b[3] / 2 - pt[0];
+    t[2] = pt[1] - b[1] + b[4] / 2; t[3] = b[1] + b[4] / 2 - pt[1];
+    t[4] = pt[2] - b[2] + b[5] / 2; t[5] = b[2] + b[5] / 2 - pt[2];
+    return;
+  }
+  /* :503-515: shift rotated by -yaw about z (rotation_3d_in_axis: x' = x cos + y (-sin), y' = x sin + y cos) */
+  const float sx = pt[0] - b[0], sy = pt[1] - b[1], sz = pt[2] - b[2];
+  const float a = -b[6], sn = sinf(a), cs = cosf(a);
+  const float rx = sx * cs + sy * (-sn), ry = sx * sn + sy * cs;
+  const float cx = b[0] + rx, cy = b[1] + ry, cz = b[2] + sz;
+  t[0] = cx - b[0] + b[3] / 2; t[1] = b[0] + b[3] / 2 - cx;
+  t[2] = cy - b[1] + b[4] / 2; t[3] = b[1] + b[4] / 2 - cy;
+  t[4] = cz - b[2] + b[5] / 2; t[5] = b[2] + b[5] / 2 - cz;
+}
+static float target_centerness(const float *t) {               /* compute_centerness, :334-343 */
+  const float xm = t[0] < t[1] ? t[0] : t[1], xM = t[0] > t[1] ? t[0] : t[1];
+  const float ym = t[2] < t[3] ? t[2] : t[3], yM = t[2] > t[3] ? t[2] : t[3];
+  const float zm = t[4] < t[5] ? t[4] : t[5], zM = t[4] > t[5] ? t[4] : t[5];
+  return sqrtf(xm / xM * ym / yM * zm / zM);
+}
+static int cmp_desc_f32(const void *a, const void *b) {
+  const float x = *(const float *)a, y = *(const float *)b;
+  return x < y ? 1 : (x > y ? -1 : 0);
+}
+int sgc_assign_targets(const float *points, const int32_t *scales, const float *boxes, const int64_t *gt_labels,
+                       int rotated, int n_scales, int limit, int centerness_topk, float *centerness_t, float *bbox_t,
+                       int64_t *labels, uint8_t *geo_occ, int32_t *workspace, int n_points, int n_boxes,
+                       sgc_stream_t stream) {
+  (void)stream; (void)workspace;
+  if (n_points <= 0) return SGC_OK;
+  if (!points || !scales || !centerness_t || !bbox_t || !labels || !geo_occ) return fail(SGC_EINVAL, "null pointer");
+  if (n_boxes <= 0 || !boxes || !gt_labels) return fail(SGC_EINVAL, "get_targets needs at least one box");
+  if (centerness_topk + 1 > n_points) return fail(SGC_EINVAL, "centerness_topk + 1 > n_points");
+  const float float_max = 1e8f;
+  const int bw = rotated ? 7 : 6;
+  int *best = (int *)malloc(sizeof(int) * (size_t)n_boxes);
+  float *top_c = (float *)malloc(sizeof(float) * (size_t)n_boxes);
+  float *col = (float *)malloc(sizeof(float) * (size_t)n_points);
+  if (!best || !top_c || !col) { free(best); free(top_c); free(col); return fail(SGC_EINVAL, "out of memory"); }
+  for (int j = 0; j < n_boxes; ++j) {
+    const float *b = boxes + (int64_t)j * 7;
+    /* condition 2 (:390-407): positive points per scale, best scale of the box */
+    int lower_index = -1, all_upper = 1;
+    int best_val = 0;
+    for (int s = 0; s < n_scales; ++s) {
+      int cnt = 0;
+      for (int i = 0; i < n_points; ++i) {
+        if (scales[i] != s) continue;
+        float t[6];
+        target_faces(points + (int64_t)i * 3, b, rotated, t);
+        float mn = t[0];
+        for (int k = 1; k < 6; ++k) mn = t[k] < mn ? t[k] : mn;
+        cnt += mn > 0;
+      }
+      const int lower = cnt < limit;
+      if (lower) all_upper = 0;
+      const int v = lower * (n_scales - s);                   /* argmax(lower_limit_mask * extra): first maximum */
+      if (s == 0 || v > best_val) { best_val = v; lower_index = s; }
+    }
+    lower_index -= 1;
+    if (lower_index < 0) lower_index = 0;
+    best[j] = all_upper ? n_scales - 1 : lower_index;
+    /* condition 3 (:413-417): (centerness_topk + 1)-th largest masked centerness of the box */
+    for (int i = 0; i < n_points; ++i) {
+      float t[6];
+      target_faces(points + (int64_t)i * 3, b, rotated, t);
+      float mn = t[0];
+      for (int k = 1; k < 6; ++k) mn = t[k] < mn ? t[k] : mn;
+      col[i] = (mn > 0 && scales[i] == best[j]) ? target_centerness(t) : -1.f;
+    }
+    qsort(col, (size_t)n_points, sizeof(float), cmp_desc_f32);
+    top_c[j] = col[centerness_topk];
+  }
+  for (int i = 0; i < n_points; ++i) {
+    const float *pt = points + (int64_t)i * 3;
+    float min_area = 0.f;
+    int arg = 0, any_inside = 0;
+    for (int j = 0; j < n_boxes; ++j) {
+      const float *b = boxes + (int64_t)j * 7;
+      float t[6];
+      target_faces(pt, b, rotated, t);
+      float mn = t[0];
+      for (int k = 1; k < 6; ++k) mn = t[k] < mn ? t[k] : mn;
+      const int inside = mn > 0;
+      any_inside |= inside;
+      float vol = b[3] * b[4] * b[5];
+      if (!inside) vol = float_max;
+      if (scales[i] != best[j]) vol = float_max;
+      const float c = (inside && scales[i] == best[j]) ? target_centerness(t) : -1.f;
+      if (!(c > top_c[j])) vol = float_max;
+      if (j == 0 || vol < min_area) { min_area = vol; arg = j; }       /* volumes.min(dim=1): first minimum */
+    }
+    const float *b = boxes + (int64_t)arg * 7;
+    float t[6];
+    target_faces(pt, b, rotated, t);
+    labels[i] = min_area == float_max ? -1 : gt_labels[arg];
+    centerness_t[i] = target_centerness(t);
+    geo_occ[i] = (uint8_t)any_inside;
+    float *o = bbox_t + (int64_t)i * bw;
+    if (rotated) {
+      for (int k = 0; k < 7; ++k) o[k] = b[k];                /* gt_bboxes[range(n_points), min_area_inds], :561 */
+    } else {                                                  /* _bbox_pred_to_bbox(points, bbox_targets), :456-464 */
+      o[0] = pt[0] - t[0]; o[1] = pt[1] - t[2]; o[2] = pt[2] - t[4];
+      o[3] = pt[0] + t[1]; o[4] = pt[1] + t[3]; o[5] = pt[2] + t[5];
+    }
+  }
+  free(best); free(top_c); free(col);
   return SGC_OK;
 }
 

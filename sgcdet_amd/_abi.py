@@ -34,6 +34,7 @@ SIGNATURES = {
     "sgc_aligned_nms3d": [_p] * 3 + [_f] + [_p] * 3 + [_i] + [_p],
     "sgc_nms_rotated_bev": [_p] * 3 + [_f] + [_p] * 3 + [_i, _i] + [_p],
     "sgc_box_iou_rotated": [_p] * 3 + [_i, _i] + [_p],
+    "sgc_assign_targets": [_p] * 4 + [_i] * 4 + [_p] * 5 + [_i, _i] + [_p],
     "sgc_plane_sweep_corr": [_p] * 5 + [_i] * 6 + [_p],
     "sgc_upsample2x_occ": [_p] * 5 + [_i] * 4 + [_p],
     "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],

@@ -4,8 +4,9 @@ Reference: mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py -- ``ImVoxelHead
 (:42-88, :237-317), ``ScanNetImVoxelHeadV2`` (:346-359, :437-464), ``SunRgbdImVoxelHeadV2``
 (:467-483, :563-613); ``get_points`` from mmdet3d_plugin/models/detectors/utils.py:5-14.
 Parameter names (``centerness_conv``, ``reg_conv``, ``cls_conv``, ``scales.i.scale``) are
-the reference's.  Target assignment and losses (:95-235, :361-435, :485-561) are the
-"next" row f-3 of SURVEY.md section 8 and are not part of this path yet.
+the reference's.  Training side (row f-3 of SURVEY.md section 8): target assignment (:361-435, :485-561) is one
+fused pass on the GPU (``sgc_assign_targets``), ``loss`` / ``forward_train`` (:90-235) follow the reference with the
+losses of ``plugin/losses.py``.
 
 NMS (row f-4): ScanNet's ``aligned_3d_nms`` (mmdet3d, a Python while-loop in the reference) runs on the GPU
 (``sgc_aligned_nms3d``: one mask kernel + one sweep, same keep/drop arithmetic); ARKit's
@@ -19,6 +20,7 @@ from torch import nn
 from .. import ext
 from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
 from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
+from . import losses
 
 
 @torch.no_grad()
@@ -43,13 +45,17 @@ def rotation_3d_in_axis_z(points, angles):
 class ImVoxelHeadV2(nn.Module):
     def __init__(self, n_classes, n_channels, n_reg_outs, n_scales, limit, centerness_topk=-1,
                  loss_centerness=None, loss_bbox=None, loss_cls=None, train_cfg=None, test_cfg=None,
-                 nms_fn=None):
+                 nms_fn=None, loss_bbox_fn=None):
         super().__init__()
         self.n_classes = n_classes
         self.n_scales = n_scales
         self.limit = limit
         self.centerness_topk = centerness_topk
         self.loss_cfgs = dict(loss_centerness=loss_centerness, loss_bbox=loss_bbox, loss_cls=loss_cls)
+        lc = loss_cls or {}                       # reference defaults (:50-62): FocalLoss(gamma 2, alpha .25), weights 1
+        self.focal_gamma, self.focal_alpha = lc.get("gamma", 2.0), lc.get("alpha", 0.25)
+        self.loss_weights = tuple((c or {}).get("loss_weight", 1.0) for c in (loss_centerness, loss_bbox, loss_cls))
+        self.loss_bbox_fn = loss_bbox_fn
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.nms_fn = nms_fn
@@ -142,6 +148,82 @@ class ImVoxelHeadV2(nn.Module):
         boxes, scores = self.decode_candidates(centernesses, bbox_preds, cls_scores, valids, img_meta)
         return self._nms(boxes, scores, img_meta)
 
+    # ---- training side (row f-3): target assignment + losses, imvoxel_head_v2.py:90-235 --------------------
+    rotated_targets = False          # SunRgbdImVoxelHeadV2: boxes with yaw, targets = the assigned gt row
+
+    def forward_train(self, x, valid, img_metas, gt_bboxes, gt_labels):
+        return self.loss(*(self(x) + (valid, img_metas, gt_bboxes, gt_labels)))
+
+    def loss(self, centernesses, bbox_preds, cls_scores, valid, img_metas, gt_bboxes, gt_labels):
+        """-> (dict(loss_centerness, loss_bbox, loss_cls), sem_occ [B, n_points], geo_occ [B, n_points]) (:95-145)."""
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(valid) == len(img_metas) \
+            == len(gt_bboxes) == len(gt_labels)
+        valids = [nn.Upsample(size=x.shape[-3:], mode="trilinear")(valid).round().bool() for x in centernesses]
+        per_img = [self._loss_single([x[i] for x in centernesses], [x[i] for x in bbox_preds], [x[i] for x in cls_scores],
+                                     [x[i] for x in valids], img_metas[i], gt_bboxes[i], gt_labels[i])
+                   for i in range(len(img_metas))]
+        lc, lb, ls, sem, geo = zip(*per_img)
+        return dict(loss_centerness=torch.mean(torch.stack(lc)), loss_bbox=torch.mean(torch.stack(lb)),
+                    loss_cls=torch.mean(torch.stack(ls))), torch.stack(sem), torch.stack(geo)
+
+    @staticmethod
+    def _gt_rows(gt_bboxes, device):
+        """[n_boxes, 7] (gravity centre, dims, yaw) from an mmdet3d box structure or a plain tensor in that layout."""
+        if torch.is_tensor(gt_bboxes):
+            rows = gt_bboxes
+        else:
+            rows = torch.cat((gt_bboxes.gravity_center, gt_bboxes.tensor[:, 3:]), dim=1)
+        if rows.shape[1] == 6:
+            rows = torch.cat((rows, rows.new_zeros(rows.shape[0], 1)), dim=1)
+        return rows.to(device=device, dtype=torch.float32).contiguous()
+
+    @torch.no_grad()
+    def get_targets(self, points, gt_bboxes, gt_labels):
+        """(:361-435 / :485-561) -> centerness_targets [n], bbox_targets [n, 6|7], labels [n] (-1 background),
+        geo_occ_box [n] bool; one fused pass on the GPU (sgc_assign_targets), no [n_points, n_boxes] tensors."""
+        dev = gt_labels.device
+        scales = torch.cat([torch.full((len(p),), i, dtype=torch.int32, device=dev) for i, p in enumerate(points)])
+        pts = torch.cat(points, dim=0).to(device=dev, dtype=torch.float32).contiguous()
+        return ext.ops().assign_targets(pts, scales, self._gt_rows(gt_bboxes, dev), gt_labels.to(torch.int64).contiguous(),
+                                        self.rotated_targets, self.n_scales, self.limit, self.centerness_topk)
+
+    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
+        raise NotImplementedError
+
+    def _loss_single(self, centernesses, bbox_preds, cls_scores, valids, img_meta, gt_bboxes, gt_labels):
+        """(:147-235)."""
+        dev = centernesses[0].device
+        sizes = [f.size()[-3:] for f in centernesses]
+        mlvl_points = self.get_points(sizes, img_meta["lidar2img"]["origin"], dev)
+        ctr_t, box_t, labels, geo_occ = self.get_targets(mlvl_points, gt_bboxes, gt_labels.to(dev))
+        n_reg = bbox_preds[0].shape[0]
+        ctr = torch.cat([c.permute(1, 2, 3, 0).reshape(-1) for c in centernesses])
+        reg = torch.cat([r.permute(1, 2, 3, 0).reshape(-1, n_reg) for r in bbox_preds])
+        cls = torch.cat([c.permute(1, 2, 3, 0).reshape(-1, self.n_classes) for c in cls_scores])
+        val = torch.cat([v.permute(1, 2, 3, 0).reshape(-1) for v in valids])
+        points = torch.cat(mlvl_points)
+        pos_inds = torch.nonzero(torch.logical_and(labels >= 0, val)).reshape(-1)
+        n_pos = torch.tensor(len(pos_inds), dtype=torch.float, device=dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():      # mmdet reduce_mean
+            n_pos = n_pos.clone()
+            torch.distributed.all_reduce(n_pos.div_(torch.distributed.get_world_size()))
+        n_pos = max(float(n_pos), 1.0)
+        if torch.any(val):
+            loss_cls = losses.sigmoid_focal_loss(cls[val], labels[val], gamma=self.focal_gamma, alpha=self.focal_alpha,
+                                                 avg_factor=n_pos)
+        else:
+            loss_cls = cls[val].sum()
+        pos_ctr, pos_reg = ctr[pos_inds], reg[pos_inds]
+        if len(pos_inds) > 0:
+            pos_ctr_t = ctr_t[pos_inds]
+            loss_centerness = losses.sigmoid_bce_loss(pos_ctr, pos_ctr_t, avg_factor=n_pos)
+            loss_bbox = self._loss_bbox(self._bbox_pred_to_bbox(points[pos_inds], pos_reg), box_t[pos_inds], pos_ctr_t,
+                                        pos_ctr_t.sum())
+        else:
+            loss_centerness, loss_bbox = pos_ctr.sum(), pos_reg.sum()
+        wc, wb, wl = self.loss_weights
+        return loss_centerness * wc, loss_bbox * wb, loss_cls * wl, labels, geo_occ
+
     def forward_single(self, x, scale):
         raise NotImplementedError
 
@@ -159,6 +241,9 @@ class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
 
     def _reg_activation(self, reg, scale):
         return torch.exp(scale(reg))
+
+    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
+        return losses.axis_aligned_iou_loss(pred_boxes, target_boxes, weight=weight, avg_factor=avg_factor)   # config :111
 
     def _bbox_pred_to_bbox(self, points, bbox_pred):
         """point -/+ distances -> (x0,y0,z0,x1,y1,z1), :456-464."""
@@ -187,6 +272,14 @@ class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
 
 @HEADS.register_module()
 class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
+    rotated_targets = True
+
+    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
+        if self.loss_bbox_fn is None:
+            raise NotImplementedError("SunRgbdImVoxelHeadV2: the ARKit config's RotatedIoU3DLoss (mmcv diff_iou_rotated_3d) is "
+                                      "not built; pass loss_bbox_fn(pred [n,7], target [n,7], weight, avg_factor)")
+        return self.loss_bbox_fn(pred_boxes, target_boxes, weight, avg_factor)
+
     def forward_single(self, x, scale):
         reg = self.reg_conv(x)
         return self.centerness_conv(x), torch.cat((torch.exp(scale(reg[:, :6])), reg[:, 6:]), dim=1), self.cls_conv(x)

@@ -191,6 +191,17 @@ class SGCDet(nn.Module):
         outs = self._neck_head(volume)
         return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])
 
+    def forward_train_from_features(self, x, img_metas, dpt_dist, gt_bboxes_3d, gt_labels_3d):
+        """SGCDet.forward_train (SGCDet.py:98-114) from the FPN maps on: detection losses of the head and, with
+        ``occ_loss=True``, the occupancy loss of the voxel head against the head's own ``geo_occ`` targets (the 2D
+        head / depth-loss branches belong to the out-of-scope producers)."""
+        volume, valid, occ = self.build_volume_from_features(x, img_metas, dpt_dist)
+        feats = self.neck_3d(volume)
+        losses, sem_occ, geo_occ = self.bbox_head.forward_train(feats, valid.float(), img_metas, gt_bboxes_3d, gt_labels_3d)
+        if self.occ_loss:
+            losses.update(self.voxel_head.occ_loss(occ, sem_occ, geo_occ))
+        return losses
+
     def simple_test_from_features(self, x, img_metas, dpt_dist):
         r = self.forward_features(x, img_metas, dpt_dist)
         return self.bbox_head.get_bboxes(r["centerness"], r["bbox_pred"], r["cls_score"], r["valid"].float(),

@@ -452,6 +452,29 @@ class TensorOps:
         self._call("sgc_box_iou_rotated", a, b, iou, n, m)
         return iou
 
+    def assign_targets(self, points, scales, boxes, gt_labels, rotated, n_scales, limit, centerness_topk):
+        """``ImVoxelHeadV2.get_targets`` (imvoxel_head_v2.py:361-435 / :485-561): points [n,3], scales [n] int32,
+        boxes [n_boxes,7] (gravity centre, dims, yaw), gt_labels [n_boxes] int64 ->
+        (centerness_targets [n], bbox_targets [n,6|7], labels [n] int64, geo_occ_box [n] bool)."""
+        self._check(points=points, scales=scales, boxes=boxes, gt_labels=gt_labels)
+        self._f32(points=points, boxes=boxes)
+        self._i32(scales=scales)
+        self._i64(gt_labels=gt_labels)
+        n, nb = points.shape[0], boxes.shape[0]
+        if points.shape != (n, 3) or scales.shape != (n,) or boxes.shape != (nb, 7) or gt_labels.shape != (nb,):
+            raise RuntimeError("assign_targets: points [n,3], scales [n], boxes [n_boxes,7], gt_labels [n_boxes] expected")
+        if nb == 0:
+            raise RuntimeError("assign_targets: at least one ground-truth box is required (as the reference)")
+        dev = points.device
+        ct = torch.empty(n, dtype=torch.float32, device=dev)
+        bt = torch.empty((n, 7 if rotated else 6), dtype=torch.float32, device=dev)
+        lb = torch.empty(n, dtype=torch.int64, device=dev)
+        occ = torch.empty(n, dtype=torch.uint8, device=dev)
+        ws = torch.empty(nb * (n_scales + 2), dtype=torch.int32, device=dev)
+        self._call("sgc_assign_targets", points, scales, boxes, gt_labels, int(bool(rotated)), int(n_scales), int(limit),
+                   int(centerness_topk), ct, bt, lb, occ, ws, n, nb)
+        return ct, bt, lb, occ.bool()
+
     # ---- 9. upstream: plane-sweep matching cost ------------------------------------------------
     def plane_sweep_corr(self, feat, nbr, rt, depth, H, W):
         """feat [N, H*W, C] channels-last; nbr [N,K] int32; rt [N,K,12]; depth [D] -> corr [N,D,H,W]."""

@@ -314,6 +314,16 @@ def test_rotated_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
         gpu_ops.nms_rotated_bev(torch.zeros(5000, 5).cuda(), torch.zeros(5000, 2).cuda(), 0.0, 0.15)
 
 
+def test_target_assignment_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
+    """row f-3: ImVoxelHeadV2.get_targets as one fused pass (sgc_assign_targets)"""
+    from targets_contract import check_against_oracle, check_targets_golden
+    check_targets_golden(gpu_ops, "cuda")
+    check_against_oracle(gpu_ops, oracle_ops, "cuda")
+    with pytest.raises(Exception):        # the reference cannot assign without boxes either
+        gpu_ops.assign_targets(torch.zeros(30, 3).cuda(), torch.zeros(30, dtype=torch.int32).cuda(), torch.zeros(0, 7).cuda(),
+                               torch.zeros(0, dtype=torch.int64).cuda(), False, 3, 27, 18)
+
+
 def test_camera_stride_of_channels_last_maps(oracle_ops, gpu_ops):
     from count_contract import check_camera_stride
     check_camera_stride(gpu_ops, oracle_ops, "cuda")

@@ -409,6 +409,56 @@ def test_arkit_head_get_bboxes_runs_rotated_multiclass_nms_on_the_gpu(oracle_ops
     assert len(set(labels.tolist())) > 3
 
 
+def test_forward_train_losses_match_cpu_recomputation_with_oracle_targets(oracle_ops):
+    """SGCDet.forward_train from the FPN maps on (SGCDet.py:98-114) for the ScanNet head: the three detection
+    losses and the occupancy loss equal a CPU recomputation from the same head tensors with the ORACLE's target
+    assignment, and every trainable parameter of the path receives a finite gradient."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin import losses as L
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from targets_contract import random_boxes
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(23)
+    cfg = model_config(w)
+    cfg["occ_loss"] = True
+    det = build_detector(cfg).cuda().train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    feats, dpt, meta = make_scene(3, w["embed_dims"], kind="scannet", seed=14, device="cuda")
+    boxes, gl = random_boxes(9, 6, False)
+    boxes[:, :3] *= 0.55                                        # inside the 6.4 x 6.4 x 3.2 m plumbing volume
+    losses = det.forward_train_from_features(feats, [meta], dpt, [boxes.cuda()], [gl.cuda()])
+    assert set(losses) == {"loss_centerness", "loss_bbox", "loss_cls", "loss_occ"}
+    total = sum(losses.values())
+    total.backward()
+    for name, p in det.named_parameters():
+        if p.requires_grad and ("voxel_head" in name or "neck_3d" in name or "bbox_head" in name):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    # CPU recomputation from the head tensors of the same (deterministic) forward
+    with torch.no_grad():
+        volume, valid, occ = det.build_volume_from_features(feats, [meta], dpt)
+        ctr, reg, cls = det.bbox_head(det.neck_3d(volume))
+    head = det.bbox_head
+    pts = head.get_points([c.shape[-3:] for c in ctr], meta["lidar2img"]["origin"], "cpu")
+    scales = torch.cat([torch.full((len(p),), i, dtype=torch.int32) for i, p in enumerate(pts)])
+    P = torch.cat(pts).float().contiguous()
+    ct_t, bx_t, lb, geo = oracle_ops.assign_targets(P, scales, boxes, gl, False, head.n_scales, head.limit, head.centerness_topk)
+    vals = [torch.nn.Upsample(size=c.shape[-3:], mode="trilinear")(valid.float()).round().bool() for c in ctr]
+    flat = lambda ts, k: torch.cat([t[0].permute(1, 2, 3, 0).reshape(-1, k) for t in ts]).cpu()
+    c_, r_, s_, v_ = flat(ctr, 1)[:, 0], flat(reg, 6), flat(cls, head.n_classes), flat(vals, 1)[:, 0]
+    pos = torch.nonzero((lb >= 0) & v_).reshape(-1)
+    assert len(pos) > 10
+    n_pos = float(len(pos))
+    want_cls = L.sigmoid_focal_loss(s_[v_], lb[v_], avg_factor=n_pos)
+    want_ctr = L.sigmoid_bce_loss(c_[pos], ct_t[pos], avg_factor=n_pos)
+    want_box = L.axis_aligned_iou_loss(head._bbox_pred_to_bbox(P[pos], r_[pos]), bx_t[pos], weight=ct_t[pos], avg_factor=ct_t[pos].sum())
+    want_occ = torch.nn.functional.binary_cross_entropy(occ.cpu(), geo[None, :occ.shape[1]].float()) * 0.5
+    for k, want in (("loss_cls", want_cls), ("loss_centerness", want_ctr), ("loss_bbox", want_box), ("loss_occ", want_occ)):
+        assert abs(float(losses[k].detach()) - float(want)) < 2e-4 * max(1.0, abs(float(want))), (k, float(losses[k].detach()), float(want))
+
+
 def test_scene_graph_follows_weight_updates():
     """A parameter changed in place (optimizer step, checkpoint load) must not be served by a stale graph or a stale
     prepared plan: the graph cache is keyed by (address, version) of every parameter / buffer of the path."""

@@ -106,6 +106,11 @@ def test_oracle_rotated_iou_matches_float64_polygon_clip(oracle_ops):
     check_mask_sweep_equals_textbook_loop(oracle_ops, "cpu")
 
 
+def test_oracle_target_assignment_reproduces_reference_get_targets(oracle_ops):
+    from targets_contract import check_targets_golden
+    check_targets_golden(oracle_ops, "cpu")
+
+
 def test_oracle_plane_sweep_reproduces_reference_cost_volume(oracle_ops):
     """tests/golden/plane_sweep.npz: correlation volume of the reference's own homo_warping + cost-volume loop
     (make_golden_planesweep.py) -- the oracle never builds the warped features and agrees to 1e-5."""

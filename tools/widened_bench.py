@@ -83,4 +83,16 @@ pairs = int(((rs > 0).sum(0).double() ** 2 / 2).sum())
 out["nms_rotated_bev"] = dict(candidates_per_class=3000, classes=17, candidates_total=cand, pairs=pairs, kept=int(nk.sum()),
                               sort_mask_sweep_ms=round(t_k * 1e3, 3), with_glue_and_readback_ms=round(t_g * 1e3, 3),
                               note="reference: 17 x (sort + mmcv nms_rotated mask kernel + bit-matrix copy to the host + CPU sweep)")
+# ---- f-3: target assignment of the head at the config-2 point set (29 200 points x 3 scales), 40 boxes ----
+from targets_contract import random_boxes
+d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "head_targets.npz"))
+pts, scl = torch.from_numpy(d["points"]).cuda().contiguous(), torch.from_numpy(d["scales"]).cuda().contiguous()
+out["assign_targets"] = {}
+for rotated in (False, True):
+    tb, tl = random_boxes(40, 3, rotated)
+    tb, tl = tb.cuda(), tl.cuda()
+    t_a, res = timeit(lambda: ops.assign_targets(pts, scl, tb, tl, rotated, 3, 27, 18), 20)
+    out["assign_targets"]["rotated" if rotated else "axis_aligned"] = dict(points=int(pts.shape[0]), boxes=40, hip_ms=round(t_a * 1e3, 3),
+                                                                           positives=int((res[2] >= 0).sum()))
+out["assign_targets"]["note"] = "reference: ~40 torch launches over [n_points, n_boxes(, 6)] tensors (29 200 x 40 x 6 floats = 28 MB each)"
 print(json.dumps(out))
