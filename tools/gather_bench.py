@@ -39,6 +39,17 @@ ZR = os.environ.get("SGC_ZR", "1") == "1"
 dist = torch.randn(N, H * W, D, device=dev).mul(2).softmax(-1).contiguous()
 raw = torch.randn(n_pairs, M * P * 4, device=dev)
 raw[:, :M * P * 2] *= float(os.environ.get("SGC_OFFSET_SCALE", "2.0"))
+if os.environ.get("SGC_OFFSETS") == "ring":   # the reference's init (deformable_cross_attention.py:194-212) + noise, as bench.py's weights
+    import math
+    th = torch.arange(M, dtype=torch.float32) * (2 * math.pi / M)
+    ring = torch.stack([th.cos(), th.sin()], -1)
+    ring = ring / ring.abs().max(-1, keepdim=True)[0]
+    steps = torch.arange(1, P + 1, dtype=torch.float32)
+    uvb = (ring.view(M, 1, 2) * steps.view(1, P, 1)).reshape(-1)
+    dzb = (((th.cos() + th.sin()) / 2).view(M, 1) * steps.view(1, P)).reshape(-1)
+    noise = float(os.environ.get("SGC_RING_NOISE", "0.3"))
+    raw[:, :M * P * 2] = uvb.to(dev) + torch.randn(n_pairs, M * P * 2, device=dev) * noise
+    raw[:, M * P * 2:M * P * 3] = dzb.to(dev) + torch.randn(n_pairs, M * P, device=dev) * noise
 if os.environ.get("SGC_ZERO_DEPTH_OFF"):
     raw[:, M * P * 2:M * P * 3] = 0
 feat = value.view(N, H * W, C)
