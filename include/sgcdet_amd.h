@@ -265,6 +265,14 @@ int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, in
 int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,
                        float *occ_or_null, int ix, int iy, int iz, int C, sgc_stream_t stream);
 
+/* Backward of that x2 trilinear upsample for the training path (the adjoint of F.interpolate(scale_factor=2,
+ * mode='trilinear', align_corners=False), AdaptiveSparseHead.py:64-69) on NCDHW planes, as a gather:
+ *   grad_in [C, X, Y, Z] <- grad_out [C, 2X, 2Y, 2Z]; per axis an input index i collects outputs 2i-1, 2i, 2i+1,
+ *   2i+2 with weights .25, .75, .75, .25 (border outputs 0 and 2n-1 carry weight 1 on their single source).
+ *   torch's upsample_trilinear3d_backward scatters with float atomics (5.2 ms per config-2 step); this reads
+ *   every output 8 times from L2 and writes every input once, bit-reproducibly.                              */
+int sgc_upsample2x_backward(const float *grad_out, float *grad_in, int C, int X, int Y, int Z, sgc_stream_t stream);
+
 /* vol[idx[i], :] += rows[i, :] -- `upsampled_volume + DenseHead(...)` where the dense head's output is zero
  * outside the selected voxels (AdaptiveSparseHead.py:77-82, DenseHead.py:80-81); idx int64, distinct.   */
 int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int n, int C, sgc_stream_t stream);

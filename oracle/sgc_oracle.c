@@ -797,6 +797,50 @@ int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int 
 }
 
 
+/* ---- 7b. adjoint of the x2 trilinear upsample (AdaptiveSparseHead.py:64-69; torch's upsample_trilinear3d index
+ * rule, align_corners = False: src = max(0.5 (o + 0.5) - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, n - 1)), written
+ * as the scatter torch's backward performs; pinned by torch autograd in tests/test_oracle_conv.py ------------- */
+static void up2_src(int o, int n, int *i0, int *i1, float *l0, float *l1) {
+  float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  *i0 = (int)src;
+  *i1 = *i0 + (*i0 < n - 1 ? 1 : 0);
+  *l1 = src - (float)*i0;
+  *l0 = 1.f - *l1;
+}
+int sgc_upsample2x_backward(const float *grad_out, float *grad_in, int C, int X, int Y, int Z, sgc_stream_t stream) {
+  (void)stream;
+  if (C <= 0 || X <= 0 || Y <= 0 || Z <= 0) return SGC_OK;
+  if (!grad_out || !grad_in) return fail(SGC_EINVAL, "null pointer");
+  const int64_t vin = (int64_t)X * Y * Z, vout = vin * 8;
+  memset(grad_in, 0, sizeof(float) * (size_t)(C * vin));
+  for (int c = 0; c < C; ++c)
+    for (int ox = 0; ox < 2 * X; ++ox) {
+      int x0, x1; float a0, a1;
+      up2_src(ox, X, &x0, &x1, &a0, &a1);
+      for (int oy = 0; oy < 2 * Y; ++oy) {
+        int y0, y1; float b0, b1;
+        up2_src(oy, Y, &y0, &y1, &b0, &b1);
+        for (int oz = 0; oz < 2 * Z; ++oz) {
+          int z0, z1; float c0, c1;
+          up2_src(oz, Z, &z0, &z1, &c0, &c1);
+          const float g = grad_out[c * vout + ((int64_t)ox * 2 * Y + oy) * 2 * Z + oz];
+          float *gi = grad_in + c * vin;
+          gi[((int64_t)x0 * Y + y0) * Z + z0] += a0 * b0 * c0 * g;
+          gi[((int64_t)x0 * Y + y0) * Z + z1] += a0 * b0 * c1 * g;
+          gi[((int64_t)x0 * Y + y1) * Z + z0] += a0 * b1 * c0 * g;
+          gi[((int64_t)x0 * Y + y1) * Z + z1] += a0 * b1 * c1 * g;
+          gi[((int64_t)x1 * Y + y0) * Z + z0] += a1 * b0 * c0 * g;
+          gi[((int64_t)x1 * Y + y0) * Z + z1] += a1 * b0 * c1 * g;
+          gi[((int64_t)x1 * Y + y1) * Z + z0] += a1 * b1 * c0 * g;
+          gi[((int64_t)x1 * Y + y1) * Z + z1] += a1 * b1 * c1 * g;
+        }
+      }
+    }
+  return SGC_OK;
+}
+
+
 /* ---- 8. post-processing: mmdet3d aligned_3d_nms (box3d_nms.py:131-178), restated loop for loop -------------- */
 int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *labels, float iou_thr,
                       int64_t *keep, int32_t *n_keep, uint64_t *workspace, int n, sgc_stream_t stream) {

@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgc_assign_targets": [_p] * 4 + [_i] * 4 + [_p] * 5 + [_i, _i] + [_p],
     "sgc_plane_sweep_corr": [_p] * 5 + [_i] * 6 + [_p],
     "sgc_upsample2x_occ": [_p] * 5 + [_i] * 4 + [_p],
+    "sgc_upsample2x_backward": [_p, _p] + [_i] * 4 + [_p],
     "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],
     "sgc_set_tuning": [C.c_char_p, _i],
 }

@@ -20,6 +20,25 @@ from ..mmcv_lite import HEADS, build_head, build_transformer
 from .. import ext
 
 
+class _TrilinearUp2x(torch.autograd.Function):
+    """``F.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)`` (AdaptiveSparseHead.py:64-69) whose
+    backward is a gather (``sgc_upsample2x_backward``) instead of torch's atomic scatter."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ext.ops().upsample2x_backward(grad_out.contiguous().float())
+
+
+def trilinear_up2x(x):
+    if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.dtype == torch.float32:
+        return _TrilinearUp2x.apply(x)
+    return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)
+
+
 def topk_wo_grad(occ_preds_flatten, topk=10):
     """Hard top-k mask, no gradient (AdaptiveSparseHead.py:9-13).  Ties follow torch.topk."""
     _, idx = torch.topk(occ_preds_flatten, k=topk, dim=1)
@@ -166,7 +185,7 @@ class AdaptiveSparseHead(nn.Module):
             if i == 0:
                 volume = self.base_heads[0]([feat], img_meta, mlvl_dpt_dists=[dpt])
                 continue
-            up = F.interpolate(volume, scale_factor=2, mode="trilinear", align_corners=False)
+            up = trilinear_up2x(volume)
             occ = self.occ_pred_heads[i - 1](up.permute(0, 2, 3, 4, 1)).reshape(1, -1)
             occ_preds_list.append(occ)
             mask, idx = None, None

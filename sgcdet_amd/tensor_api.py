@@ -530,6 +530,21 @@ class TensorOps:
         self._call("sgc_upsample2x_occ", vol, w, b, up, occ, ix, iy, iz, Cc)
         return up, occ, (2 * ix, 2 * iy, 2 * iz)
 
+    def upsample2x_backward(self, grad_out):
+        """grad_out [1|none, C, 2X, 2Y, 2Z] (NCDHW, contiguous) -> grad_in [same leading dims, C, X, Y, Z]: the adjoint
+        of ``F.interpolate(scale_factor=2, mode='trilinear', align_corners=False)``."""
+        self._check(grad_out=grad_out)
+        self._f32(grad_out=grad_out)
+        *lead, ox, oy, oz = grad_out.shape
+        if ox % 2 or oy % 2 or oz % 2:
+            raise RuntimeError("upsample2x_backward: even output sizes expected")
+        planes = 1
+        for d in lead:
+            planes *= d
+        gi = torch.empty((*lead, ox // 2, oy // 2, oz // 2), dtype=torch.float32, device=grad_out.device)
+        self._call("sgc_upsample2x_backward", grad_out, gi, planes, ox // 2, oy // 2, oz // 2)
+        return gi
+
     def scatter_add_rows(self, rows, idx, vol):
         self._check(rows=rows, idx=idx, vol=vol)
         self._f32(rows=rows, vol=vol)

@@ -31,3 +31,17 @@ def test_transposed_conv_matches_torch(oracle_ops):
     wt = w.permute(2, 3, 4, 1, 0).reshape(8, 8, 32).contiguous()
     y, og = oracle_ops.conv3d_cl(cl(x), wt, (3, 4, 2), 2, 2, True)
     assert og == (6, 8, 4) and (y - cl(ref)).abs().max() < 1e-5
+
+
+def test_oracle_upsample_backward_is_the_adjoint_torch_autograd_computes(oracle_ops):
+    """sgc_upsample2x_backward restates torch's upsample_trilinear3d backward (align_corners=False, x2): pinned
+    by autograd of F.interpolate itself, odd sizes and size-1 axes included."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    for shape in ((3, 4, 5, 3), (2, 1, 6, 2), (1, 7, 1, 1), (4, 10, 10, 4)):
+        x = torch.randn(1, *shape, generator=g, requires_grad=True)
+        up = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)
+        go = torch.randn(up.shape, generator=g)
+        want, = torch.autograd.grad(up, x, go)
+        got = oracle_ops.upsample2x_backward(go.contiguous())
+        assert got.shape == want.shape and (got - want).abs().max() < 1e-5, shape
