@@ -202,7 +202,12 @@ class SGCDet(nn.Module):
             losses.update(self.voxel_head.occ_loss(occ, sem_occ, geo_occ))
         return losses
 
-    def simple_test_from_features(self, x, img_metas, dpt_dist):
+    def simple_test_from_features(self, x, img_metas, dpt_dist, as_results=False):
+        """SGCDet.simple_test (SGCDet.py:119-129) from the FPN maps on.  ``as_results=True`` returns the reference's
+        ``bbox3d2result`` dicts (mmdet3d core/bbox/transforms.py:50-77: ``boxes_3d`` / ``scores_3d`` / ``labels_3d`` on
+        the CPU), the format ``dataset.evaluate`` / ``indoor_eval`` consume."""
         r = self.forward_features(x, img_metas, dpt_dist)
-        return self.bbox_head.get_bboxes(r["centerness"], r["bbox_pred"], r["cls_score"], r["valid"].float(),
-                                         img_metas)
+        dets = self.bbox_head.get_bboxes(r["centerness"], r["bbox_pred"], r["cls_score"], r["valid"].float(), img_metas)
+        if not as_results:
+            return dets
+        return [dict(boxes_3d=b.to("cpu"), scores_3d=s.cpu(), labels_3d=l.cpu()) for b, s, l in dets]

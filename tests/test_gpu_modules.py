@@ -404,6 +404,9 @@ def test_arkit_head_get_bboxes_runs_rotated_multiclass_nms_on_the_gpu(oracle_ops
                                                 [x[0] for x in r["cls_score"]], [v[0] for v in valids], meta)
     assert cand_b.shape == (350, 7) and cand_s.shape == (350, 17)              # 150 + 150 + all 50 coarse voxels
     wb, ws, wl = box3d_multiclass_nms_rotated(oracle_ops, cand_b.cpu().contiguous(), cand_s.cpu().contiguous(), 0.0, 150, 0.15)
+    res, = det.simple_test_from_features(feats, [meta], dpt, as_results=True)                 # bbox3d2result format
+    assert set(res) == {"boxes_3d", "scores_3d", "labels_3d"} and not res["scores_3d"].is_cuda
+    assert torch.equal(res["scores_3d"], scores.cpu()) and torch.equal(res["labels_3d"], labels.cpu())
     assert boxes.shape == (150, 7)                                   # more than max_num survive over 17 classes: cut
     assert torch.equal(labels.cpu(), wl) and torch.equal(scores.cpu(), ws) and torch.equal(boxes.cpu(), wb)
     assert len(set(labels.tolist())) > 3
