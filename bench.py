@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32"],
                     help="neck/head convolution arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
                          "default) or exact fp32 products on the fp32 MFMA")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU: consecutive steps alternate over this many HIP streams so the host "
                          "syncs / launch gaps of one scene overlap the kernels of the other")
     ap.add_argument("--graph", default="scene", choices=["scene", "tail", "none"],
@@ -87,7 +87,7 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 
 
 def cpu_baseline(w, n_views, seed):
-    """The CPU oracle (port) timed on the host cores on ONE scene of the same workload."""
+    """The CPU oracle (port) timed on the host cores on a bounded sample (~12 s) of scenes of the same workload."""
     import oracle
     from oracle.ref_path import RefPath
     from sgcdet_amd.scene import make_scene, model_config
@@ -112,12 +112,18 @@ def cpu_baseline(w, n_views, seed):
     import torch.nn.functional as F
     dpts = [dpt, F.interpolate(dpt, scale_factor=(1, 0.5, 0.5), mode="nearest"),
             F.interpolate(dpt, scale_factor=(1, 0.25, 0.25), mode="nearest")]
-    t0 = time.perf_counter()
-    vol, valid, occ = rp.adaptive_sparse_head(feats, meta, dpts)
-    rp.head(rp.neck(vol, prefix="neck."), prefix="head.")
+    def one_scene():
+        vol, valid, occ = rp.adaptive_sparse_head(feats, meta, dpts)
+        rp.head(rp.neck(vol, prefix="neck."), prefix="head.")
+    one_scene()                                     # warm-up (thread pools, oneDNN primitive caches)
+    n, t0 = 0, time.perf_counter()
+    while n < 64 and (n < 2 or time.perf_counter() - t0 < 12.0):      # a bounded sample: ~12 s of CPU work
+        one_scene()
+        n += 1
     dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="scenes/sec", cores=cores, kind="port",
-                sample=f"1 scene of {w['name']} ({n_views} views), CPU oracle (OpenMP C kernels + torch-CPU), {dt:.1f} s")
+    return dict(value=n / dt, unit="scenes/sec", cores=cores, kind="port",
+                sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels + "
+                       f"torch-CPU), {dt:.1f} s")
 
 
 def main():
@@ -228,7 +234,7 @@ def main():
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with two other scenes and runs ~3 % longer, see "
-                         "profiles/r01_kernels_from_trace_v9.json)")
+                         "profiles/r01_kernels_from_trace_v10.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
     self_check = None
