@@ -404,7 +404,8 @@ def test_arkit_head_get_bboxes_runs_rotated_multiclass_nms_on_the_gpu(oracle_ops
                                                 [x[0] for x in r["cls_score"]], [v[0] for v in valids], meta)
     assert cand_b.shape == (350, 7) and cand_s.shape == (350, 17)              # 150 + 150 + all 50 coarse voxels
     wb, ws, wl = box3d_multiclass_nms_rotated(oracle_ops, cand_b.cpu().contiguous(), cand_s.cpu().contiguous(), 0.0, 150, 0.15)
-    res, = det.simple_test_from_features(feats, [meta], dpt, as_results=True)                 # bbox3d2result format
+    with torch.no_grad():
+        res, = det.simple_test_from_features(feats, [meta], dpt, as_results=True)             # bbox3d2result format
     assert set(res) == {"boxes_3d", "scores_3d", "labels_3d"} and not res["scores_3d"].is_cuda
     assert torch.equal(res["scores_3d"], scores.cpu()) and torch.equal(res["labels_3d"], labels.cpu())
     assert boxes.shape == (150, 7)                                   # more than max_num survive over 17 classes: cut
@@ -460,6 +461,11 @@ def test_forward_train_losses_match_cpu_recomputation_with_oracle_targets(oracle
     want_occ = torch.nn.functional.binary_cross_entropy(occ.cpu(), geo[None, :occ.shape[1]].float()) * 0.5
     for k, want in (("loss_cls", want_cls), ("loss_centerness", want_ctr), ("loss_bbox", want_box), ("loss_occ", want_occ)):
         assert abs(float(losses[k].detach()) - float(want)) < 2e-4 * max(1.0, abs(float(want))), (k, float(losses[k].detach()), float(want))
+
+
+def test_indoor_eval_with_rotated_boxes_uses_the_gpu_iou():
+    from eval_contract import check_case
+    check_case(1)
 
 
 def test_scene_graph_follows_weight_updates():

@@ -51,3 +51,11 @@ def test_head_losses_follow_their_definitions():
     x, t = torch.randn(50, generator=g), torch.rand(50, generator=g)
     want = -(t * torch.log(x.sigmoid()) + (1 - t) * torch.log(1 - x.sigmoid())).sum() / 12.0
     assert torch.allclose(losses.sigmoid_bce_loss(x, t, avg_factor=12.0), want, rtol=1e-5)
+
+
+def test_indoor_eval_reproduces_the_reference_metrics_on_upright_boxes():
+    """row f-4: AP / recall / result keys of the reference's own indoor_eval (fixture), ScanNet-style boxes (no yaw:
+    the closed-form IoU on the host); the rotated case runs on the GPU (tests/test_gpu_modules.py)."""
+    from eval_contract import check_case
+    check_case(0)
+    check_case(2)
