@@ -275,10 +275,9 @@ class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
     rotated_targets = True
 
     def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
-        if self.loss_bbox_fn is None:
-            raise NotImplementedError("SunRgbdImVoxelHeadV2: the ARKit config's RotatedIoU3DLoss (mmcv diff_iou_rotated_3d) is "
-                                      "not built; pass loss_bbox_fn(pred [n,7], target [n,7], weight, avg_factor)")
-        return self.loss_bbox_fn(pred_boxes, target_boxes, weight, avg_factor)
+        if self.loss_bbox_fn is not None:
+            return self.loss_bbox_fn(pred_boxes, target_boxes, weight, avg_factor)
+        return losses.rotated_iou_3d_loss(pred_boxes, target_boxes, weight=weight, avg_factor=avg_factor)   # ARKit config :114
 
     def forward_single(self, x, scale):
         reg = self.reg_conv(x)

@@ -8,8 +8,13 @@ integer targets, any target outside [0, C) -- the head's -1 background -- is neg
 ``CrossEntropyLoss(use_sigmoid=True)``; mmdet / mmcv are pip dependencies of the reference that are not vendored, so
 these two are UNPINNED against their originals (published formulas; checked against closed forms in the tests).
 Reduction everywhere: ``sum(loss * weight) / avg_factor * loss_weight`` (mmdet ``weight_reduce_loss`` with
-``reduction='mean'`` and an ``avg_factor``).  The ARKit config's ``RotatedIoU3DLoss`` (mmcv ``diff_iou_rotated_3d``)
-is not built.
+``reduction='mean'`` and an ``avg_factor``).  ``rotated_iou_3d_loss`` is the ARKit config's ``RotatedIoU3DLoss``
+(vendored wrapper packages/mmdetection3d/mmdet3d/models/losses/rotated_iou_loss.py:10-26 around mmcv's
+``diff_iou_rotated_3d``, not vendored): 1 - IoU of paired rotated boxes, differentiable through the exact intersection
+polygon.  mmcv collects edge intersections + contained corners and sorts them with a CUDA op; here the rectangle of
+the prediction is clipped against the four edges of the target (Sutherland-Hodgman on a fixed 8-slot polygon, all
+pairs at once in torch), which yields the same polygon and the same gradients almost everywhere.  UNPINNED against
+mmcv; its forward is checked against the float64 polygon clip of the NMS fixture and its gradients by gradcheck.
 """
 import torch
 import torch.nn.functional as F
@@ -61,3 +66,70 @@ def sigmoid_bce_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0
     valid = (target >= 0).float()                      # mmdet's ignore mask; centerness targets are >= 0
     weight = valid if weight is None else weight * valid
     return _reduce(loss, weight, avg_factor, loss_weight)
+
+
+def _rect_corners(x, y, w, h, a):
+    """[n] each -> [n,4,2] counter-clockwise corners of rectangles centred (x, y), size (w, h), rotated by a."""
+    c, s_ = torch.cos(a), torch.sin(a)
+    dx = torch.stack((-w, w, w, -w), -1) * 0.5
+    dy = torch.stack((-h, -h, h, h), -1) * 0.5
+    return torch.stack((x[:, None] + dx * c[:, None] - dy * s_[:, None], y[:, None] + dx * s_[:, None] + dy * c[:, None]), -1)
+
+
+def _clip_convex(poly, valid, a, b):
+    """One Sutherland-Hodgman step for n polygons at once.  poly [n,K,2] with the first ``count`` slots live
+    (valid [n,K] bool, a prefix), clipped against the half plane left of a -> b ([n,2] each); returns a polygon in
+    2K slots' worth of candidates packed back into K slots (a convex polygon cut by a line gains at most one vertex;
+    K = 8 holds a rectangle clipped four times)."""
+    n, K, _ = poly.shape
+    count = valid.sum(1, keepdim=True)                                       # [n,1]
+    idx = torch.arange(K, device=poly.device)[None]
+    nxt = torch.where(idx + 1 < count, idx + 1, torch.zeros_like(idx))       # successor inside the live prefix
+    q = torch.gather(poly, 1, nxt[..., None].expand(-1, -1, 2))
+    e = (b - a)[:, None]                                                      # [n,1,2]
+    sp = e[..., 0] * (poly[..., 1] - a[:, None, 1]) - e[..., 1] * (poly[..., 0] - a[:, None, 0])
+    sq = e[..., 0] * (q[..., 1] - a[:, None, 1]) - e[..., 1] * (q[..., 0] - a[:, None, 0])
+    p_in, q_in = sp >= 0, sq >= 0
+    denom = sp - sq
+    t = sp / torch.where(denom == 0, torch.ones_like(denom), denom)
+    cross = poly + t[..., None] * (q - poly)
+    keep_p = valid & p_in                                                     # emit p
+    keep_x = valid & (p_in != q_in)                                           # emit the crossing after p
+    cand = torch.stack((poly, cross), 2).reshape(n, 2 * K, 2)                # p0, x0, p1, x1, ...
+    cmask = torch.stack((keep_p, keep_x), 2).reshape(n, 2 * K)
+    order = torch.sort((~cmask).to(torch.int8), dim=1, stable=True)[1][:, :K]     # live candidates first, in order
+    out = torch.gather(cand, 1, order[..., None].expand(-1, -1, 2))
+    return out, torch.gather(cmask, 1, order)
+
+
+def rotated_bev_intersection(b1, b2):
+    """[n,5] (x, y, w, h, angle) x2 -> [n] area of the intersection of paired rotated rectangles (differentiable)."""
+    n = b1.shape[0]
+    c1 = _rect_corners(b1[:, 0], b1[:, 1], b1[:, 2], b1[:, 3], b1[:, 4])
+    c2 = _rect_corners(b2[:, 0], b2[:, 1], b2[:, 2], b2[:, 3], b2[:, 4])
+    poly = torch.cat((c1, c1.new_zeros(n, 4, 2)), 1)
+    valid = torch.arange(8, device=b1.device)[None].expand(n, 8) < 4
+    for k in range(4):
+        poly, valid = _clip_convex(poly, valid, c2[:, k], c2[:, (k + 1) % 4])
+    count = valid.sum(1, keepdim=True)
+    idx = torch.arange(8, device=b1.device)[None]
+    nxt = torch.where(idx + 1 < count, idx + 1, torch.zeros_like(idx))
+    q = torch.gather(poly, 1, nxt[..., None].expand(-1, -1, 2))
+    cross = (poly[..., 0] * q[..., 1] - poly[..., 1] * q[..., 0]) * valid
+    return 0.5 * cross.sum(1).abs()
+
+
+def rotated_iou_3d(pred, target):
+    """paired boxes [n,7] (x, y, z, w, l, h, alpha), gravity centre -> [n] IoU (mmcv diff_iou_rotated_3d)."""
+    inter2d = rotated_bev_intersection(pred[:, [0, 1, 3, 4, 6]], target[:, [0, 1, 3, 4, 6]])
+    zmax = torch.min(pred[:, 2] + pred[:, 5] / 2, target[:, 2] + target[:, 5] / 2)
+    zmin = torch.max(pred[:, 2] - pred[:, 5] / 2, target[:, 2] - target[:, 5] / 2)
+    inter = inter2d * (zmax - zmin).clamp(min=0)
+    vol = pred[:, 3] * pred[:, 4] * pred[:, 5] + target[:, 3] * target[:, 4] * target[:, 5]
+    return inter / (vol - inter)
+
+
+def rotated_iou_3d_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0):
+    if weight is not None and not torch.any(weight > 0):
+        return pred.sum() * 0
+    return _reduce(1 - rotated_iou_3d(pred, target), weight, avg_factor, loss_weight)

@@ -468,6 +468,48 @@ def test_indoor_eval_with_rotated_boxes_uses_the_gpu_iou():
     check_case(1)
 
 
+def test_arkit_forward_train_uses_rotated_targets_and_rotated_iou_loss(oracle_ops):
+    """The ARKit head's training step (rotated target assignment + RotatedIoU3DLoss): finite losses and gradients,
+    loss_bbox equal to a CPU recomputation from the same head tensors with the oracle's targets."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin import losses as L
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from targets_contract import random_boxes
+    w = workload("cfg1_plumbing")
+    w.update(kind="arkit", head="SunRgbdImVoxelHeadV2", n_classes=17, n_reg_outs=7)
+    torch.manual_seed(29)
+    det = build_detector(model_config(w)).cuda().train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    feats, dpt, meta = make_scene(3, w["embed_dims"], kind="arkit", seed=15, device="cuda")
+    boxes, gl = random_boxes(8, 9, True)
+    boxes[:, :3] *= 0.5
+    gl = gl % 17
+    losses = det.forward_train_from_features(feats, [meta], dpt, [boxes.cuda()], [gl.cuda()])
+    assert set(losses) == {"loss_centerness", "loss_bbox", "loss_cls"}
+    sum(losses.values()).backward()
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in det.parameters())
+    assert det.bbox_head.reg_conv.weight.grad.abs().sum() > 0
+    with torch.no_grad():
+        volume, valid, occ = det.build_volume_from_features(feats, [meta], dpt)
+        ctr, reg, cls = det.bbox_head(det.neck_3d(volume))
+    head = det.bbox_head
+    pts = head.get_points([c.shape[-3:] for c in ctr], meta["lidar2img"]["origin"], "cpu")
+    scales = torch.cat([torch.full((len(p),), i, dtype=torch.int32) for i, p in enumerate(pts)])
+    P = torch.cat(pts).float().contiguous()
+    ct_t, bx_t, lb, geo = oracle_ops.assign_targets(P, scales, boxes, gl, True, head.n_scales, head.limit, head.centerness_topk)
+    vals = [torch.nn.Upsample(size=c.shape[-3:], mode="trilinear")(valid.float()).round().bool() for c in ctr]
+    flat = lambda ts, k: torch.cat([t[0].permute(1, 2, 3, 0).reshape(-1, k) for t in ts]).cpu()
+    r_, v_ = flat(reg, 7), flat(vals, 1)[:, 0]
+    pos = torch.nonzero((lb >= 0) & v_).reshape(-1)
+    assert len(pos) > 10
+    want = L.rotated_iou_3d_loss(head._bbox_pred_to_bbox(P[pos], r_[pos]), bx_t[pos], weight=ct_t[pos], avg_factor=ct_t[pos].sum())
+    assert abs(float(losses["loss_bbox"].detach()) - float(want)) < 5e-4, (float(losses["loss_bbox"].detach()), float(want))
+
+
 def test_scene_graph_follows_weight_updates():
     """A parameter changed in place (optimizer step, checkpoint load) must not be served by a stale graph or a stale
     prepared plan: the graph cache is keyed by (address, version) of every parameter / buffer of the path."""
