@@ -3,6 +3,10 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sgcdet_amd import ext
 ops = ext.ops()
+if os.environ.get("SGC_DIAG_LIB"):      # diagnostic builds (tools/diag): timing only
+    from sgcdet_amd._abi import Library
+    from sgcdet_amd.tensor_api import TensorOps
+    ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
 layers = [  # name, Cin, Cout, grid, k, s, transposed
  ("down0.conv 256->256 @40x40x16", 256,256,(40,40,16),3,1,False),
  ("out0 256->128 @40x40x16", 256,128,(40,40,16),3,1,False),
