@@ -791,6 +791,10 @@ static int zero_fill(float *y, int64_t n, hipStream_t st) {      // n floats, n 
 }
 
 // channel-chunk splits of the halo kernel: enough workgroups for 3/4 of the CUs, and no empty split
+// (An XCD-aware tile order for the implicit-GEMM kernel -- 1-D launch decoded so that the n-blocks of an m tile, or the
+//  m-blocks sharing a weight tile, run back to back on ONE XCD and its L2 serves the repeats -- was measured on the
+//  Linears and on the 400-voxel 1024-channel layers: no change (162 vs 165 us, 140 vs 141 us).  The repeats are
+//  served by the memory-side cache either way; the limiter is the load -> LDS -> MFMA latency chain, section 4.5.)
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;
