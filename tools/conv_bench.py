@@ -7,8 +7,6 @@ if os.environ.get("SGC_DIAG_LIB"):      # diagnostic builds (tools/diag): timing
     from sgcdet_amd._abi import Library
     from sgcdet_amd.tensor_api import TensorOps
     ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
-if os.environ.get("SGC_REMAP"):
-    ops.lib.call("sgc_set_tuning", b"conv_remap", int(os.environ["SGC_REMAP"]))
 layers = [  # name, Cin, Cout, grid, k, s, transposed
  ("down0.conv 256->256 @40x40x16", 256,256,(40,40,16),3,1,False),
  ("out0 256->128 @40x40x16", 256,128,(40,40,16),3,1,False),

@@ -6,8 +6,6 @@ if os.environ.get("SGC_DIAG_LIB"):      # diagnostic builds (tools/diag): timing
     from sgcdet_amd._abi import Library
     from sgcdet_amd.tensor_api import TensorOps
     ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
-if os.environ.get("SGC_REMAP"):
-    ops.lib.call("sgc_set_tuning", b"conv_remap", int(os.environ["SGC_REMAP"]))
 for rows, cin, cout in [(188800, 256, 256), (77000, 256, 128), (77000, 256, 512), (6400, 256, 256), (6400, 512, 256)]:
     x = torch.randn(rows, cin, device="cuda"); wt = torch.randn(1, cout, cin, device="cuda") * 0.05
     sh = torch.randn(cout, device="cuda"); wh, wl = ops.split_bf16(wt)
