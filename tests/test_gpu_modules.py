@@ -125,6 +125,35 @@ def test_hot_path_against_oracle(name, n_views):
         assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
 
 
+def test_full_size_config2_scene_against_the_oracle():
+    """BASELINE.json configs[1] at its full size -- 40 views x 256 ch, 64x80 / 32x40 / 16x20 maps, 40x40x16 voxels,
+    top-k [800, 6400] -- GPU vs the CPU oracle (its OpenMP build: same arithmetic, outputs parallelised): selected
+    voxel sets bit-exact up to near ties at the cut, voxel features and occupancy within 1e-3."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from oracle.ref_path import RefPath
+    from oracle.compare import check_sparse_head
+    w = workload("cfg2_scannet")
+    torch.manual_seed(17)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for n, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.02)
+    feats, dpt, meta = make_scene(40, w["embed_dims"], kind="scannet", seed=25, img_hw=(256, 320))
+    rp = RefPath(det.voxel_head.state_dict(), dict(embed_dims=w["embed_dims"], n_voxels_list=w["n_voxels_list"],
+                                                   voxel_size_list=w["voxel_size_list"], topk_list=w["topk_list"],
+                                                   dbound=(0.2, 5.0), num_heads=8, num_points=4), omp=True)
+    vol_c, valid_c, occ_c = rp.adaptive_sparse_head(feats, meta, depth_pyramid(dpt))
+    det = det.cuda()
+    with torch.no_grad():
+        r = det.forward_features([f.cuda() for f in feats], [meta], dpt.cuda())
+    res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, 40 * 40 * 16, w["topk_list"])
+    assert res["tie_flips"] <= 8, res
+    assert int(r["valid"].sum()) == 6400
+
+
 def test_training_path_gradients_match_oracle_backward():
     """autograd through the HIP forward/backward Function == oracle backward (a11b)."""
     from sgcdet_amd.functions import MultiScale3DDeformableAttnFunction_fp32 as Fn
