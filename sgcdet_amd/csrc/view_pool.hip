@@ -295,12 +295,50 @@ extern "C" int sgc_scatter_rows(const float *rows, const int32_t *idx, const int
   return check_launch("scatter_rows_kernel");
 }
 
+namespace sgc {
+// The same through a 64 x 64 tile with 16-byte accesses on both sides (C % 64 == 0, W, Ws % 4 == 0, 16-byte aligned
+// pointers: the feature maps): a float4 covers 4 pixels of one row on the way in and 4 channels of one pixel on the
+// way out; tile[c][px] with a 65-float pitch keeps both LDS phases conflict-free.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel64(const float *__restrict__ src, float *__restrict__ dst,
+                                                             int C, int Hs, int Ws, int H, int W) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int HW = H * W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int c = e >> 4, q = e & 15;
+    const int px = p0 + q * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (px < HW) {                                   // HW % 4 == 0: a group is in or out as a whole
+      const int h = px / W, w = px - h * W;
+      v = *reinterpret_cast<const float4 *>(src + (((int64_t)n * C + c0 + c) * Hs + h) * Ws + w);
+    }
+    tile[c][q * 4] = v.x; tile[c][q * 4 + 1] = v.y; tile[c][q * 4 + 2] = v.z; tile[c][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const int px = e >> 4, g = e & 15;
+    if (p0 + px < HW)
+      *reinterpret_cast<float4 *>(dst + ((int64_t)n * HW + p0 + px) * C + c0 + g * 4) =
+          make_float4(tile[g * 4][px], tile[g * 4 + 1][px], tile[g * 4 + 2][px], tile[g * 4 + 3][px]);
+  }
+}
+}  // namespace sgc
+
 extern "C" int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
                                      int H, int W, sgc_stream_t stream) {
   if (!src || !dst) return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: null pointer");
   if (H > Hs || W > Ws || N <= 0 || C <= 0 || H <= 0 || W <= 0)
     return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: bad sizes");
   if (N > 65535) return set_error(SGC_EUNSUP, "sgc_nchw_to_nhwc_crop: N > 65535");
+  if (C % 64 == 0 && W % 4 == 0 && Ws % 4 == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel64, dim3(ceil_div(H * W, 64), C / 64, N), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, C, Hs, Ws, H, W);
+    return check_launch("nchw_to_nhwc_kernel64");
+  }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, Hs, Ws, H, W);
   return check_launch("nchw_to_nhwc_kernel");

@@ -204,6 +204,10 @@ def test_pair_list_gathers_and_view_pool(C, M, P, HW, oracle_ops, gpu_ops):
     close(vol_g, vol_c)
     src = torch.randn(N, C, H + 1, W + 3, generator=g)
     assert torch.equal(gpu_ops.nchw_to_nhwc_crop(cu(src), H, W).cpu(), oracle_ops.nchw_to_nhwc_crop(src, H, W))
+    # the 64 x 64 / 16-byte form (C % 64 == 0, W and the source pitch % 4 == 0): crops, partial pixel tiles, two channel tiles
+    for n_, c_, hs, ws, h_, w_ in ((2, 64, 9, 12, 7, 8), (3, 128, 15, 20, 14, 20), (1, 256, 64, 80, 64, 80), (2, 64, 5, 8, 5, 4)):
+        src = torch.randn(n_, c_, hs, ws, generator=g)
+        assert torch.equal(gpu_ops.nchw_to_nhwc_crop(cu(src), h_, w_).cpu(), oracle_ops.nchw_to_nhwc_crop(src, h_, w_)), (c_, h_, w_)
 
 
 def test_errors_are_raised_not_printed(gpu_ops):
