@@ -634,7 +634,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   __syncthreads();
   // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
   // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
-  // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no)
+  // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
+  //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
   bf16x8 ah_n[2], al_n[2];
   auto read_A0 = [&](int tap) {
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
