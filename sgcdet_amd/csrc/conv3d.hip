@@ -795,7 +795,12 @@ static int zero_fill(float *y, int64_t n, hipStream_t st) {      // n floats, n 
 // (An XCD-aware tile order for the implicit-GEMM kernel -- 1-D launch decoded so that the n-blocks of an m tile, or the
 //  m-blocks sharing a weight tile, run back to back on ONE XCD and its L2 serves the repeats -- was measured on the
 //  Linears and on the 400-voxel 1024-channel layers: no change (162 vs 165 us, 140 vs 141 us).  The repeats are
-//  served by the memory-side cache either way; the limiter is the load -> LDS -> MFMA latency chain, section 4.5.)
+//  served by the memory-side cache either way; the limiter is the load -> LDS -> MFMA latency chain, section 4.5.
+//  A BK = 64 single-LDS-buffer form of the same kernel -- twice the bytes per thread in flight at the same LDS
+//  footprint and occupancy, two barriers per step, half the steps -- was built and is correct but slower where it
+//  matters: 203 vs 164 us on the 188,800-row Linear, 168 vs 140 us on the 400-voxel 1024-channel layer; it only wins
+//  on the 6,400-row Linears (16 vs 20 us).  The exposed regs -> LDS phase between its two barriers costs more than
+//  the deeper loads hide.)
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;
