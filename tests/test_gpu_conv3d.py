@@ -22,6 +22,7 @@ CASES = [  # Cin, Cout, grid, ksize, stride, transposed, residual, relu
     (32, 64, (24, 24, 4), 3, 1, False, False, True),      # bricks 8x8x4
     (64, 192, (17, 13, 16), 3, 1, False, True, True),     # partial bricks in x and y, Cout % 128 != 0
     (32, 256, (40, 40, 16), 3, 1, False, True, True),     # config-2 volume, 200 workgroups, no split-K
+    (128, 28, (20, 20, 8), 3, 1, False, False, False),    # the head's fused centerness/reg/cls conv: 28 of 128 tile columns live
 ]
 
 
