@@ -31,6 +31,7 @@
 namespace sgc {
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
+int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
 
@@ -980,7 +981,7 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
-  if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= 2048) {
+  if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
     if (p.gz >= 16) rc = launch_halo<4, 4, 16>(p, OV, st);
     else if (p.gz >= 8) rc = launch_halo<4, 8, 8>(p, OV, st);
     else rc = launch_halo<8, 8, 4>(p, OV, st);
@@ -1036,7 +1037,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
   }
   const int64_t OV = (int64_t)ox * oy * oz, M = (int64_t)gx * gy * gz;
   int splitk = 1;
-  if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && M >= 2048) {
+  if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && M >= g_tune_halo_min_m) {
     const int bx = gz >= 16 ? 4 : (gz >= 8 ? 4 : 8), by = gz >= 16 ? 4 : 8, bz = gz >= 16 ? 16 : (gz >= 8 ? 8 : 4);
     splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, 128), Cin / BK);
   } else {
