@@ -31,6 +31,7 @@
 namespace sgc {
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
+int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -982,8 +983,8 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
-    if (p.gz >= 16) rc = launch_halo<4, 4, 16>(p, OV, st);
-    else if (p.gz >= 8) rc = launch_halo<4, 8, 8>(p, OV, st);
+    if (p.gz >= 16 && g_tune_halo_brick == 0) rc = launch_halo<4, 4, 16>(p, OV, st);
+    else if (p.gz >= 8 && g_tune_halo_brick != 2) rc = launch_halo<4, 8, 8>(p, OV, st);
     else rc = launch_halo<8, 8, 4>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);

@@ -7,6 +7,8 @@ if os.environ.get("SGC_DIAG_LIB"):      # diagnostic builds (tools/diag): timing
     from sgcdet_amd._abi import Library
     from sgcdet_amd.tensor_api import TensorOps
     ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
+if os.environ.get("SGC_HALO_BRICK"):
+    ops.lib.call("sgc_set_tuning", b"halo_brick", int(os.environ["SGC_HALO_BRICK"]))
 if os.environ.get("SGC_HALO_MIN_M"):
     ops.lib.call("sgc_set_tuning", b"halo_min_m", int(os.environ["SGC_HALO_MIN_M"]))
 if os.environ.get("SGC_HALO_MIN"):
