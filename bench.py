@@ -234,7 +234,7 @@ def main():
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with two other scenes and runs ~3 % longer, see "
-                         "profiles/r01_kernels_from_trace_v11.json)")
+                         "profiles/r01_kernels_from_trace_v12.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
     self_check = None
