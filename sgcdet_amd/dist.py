@@ -91,3 +91,79 @@ class BucketedGradAllReduce:
                 else:
                     p.grad.copy_(g)
                 off += n
+
+
+class OverlappedGradAllReduce:
+    """The same averaging, started DURING the backward pass (one gradient exchange per step over
+    RCCL, overlapped with the neck's backward).  Parameters are bucketed in reverse registration order -- the order
+    their gradients become ready in; a post-accumulate hook counts a bucket's gradients in and launches its
+    asynchronous all-reduce the moment the last one lands, so the exchange of the head / neck gradients runs under
+    the view transform's backward.  ``finish()`` (after ``loss.backward()``) flushes buckets whose parameters got no
+    gradient this step (zeros, as DDP with ``find_unused_parameters=True``), waits, and writes the means back.
+
+        sync = OverlappedGradAllReduce(model.parameters())
+        for batch in data:
+            loss(model, batch).backward()
+            sync.finish()
+            optimizer.step(); optimizer.zero_grad(set_to_none=True)
+    """
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad][::-1]
+        self.buckets, cur, size = [], [], 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
+        self._ready = [0] * len(self.buckets)
+        self._pending = {}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _launch(self, b):
+        bucket = self.buckets[b]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        self._pending[b] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _on_grad(self, p):
+        if not self._active():
+            return
+        b = self._bucket_of[id(p)]
+        self._ready[b] += 1
+        if self._ready[b] == len(self.buckets[b]) and b not in self._pending:
+            self._launch(b)
+
+    def finish(self):
+        if not self._active():
+            return
+        world = dist.get_world_size()
+        for b in range(len(self.buckets)):
+            if b not in self._pending:              # some parameter of the bucket had no gradient this step
+                self._launch(b)
+        for b, (flat, work) in sorted(self._pending.items()):
+            work.wait()
+            flat.div_(world)
+            off = 0
+            for p in self.buckets[b]:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self._pending.clear()
+        self._ready = [0] * len(self.buckets)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -37,8 +37,22 @@ def _worker(rank, world, port, out):
     loss.backward()
     sd.BucketedGradAllReduce(neck.parameters(), bucket_bytes=1 << 12)()
     grads = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
+    # the overlapped form (hooks fire during backward, finish() after it) on a fresh copy, one parameter left unused
+    torch.manual_seed(0)
+    neck2 = FastIndoorImVoxelNeck(in_channels=8, n_blocks=[1, 1, 1], out_channels=4).train()
+    unused = torch.nn.Parameter(torch.ones(3))
+    sync = sd.OverlappedGradAllReduce(list(neck2.parameters()) + [unused], bucket_bytes=1 << 12)
+    assert len(sync.buckets) > 3
+    for step in range(2):                           # twice: the bookkeeping resets between steps
+        for p in neck2.parameters():
+            p.grad = None
+        sum(o.square().mean() for o in neck2(scenes[rank])).backward()
+        sync.finish()
+    grads2 = torch.cat([p.grad.reshape(-1) for p in neck2.parameters()])
+    assert unused.grad is not None and float(unused.grad.abs().sum()) == 0.0
+    sync.remove()
     if rank == 0:
-        torch.save(dict(mine=mine, slowest=slowest, grads=grads), out)
+        torch.save(dict(mine=mine, slowest=slowest, grads=grads, grads2=grads2), out)
     else:
         torch.save(dict(mine=mine), out + ".1")
     dist.barrier()
@@ -63,3 +77,4 @@ def test_two_rank_gloo_sharding_and_grad_allreduce(tmp_path):
         ref.append(torch.cat([p.grad.reshape(-1) for p in neck.parameters()]))
     want = (ref[0] + ref[1]) / 2
     assert torch.allclose(r0["grads"], want, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(r0["grads2"], want, rtol=1e-5, atol=1e-7)        # OverlappedGradAllReduce: same means
