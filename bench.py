@@ -233,7 +233,7 @@ def main():
         det.scene_graph, det.use_graph = True, tail_graph
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
-                         "events; inside it the kernel shares the chip with two other scenes and runs ~3 % longer, see "
+                         "events; inside it the kernel shares the chip with the other scenes in flight and runs 0-3 % longer, see "
                          "profiles/r01_kernels_from_trace_v12.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
@@ -249,28 +249,31 @@ def main():
                                [t.clone() for t in r["centerness"] + r["bbox_pred"] + r["cls_score"]]))
         torch.cuda.synchronize()
         det.use_graph, det.scene_graph = graph_was
-        runs = []
-        for i in range(10 * n_scenes):
+        # every run is compared on its own stream, right behind the replay that produced it (no host sync, nothing
+        # kept): per run one device-side flag and the largest deviations; SGC_SELF_CHECK_RUNS lengthens the check
+        n_runs = int(os.environ.get("SGC_SELF_CHECK_RUNS", 10 * n_scenes))
+        flags = torch.zeros(n_runs, dtype=torch.int32, device=device)
+        devs = torch.zeros((n_runs, 2), dtype=torch.float32, device=device)
+        for i in range(n_runs):
             r = step(i)
+            ref = serial[i % n_scenes]
             with torch.cuda.stream(streams[i % len(streams)] if streams else torch.cuda.current_stream()):
-                runs.append((i, dict(volume=r["volume"].clone(), occ=r["occ"].clone(), valid=r["valid"].clone(),
-                                     heads=[t.clone() for t in r["centerness"] + r["bbox_pred"] + r["cls_score"]])))
+                heads = r["centerness"] + r["bbox_pred"] + r["cls_score"]
+                ne = (r["volume"] != ref[0]).any() | (r["occ"] != ref[1]).any()
+                hrel = torch.zeros((), device=device)
+                for a_, b_ in zip(heads, ref[2]):
+                    ne = ne | (a_ != b_).any()
+                    hrel = torch.maximum(hrel, (a_ - b_).abs().max() / b_.abs().max().clamp(min=1.0))
+                flags[i] = ne.to(torch.int32)
+                devs[i, 0] = (r["volume"] - ref[0]).abs().max()
+                devs[i, 1] = hrel
         torch.cuda.synchronize()
-        bad = [i for i, r in runs if not (torch.equal(r["volume"], serial[i % n_scenes][0])
-                                           and torch.equal(r["occ"], serial[i % n_scenes][1])
-                                           and all(torch.equal(a, b) for a, b in zip(r["heads"], serial[i % n_scenes][2])))]
-        worst = max([float((r["volume"] - serial[i % n_scenes][0]).abs().max()) for i, r in runs] + [0.0])
-        head_rel = max(float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
-                       for i, r in runs for a, b in zip(r["heads"], serial[i % n_scenes][2]))
-        self_check = dict(scene_runs=len(runs), mismatching=len(bad), max_abs_diff=worst, head_max_rel_diff=head_rel,
-                          compared="volume, occupancy and all head tensors bit-exact (torch.equal) vs serial eager launches")
+        bad = torch.nonzero(flags).reshape(-1).tolist()
+        self_check = dict(scene_runs=n_runs, mismatching=len(bad), max_abs_diff=float(devs[:, 0].max()),
+                          head_max_rel_diff=float(devs[:, 1].max()),
+                          compared="volume, occupancy and all head tensors bit-exact (elementwise ==) vs serial eager launches")
         if os.environ.get("SGC_BENCH_DEBUG"):
             print("self-check mismatching runs:", bad, file=sys.stderr)
-            for i, r in runs[:6]:
-                print(i, float((r["volume"] - serial[i % n_scenes][0]).abs().max()),
-                      float((r["occ"] - serial[i % n_scenes][1]).abs().max()),
-                      int((r["valid"] != 0).sum()), file=sys.stderr)
-        del runs
 
     # ---- roofline of the dominant hand-written kernel: finest-level deformable gather ----
     per_kernel = {}
