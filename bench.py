@@ -13,8 +13,12 @@ tensors.  Default workload = BASELINE.json configs[1]: 40 views x 256 ch, 40x40x
 Multi-GPU: scenes are independent (batch size is 1 scene per GPU in the reference too), so
 ranks shard scenes with NO data-path collective; scaling is weak (one scene per rank per
 step).  Rank 0 prints ONE JSON line; ``roofline`` is for the deformable-gather kernel at the
-finest level (HIP-event timed inside the timed region), ``cpu_baseline`` is the CPU oracle
-(a port: the reference has no CPU implementation of this path) on the host cores.
+finest level, timed with HIP events on its launch stream (with the default whole-scene hipGraph
+replay the events bracket the same kernel in an eager pass over the same scenes right after the
+timed region -- ``roofline.measured`` says which), ``roofline_mfma`` for the 90-GFLOP convolution,
+``cpu_baseline`` is the CPU oracle (a port: the reference has no CPU implementation of this path)
+on a bounded sample on the host cores, ``self_check`` re-runs the scenes-in-flight configuration
+against serial eager launches bit for bit.
 """
 import argparse
 import json
