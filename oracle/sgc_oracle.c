@@ -435,7 +435,8 @@ int sgc_project_points(const float *ref3d, const float *origin, const float *pro
       const float zn = (cam[2] - d_near) * rd;
       float *o = ref_cam + ((int64_t)n * Nq + q) * 3;
       o[0] = u; o[1] = v; o[2] = zn;
-      mask[(int64_t)n * Nq + q] = (uint8_t)(cam[2] > eps && u > eps && u < hi && v > eps && v < hi);
+      /* `points_d` aliases reference_points_cam[..., 2:3], overwritten with zn before the test (TU/encoder.py:203-213) */
+      mask[(int64_t)n * Nq + q] = (uint8_t)(zn > eps && u > eps && u < hi && v > eps && v < hi);
     }
   }
   return SGC_OK;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/sgcdet_amd.h"
 
 namespace sgc {
@@ -20,6 +22,18 @@ inline int check_launch(const char *what) {
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: `done` is a bitmask over device ordinals
+// (one static per call site), so a process that drives several GPUs sets it once on each of them; thread-safe
+// (setting it twice is harmless, the mask only saves the driver call on the hot path).
+inline void ensure_dynamic_lds(const void *fn, int bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 // XCD-aware, bijective block -> tile map: the blocks that share an XCD (equal
 // blockIdx % 8 under round-robin dispatch) walk one contiguous chunk of the tile

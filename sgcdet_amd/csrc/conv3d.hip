@@ -816,11 +816,8 @@ template <int BX, int BY, int BZ>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
   const size_t smem = halo_tab_offset(LROWS) + 256 * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, 128);
   const int nchunks = p.Cin / BK;
@@ -953,11 +950,8 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   if (narrow) {
     hipLaunchKernelGGL((conv3d_igemm_f32_kernel<32, 4, 1>), grid, dim3(256), smem, st, p);
   } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void *)conv3d_igemm_f32_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    ensure_dynamic_lds((const void *)conv3d_igemm_f32_kernel<128, 2, 2>, (int)smem, attr_done);
     hipLaunchKernelGGL((conv3d_igemm_f32_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
   }
   rc = check_launch("conv3d_igemm_f32_kernel");
@@ -1005,12 +999,11 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
+    static std::atomic<uint64_t> attr_done_a{0}, attr_done_b{0};
     const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
-    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    attr_set = true;
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, attr_done_a);
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, attr_done_b);
   }
   if (narrow)
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
@@ -1074,12 +1067,11 @@ extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, cons
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
+    static std::atomic<uint64_t> attr_done_a{0}, attr_done_b{0};
     const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
-    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    attr_set = true;
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, attr_done_a);
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, attr_done_b);
   }
   if (narrow)
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);

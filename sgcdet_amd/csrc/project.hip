@@ -12,7 +12,7 @@ namespace sgc {
 // would contract, so contraction is switched off for this kernel by pragma):
 //   p = ref + origin;  cam_r = ((P_r0*x + P_r1*y) + P_r2*z) + P_r3
 //   den = max(cam_z, eps); u = (cam_x/den)*(1/img_w); v = (cam_y/den)*(1/img_h);
-//   zn = (cam_z - d_near) * (1/(d_far - d_near))
+//   zn = (cam_z - d_near) * (1/(d_far - d_near));  mask = zn > eps & eps < u < 1-eps & eps < v < 1-eps
 // torch's GPU `tensor / python_scalar` (TU/encoder.py:209-211) multiplies by the fp32
 // reciprocal, which is what rw/rh/rd reproduce.  The oracle uses the same order.
 __global__ void project_points_kernel(const float *__restrict__ ref3d, const float *__restrict__ origin,
@@ -39,7 +39,10 @@ __global__ void project_points_kernel(const float *__restrict__ ref3d, const flo
   const float zn = (cam[2] - d_near) * rd;
   float *o = ref_cam + ((int64_t)n * Nq + q) * 3;
   o[0] = u; o[1] = v; o[2] = zn;
-  mask[(int64_t)n * Nq + q] = (uint8_t)(cam[2] > eps && u > eps && u < hi && v > eps && v < hi);
+  // the reference's `points_d` is a VIEW of reference_points_cam[..., 2:3] and that slice is overwritten in place
+  // with the normalised depth before `volume_mask = points_d > eps` runs (TU/encoder.py:203-213): the depth test is
+  // on zn, i.e. points closer than d_near (+ eps * range) are dropped, not only points behind the camera
+  mask[(int64_t)n * Nq + q] = (uint8_t)(zn > eps && u > eps && u < hi && v > eps && v < hi);
 }
 
 // block-wide exclusive scan of one flag per thread (1024 threads = 16 waves)

@@ -38,8 +38,11 @@ def shard_scenes(n_scenes, rank, world, pad=True):
     """Indices of the scenes rank ``rank`` processes: strided like DistributedSampler(shuffle=False);
     with ``pad`` every rank gets ceil(n/world) items (wrap-around) so ranks stay in lock-step."""
     idx = list(range(n_scenes))
-    if pad and n_scenes % world:
-        idx += idx[: world - n_scenes % world]
+    if pad and n_scenes and n_scenes % world:
+        # pad by repetition (DistributedSampler does the same): with fewer scenes than the pad length a single
+        # wrap-around slice would leave some ranks empty and the next barrier would hang
+        total = -(-n_scenes // world) * world
+        idx = (idx * (-(-total // n_scenes)))[:total]
     return idx[rank::world]
 
 
@@ -97,8 +100,9 @@ class OverlappedGradAllReduce:
     """The same averaging, started DURING the backward pass (one gradient exchange per step over
     RCCL, overlapped with the neck's backward).  Parameters are bucketed in reverse registration order -- the order
     their gradients become ready in; a post-accumulate hook counts a bucket's gradients in and launches its
-    asynchronous all-reduce the moment the last one lands, so the exchange of the head / neck gradients runs under
-    the view transform's backward.  ``finish()`` (after ``loss.backward()``) flushes buckets whose parameters got no
+    asynchronous all-reduce as soon as the last one lands AND every earlier bucket is out (strict index order on
+    every rank, as DDP: ranks whose used-parameter sets differ still issue identical collective sequences), so the
+    exchange of the head / neck gradients runs under the view transform's backward.  ``finish()`` (after ``loss.backward()``) flushes buckets whose parameters got no
     gradient this step (zeros, as DDP with ``find_unused_parameters=True``), waits, and writes the means back.
 
         sync = OverlappedGradAllReduce(model.parameters())
@@ -121,7 +125,8 @@ class OverlappedGradAllReduce:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): b for b, bucket in enumerate(self.buckets) for p in bucket}
-        self._ready = [0] * len(self.buckets)
+        self._seen = [set() for _ in self.buckets]   # ids of the parameters whose gradient has landed this step
+        self._next = 0                               # buckets [0, _next) have been launched (always in index order)
         self._pending = {}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -133,22 +138,36 @@ class OverlappedGradAllReduce:
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         self._pending[b] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
+    def _launch_ready_prefix(self):
+        """Collectives are matched across ranks by ISSUE ORDER, and which parameters receive a gradient may differ
+        from rank to rank (``find_unused_parameters=True`` semantics): bucket b goes out only once buckets 0 .. b-1
+        have, so every rank issues the same sequence 0, 1, 2, ... whatever order its buckets fill up in."""
+        while self._next < len(self.buckets) and len(self._seen[self._next]) == len(self.buckets[self._next]):
+            self._launch(self._next)
+            self._next += 1
+
     def _on_grad(self, p):
         if not self._active():
             return
         b = self._bucket_of[id(p)]
-        self._ready[b] += 1
-        if self._ready[b] == len(self.buckets[b]) and b not in self._pending:
-            self._launch(b)
+        if id(p) in self._seen[b]:
+            # a bucket that is already on the wire was reduced from the FIRST micro-batch; finish() would overwrite
+            # the accumulated gradient with it.  Gradient accumulation needs finish() once per backward().
+            raise RuntimeError("OverlappedGradAllReduce: a second backward() reached a parameter before finish(); "
+                               "call finish() after every backward() (or use BucketedGradAllReduce once after the "
+                               "accumulation steps)")
+        self._seen[b].add(id(p))
+        self._launch_ready_prefix()
 
     def finish(self):
         if not self._active():
             return
         world = dist.get_world_size()
+        for b in range(self._next, len(self.buckets)):     # the rest, in index order (buckets with unused parameters)
+            self._launch(b)
+        self._next = len(self.buckets)
         for b in range(len(self.buckets)):
-            if b not in self._pending:              # some parameter of the bucket had no gradient this step
-                self._launch(b)
-        for b, (flat, work) in sorted(self._pending.items()):
+            flat, work = self._pending[b]
             work.wait()
             flat.div_(world)
             off = 0
@@ -161,7 +180,8 @@ class OverlappedGradAllReduce:
                     p.grad.copy_(g)
                 off += n
         self._pending.clear()
-        self._ready = [0] * len(self.buckets)
+        self._seen = [set() for _ in self.buckets]
+        self._next = 0
 
     def remove(self):
         for h in self._hooks:

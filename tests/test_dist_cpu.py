@@ -50,9 +50,28 @@ def _worker(rank, world, port, out):
         sync.finish()
     grads2 = torch.cat([p.grad.reshape(-1) for p in neck2.parameters()])
     assert unused.grad is not None and float(unused.grad.abs().sum()) == 0.0
+    # a second backward() before finish() must not be silently lost
+    for p in neck2.parameters():
+        p.grad = None
+    sum(o.square().mean() for o in neck2(scenes[rank])).backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        sum(o.square().mean() for o in neck2(scenes[rank])).backward()
+    sync.finish()
     sync.remove()
+    # the set of parameters that receive a gradient DIFFERS per rank (find_unused_parameters semantics): rank r leaves
+    # branch r of a two-branch model unused, so its buckets fill in a different order -- collectives must still pair up
+    torch.manual_seed(1)
+    branches = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(4)])
+    sync3 = sd.OverlappedGradAllReduce(branches.parameters(), bucket_bytes=16 * 16 * 4)     # ~one bucket per layer
+    assert len(sync3.buckets) >= 4
+    x = torch.randn(3, 16, generator=torch.Generator().manual_seed(7))
+    used = [i for i in range(4) if i != rank]                 # rank 0 skips branch 0, rank 1 skips branch 1
+    sum(branches[i](x).square().mean() * (i + 1) for i in used).backward()
+    sync3.finish()
+    grads3 = torch.cat([p.grad.reshape(-1) for p in branches.parameters()])
+    sync3.remove()
     if rank == 0:
-        torch.save(dict(mine=mine, slowest=slowest, grads=grads, grads2=grads2), out)
+        torch.save(dict(mine=mine, slowest=slowest, grads=grads, grads2=grads2, grads3=grads3, tiny=sd.shard_scenes(1, rank, 4)), out)
     else:
         torch.save(dict(mine=mine), out + ".1")
     dist.barrier()
@@ -78,3 +97,25 @@ def test_two_rank_gloo_sharding_and_grad_allreduce(tmp_path):
     want = (ref[0] + ref[1]) / 2
     assert torch.allclose(r0["grads"], want, rtol=1e-5, atol=1e-7)
     assert torch.allclose(r0["grads2"], want, rtol=1e-5, atol=1e-7)        # OverlappedGradAllReduce: same means
+    # per-rank different unused branches: mean over ranks with zeros for the rank that skipped the branch
+    torch.manual_seed(1)
+    branches = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(4)])
+    x = torch.randn(3, 16, generator=torch.Generator().manual_seed(7))
+    per_rank = []
+    for rank in range(2):
+        for p in branches.parameters():
+            p.grad = None
+        sum(branches[i](x).square().mean() * (i + 1) for i in range(4) if i != rank).backward()
+        per_rank.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                   for p in branches.parameters()]))
+    assert torch.allclose(r0["grads3"], (per_rank[0] + per_rank[1]) / 2, rtol=1e-5, atol=1e-7)
+    assert r0["tiny"] == [0]                                                 # 1 scene, 4 ranks: nobody is left empty
+
+
+def test_shard_scenes_pads_by_repetition():
+    from sgcdet_amd.dist import shard_scenes
+    for n, world in [(1, 4), (2, 8), (3, 8), (5, 2), (8, 8), (9, 4)]:
+        shards = [shard_scenes(n, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == -(-n // world)
+        assert set(i for s in shards for i in s) == set(range(n))
+    assert shard_scenes(0, 0, 4) == []

@@ -51,6 +51,21 @@ def test_point_sampling_against_reference_golden():
     assert max_err(ref_cam, ps["ref_cam"]) < 2e-6
 
 
+def test_point_sampling_near_plane_rule_against_reference_golden():
+    """tests/golden/point_sampling_near.npz: in-image voxels closer than d_near are invisible in the reference (its depth
+    test reads the slice already overwritten with the normalised depth, encoder.py:203-213); bit-exact mask."""
+    d, sd = load("voxel_head")
+    ps, _ = load("point_sampling_near")
+    head = _build_voxel_head(d).cuda().eval()
+    enc = head.base_heads[2].cross_transformer.encoder
+    ref_cam, mask = enc.point_sampling(ps["ref_3d"].cuda()[None, None], img_meta=img_meta(ps))
+    assert int(ps["n_band"]) >= 8
+    assert torch.equal(mask.cpu().to(torch.uint8), ps["mask"])
+    g = ps["ref_cam"]
+    inside = (g[..., 0] > 1e-5) & (g[..., 0] < 1 - 1e-5) & (g[..., 1] > 1e-5) & (g[..., 1] < 1 - 1e-5)
+    assert max_err(ref_cam.cpu()[inside], g[inside]) < 2e-6
+
+
 def test_neck_and_heads_against_reference_golden():
     import sgcdet_amd.plugin as P
     d, sd = load("neck")

@@ -37,6 +37,26 @@ def test_point_sampling_matches_reference_torch(oracle_ops):
     assert max_err(ref_cam, g_cam) < 2e-6
 
 
+def test_point_sampling_near_plane_rule_matches_reference_torch(oracle_ops):
+    """Cameras inside the grid (tests/golden/make_golden_near.py): 48 in-image voxels lie 0 .. 0.2 m in front of a
+    camera.  The reference drops them -- its depth test runs on the slice it has just overwritten with the
+    normalised depth (encoder.py:203-213) -- and so must the oracle: mask identical, and none of the band's points
+    visible."""
+    d, _ = load("point_sampling_near")
+    meta = img_meta(d)
+    rp = RefPath({}, dict(dbound=(float(d["dbound"][0]), float(d["dbound"][1]))))
+    ref_cam, mask = rp.project(d["ref_3d"].float(), meta)
+    g_cam, g_mask = d["ref_cam"][:, 0, :, 0], d["mask"][:, 0, :, 0]
+    assert int(d["n_band"]) >= 8
+    assert torch.equal(mask, g_mask)
+    u, v, zn = g_cam[..., 0], g_cam[..., 1], g_cam[..., 2]
+    inside = (u > 1e-5) & (u < 1 - 1e-5) & (v > 1e-5) & (v < 1 - 1e-5)
+    band = inside & (zn <= 1e-5) & (zn > -0.2 / 4.8 + 1e-4)          # in front of the camera, closer than d_near
+    assert int(band.sum()) >= 8 and not g_mask[band].any()
+    # u, v of points almost in the camera plane are huge (division by ~1 cm): compare where the mask can be 1
+    assert max_err(ref_cam[inside], g_cam[inside]) < 2e-6
+
+
 def test_voxel_head_restatement_matches_reference():
     d, sd = load("voxel_head")
     meta = img_meta(d)
