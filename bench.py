@@ -181,6 +181,9 @@ def main():
         scenes.append((feats, dpt, [meta]))
 
     ops = ext.ops()
+    for kv in filter(None, os.environ.get("SGC_TUNE", "").split(",")):      # development knobs: SGC_TUNE="tile_nw=8,tile_hg=2"
+        key, val = kv.split("=")
+        ops.lib.call("sgc_set_tuning", key.encode(), int(val))
 
     streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
 
@@ -209,7 +212,7 @@ def main():
     eager_events = not det.scene_graph      # kernels inside a replayed scene graph cannot carry host-side events
     if eager_events:
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
+        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -227,7 +230,7 @@ def main():
         det.scene_graph = False
         tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
+        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
         with torch.no_grad():
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
@@ -284,10 +287,12 @@ def main():
     for name, meta, e0, e1 in log:
         per_kernel.setdefault(name, []).append((e0.elapsed_time(e1) * 1e-3, meta))
     roofline = None
-    dg = per_kernel.get("sgc_pairs_deform_gather", [])
+    dg = per_kernel.get("sgc_pairs_deform_gather", []) + per_kernel.get("sgc_pairs_deform_gather_tiled", [])
+    tiled_finest = False
     if dg:
         big = max(m["n_pairs"] * m["C"] + m["N"] * m["H"] * m["W"] * m["C"] for _, m in dg)
         finest = [(t, m) for t, m in dg if m["n_pairs"] * m["C"] + m["N"] * m["H"] * m["W"] * m["C"] >= 0.5 * big]
+        tiled_finest = "bin" in finest[0][1]
         t_avg = sum(t for t, _ in finest) / len(finest)
         b_avg = sum(algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"])
                     for _, m in finest) / len(finest)
@@ -301,7 +306,8 @@ def main():
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                        kernel="sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8, Cm=32> (finest level)",
+                        kernel=("sgc::dfa3d_fwd_tile_kernel (LDS-staged head windows, finest level)" if tiled_finest else
+                                "sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8> (finest level)"),
                         measured=roofline_pass,
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----

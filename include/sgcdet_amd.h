@@ -207,6 +207,54 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
                             int N, int Nq, int H, int W, int M, int Cm, int D, int P, int cam_stride_or_0,
                             int value_has_zero_row, int n_pairs_or_neg, int cap, sgc_stream_t stream);
 
+/* ---- LDS-tiled form of the same gather (the hot-path default where the shape allows) ----------------------
+ *
+ * sgc_bin_pairs: REORDERS the visible pairs of every camera by the feature pixel their reference point projects to
+ * (a stable counting sort per camera; the camera-major layout of sgc_compact_pairs is kept, so pair_cam and
+ * cam_offset stay valid).
+ *   ref_cam [N,Nq,3]; pair_cam / pair_q [cap], cam_offset [N+1] from sgc_compact_pairs (counts stay on the device).
+ *   bin(u, v) = (clamp(floor(v*H - 0.5), 0, H-1) / bin_h) * ceil(W / bin_w) + clamp(floor(u*W - 0.5), 0, W-1) / bin_w
+ *   (fp32, no FMA contraction).  nb = ceil(W/bin_w) * ceil(H/bin_h) <= 1024 bins per camera.
+ *   OUT pair_q_out [cap] int32 (must not alias pair_q): the queries in the new order -- grouped by (camera, bin),
+ *       ascending ORIGINAL pair index (= ascending query) inside a group, identical from run to run;
+ *   IN/OUT slot [N,Nq] int32: rewritten to the new pair index of every visible (camera, query);
+ *   OUT pair_ref [cap][4] fp32, 16-byte aligned: (u, v, zn, bit pattern of the int32 query) of every pair, new order;
+ *   OUT bin_offset [N*nb + 1] int32: first pair of every (camera, bin) group; the last entry is n_pairs;
+ *   workspace: sgc_bin_pairs_workspace_bytes(...) bytes, 16-byte aligned.                                       */
+int sgc_bin_pairs(const float *ref_cam, const int32_t *pair_cam, const int32_t *pair_q, const int32_t *cam_offset,
+                  int32_t *pair_q_out, int32_t *slot, float *pair_ref, int32_t *bin_offset, void *workspace,
+                  int N, int Nq, int cap, int H, int W, int bin_w, int bin_h, sgc_stream_t stream);
+int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int bin_w, int bin_h);
+
+/* sgc_pairs_deform_gather_tiled: the operator of sgc_pairs_deform_gather (MSDeformableAttention3D_DFA3D's DFA3D
+ * call, TU/deformable_cross_attention.py:423-489; one level, softmax over the P points and `ref + offset/(W,H,D)`
+ * fused in) on a BINNED pair list with HEAD-MAJOR operands.  One workgroup per (camera, bin) walks the heads and
+ * stages each head's window of the value map (and the camera's depth window) in LDS:
+ *   value_hm [N][M][S][Cm]          value_proj output as written by sgc_linear_rows_headmajor_bf16x3
+ *   dist     [N][S][D]
+ *   pair_ref / bin_offset           from sgc_bin_pairs with the same (H, W, bin_w, bin_h)
+ *   raw_hm   [n_pairs][M][P][4]     per (pair, head, point): (du, dv, dz, attention logit) -- the three Linear
+ *                                   outputs of sgc_pairs_deform_gather's `raw`, columns permuted head-major; rows in
+ *                                   the binned pair order
+ *   head_shift_or_null [M][2] int32 per-head shift (x, y) in pixels of the staged window (a head's mean sampling
+ *                                   offset), |shift| <= max_shift_x / max_shift_y; speed only
+ *   out      [n_pairs][M*Cm]        fully written for every pair, binned pair order
+ * The staged window is the bin + halo_x / halo_y pixels on each side (clipped to the map); samples outside it are
+ * served from global memory: results do not depend on bin_w / bin_h / halo / head_shift.  P == 4, Cm in {16, 32},
+ * depth_in_lds != 0: the depth taps are served from an LDS copy of the camera's depth window as well (when it fits;
+ * pays when many pairs share a bin).  D >= 2, H*W < 32767; the windows must fit 160 KB of LDS (sgc_tile_window
+ * reports what would be staged).                                                                                 */
+int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, const float *pair_ref,
+                                  const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
+                                  float *out, int N, int H, int W, int M, int Cm, int D, int P,
+                                  int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,
+                                  int max_shift_x, int max_shift_y, int depth_in_lds, sgc_stream_t stream);
+/* (host-side helper, no launch, HOST pointers) value window, LDS bytes, number of value buffers (2 = the next head's
+ * window is loaded while the current head is computed) and whether the depth window is staged too */
+int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int max_shift_x,
+                    int max_shift_y, int depth_in_lds, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
+                    int *depth_in_lds_out);
+
 /* dp [N,H,W+1,D,2]: dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0); dist [N,H*W,D]. */
 int sgc_depth_pairs(const float *dist, float *dp, int N, int H, int W, int D, int cam_stride_or_0,
                     sgc_stream_t stream);
@@ -329,6 +377,12 @@ int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, i
 int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                            float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
                            sgc_stream_t stream);
+
+/* value_proj (TU/deformable_cross_attention.py:417) with the result stored HEAD-MAJOR for the tiled gather:
+ *   x [N*S][Cin] camera-major pixel rows -> y [N][M][S][Cm], y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j].
+ *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128.            */
+int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                     float *y, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 8. Post-processing

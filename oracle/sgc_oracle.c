@@ -47,6 +47,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/sgcdet_amd.h"
@@ -568,6 +569,115 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
   return SGC_OK;
 }
 
+/* ---- 4b. binned / head-major forms (include/sgcdet_amd.h: sgc_bin_pairs, sgc_pairs_deform_gather_tiled) ---- */
+static int oracle_ref_bin(const float *rc, int H, int W, int bw, int bh, int nbx) {
+  const float w_im = rc[0] * (float)W - 0.5f, h_im = rc[1] * (float)H - 0.5f;
+  int px = (int)floorf(w_im), py = (int)floorf(h_im);
+  px = px < 0 ? 0 : (px > W - 1 ? W - 1 : px);
+  py = py < 0 ? 0 : (py > H - 1 ? H - 1 : py);
+  return (py / bh) * nbx + px / bw;
+}
+
+/* stable counting sort of every camera's pairs by bin: ascending ORIGINAL pair index inside a bin */
+int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int bin_w, int bin_h) {
+  (void)N; (void)Nq; (void)cap; (void)H; (void)W; (void)bin_w; (void)bin_h;
+  return 16;
+}
+
+int sgc_bin_pairs(const float *ref_cam, const int32_t *pair_cam, const int32_t *pair_q, const int32_t *cam_offset,
+                  int32_t *pair_q_out, int32_t *slot, float *pair_ref, int32_t *bin_offset, void *workspace,
+                  int N, int Nq, int cap, int H, int W, int bin_w, int bin_h, sgc_stream_t stream) {
+  (void)stream; (void)workspace; (void)pair_cam; (void)cap;
+  if (!ref_cam || !pair_q || !cam_offset || !pair_q_out || !slot || !pair_ref || !bin_offset) return fail(SGC_EINVAL, "null pointer");
+  if (N <= 0 || Nq <= 0 || H <= 0 || W <= 0 || bin_w <= 0 || bin_h <= 0) return fail(SGC_EINVAL, "bad size");
+  if (pair_q_out == pair_q) return fail(SGC_EINVAL, "pair_q_out must not alias pair_q");
+  const int nbx = (W + bin_w - 1) / bin_w, nby = (H + bin_h - 1) / bin_h, nb = nbx * nby;
+  if (nb > 1024) return fail(SGC_EUNSUP, "more than 1024 bins per camera");
+  int *next = (int *)malloc(sizeof(int) * (size_t)nb);
+  if (!next) return fail(SGC_EINVAL, "out of memory");
+  for (int n = 0; n < N; ++n) {
+    const int p0 = cam_offset[n], p1 = cam_offset[n + 1];
+    const float *rcam = ref_cam + (int64_t)n * Nq * 3;
+    for (int b = 0; b < nb; ++b) next[b] = 0;
+    for (int p = p0; p < p1; ++p) next[oracle_ref_bin(rcam + (int64_t)pair_q[p] * 3, H, W, bin_w, bin_h, nbx)]++;
+    int run = p0;
+    for (int b = 0; b < nb; ++b) { const int c = next[b]; bin_offset[(int64_t)n * nb + b] = run; next[b] = run; run += c; }
+    for (int p = p0; p < p1; ++p) {
+      const int32_t q = pair_q[p];
+      const float *rc = rcam + (int64_t)q * 3;
+      const int pos = next[oracle_ref_bin(rc, H, W, bin_w, bin_h, nbx)]++;
+      float *o = pair_ref + (int64_t)pos * 4;
+      o[0] = rc[0]; o[1] = rc[1]; o[2] = rc[2];
+      memcpy(o + 3, &q, sizeof(int32_t));
+      pair_q_out[pos] = q;
+      slot[(int64_t)n * Nq + q] = pos;
+    }
+    if (n == N - 1) bin_offset[(int64_t)N * nb] = p1;
+  }
+  free(next);
+  return SGC_OK;
+}
+
+int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int max_shift_x,
+                    int max_shift_y, int depth_in_lds, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
+                    int *depth_in_lds_out) {
+  const int tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W;
+  const int th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
+  (void)max_shift_x; (void)max_shift_y; (void)D; (void)depth_in_lds;
+  if (tw_out) *tw_out = tw;
+  if (th_out) *th_out = th;
+  if (lds_bytes_out) *lds_bytes_out = (tw * th + 1) * Cm * 4;
+  if (nbuf_out) *nbuf_out = 1;
+  if (depth_in_lds_out) *depth_in_lds_out = 0;
+  return SGC_OK;
+}
+
+/* Same arithmetic as sgc_pairs_deform_gather (the reference kernels' order), operands head-major, pairs in the
+ * binned order; the window parameters (bin / halo / head_shift) only choose what the GPU stages in LDS and cannot
+ * change a result. */
+int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, const float *pair_ref,
+                                  const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
+                                  float *out, int N, int H, int W, int M, int Cm, int D, int P,
+                                  int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,
+                                  int max_shift_x, int max_shift_y, int depth_in_lds, sgc_stream_t stream) {
+  (void)stream; (void)head_shift_or_null; (void)halo_x; (void)halo_y; (void)max_shift_x; (void)max_shift_y; (void)depth_in_lds;
+  if (!value_hm || !dist || !pair_ref || !bin_offset || !raw_hm || !out) return fail(SGC_EINVAL, "null pointer");
+  if (P > 64) return fail(SGC_EUNSUP, "P > 64");
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
+  const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;
+  const int nb = ((W + bin_w - 1) / bin_w) * ((H + bin_h - 1) / bin_h);
+  const int MC = M * Cm;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < N * nb; ++t) {
+    const int n = t / nb;
+    for (int i = bin_offset[t]; i < bin_offset[t + 1]; ++i) {
+      const float *r = pair_ref + (int64_t)i * 4;
+      for (int m = 0; m < M; ++m) {
+        const float *rw = raw_hm + ((int64_t)i * M + m) * P * 4;         /* [P][4] = (du, dv, dz, logit) */
+        float mx = rw[3];
+        for (int p = 1; p < P; ++p) mx = fmaxf(mx, rw[p * 4 + 3]);
+        float e[64], sum = 0.f;
+        for (int p = 0; p < P; ++p) { e[p] = expf(rw[p * 4 + 3] - mx); sum += e[p]; }
+        float *o = out + (int64_t)i * MC + m * Cm;
+        for (int c = 0; c < Cm; ++c) o[c] = 0.f;
+        const float *plane = value_hm + ((int64_t)n * M + m) * S * Cm;
+        for (int p = 0; p < P; ++p) {
+          const float x = r[0] + rw[p * 4] / (float)W;
+          const float y = r[1] + rw[p * 4 + 1] / (float)H;
+          const float z = r[2] + rw[p * 4 + 2] / (float)D;
+          const float aw = e[p] / sum;
+          float s[4];
+          depth_score_sample(dist + n * S * D, D, 0, H, W, D, x, y, z, s);
+          const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+          if (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+            for (int c = 0; c < Cm; ++c) o[c] += wms_bilinear(plane, H, W, Cm, c, h_im, w_im, s) * aw;
+        }
+      }
+    }
+  }
+  return SGC_OK;
+}
+
 /* ---- 5. inter-view aggregation ---------------------------------------------- */
 int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
                   float *mean, int N, int Nq, int C, const int32_t *n_valid_dev_or_null, int n_valid,
@@ -712,7 +822,6 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
 
 /* bf16x3 entry point: the oracle is the fp32 truth -- it rebuilds w = float(hi) + float(lo) and runs
  * the naive fp32 convolution above. */
-#include <stdlib.h>
 static float bf16_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
 int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                     int transposed, int bf16x3) {
@@ -748,6 +857,24 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
   if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
   if (rows <= 0) return SGC_OK;
   return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, NULL, 0, stream);
+}
+
+/* value_proj with a head-major result: y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j] */
+int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                     float *y, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream) {
+  if (!x || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  if (N <= 0 || S <= 0 || M <= 0 || Cm <= 0) return fail(SGC_EINVAL, "bad size");
+  const int64_t rows = (int64_t)N * S;
+  const int C = M * Cm;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)rows * C);
+  if (!tmp) return fail(SGC_EINVAL, "out of memory");
+  const int rc = sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, tmp, (int)rows, 1, 1, Cin, C, 1, 1, 0, 0, NULL, 0, stream);
+  if (rc == SGC_OK)
+    for (int64_t r = 0; r < rows; ++r)
+      for (int c = 0; c < C; ++c)
+        y[(((r / S) * M + c / Cm) * S + r % S) * Cm + c % Cm] = tmp[r * C + c];
+  free(tmp);
+  return rc;
 }
 
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */

@@ -60,6 +60,8 @@ struct ConvParams {
   int64_t ws_floats;      // capacity of ws
   const int32_t *m_dev;   // optional: the live row count lives on the device (sgc_linear_rows_*); rows >= *m_dev
                           // are neither read nor written and workgroups past it exit at once
+  int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
+                          // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
 };
 
 constexpr int BM = 128, BK = 32, LDK = BK + 4;
@@ -419,6 +421,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
               acc[i][j][k];
     __syncthreads();
     constexpr int C4 = BN / 4;
+    if (p.hm_cm > 0) {
+      // head-major store: the lanes of a wave instruction walk ROWS of one head (a head's rows are hm_cm * 4 bytes apart in
+      // its plane), so a wave writes one contiguous 1 KiB run instead of 8 head segments 1 plane apart
+      const int cvh = p.hm_cm / 4, per_head = BM * cvh, heads = p.Cout / p.hm_cm;
+      for (int e = tid; e < BM * C4; e += NT) {
+        const int hl = e / per_head, rr = e - hl * per_head;
+        const int rl = rr / cvh, c4 = hl * cvh + (rr - rl * cvh);
+        const int m = m0 + rl, col = n0 + c4 * 4;
+        if (m >= Mrows || col >= p.Cout) continue;
+        float4 v = *reinterpret_cast<const float4 *>(cs + rl * LDC + c4 * 4);
+        if (p.shift) {
+          const float4 sh4 = *reinterpret_cast<const float4 *>(p.shift + col);
+          v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
+        }
+        const int ncam = m / p.hm_S, spx = m - ncam * p.hm_S, head = col / p.hm_cm;
+        *reinterpret_cast<float4 *>(p.y + (((int64_t)ncam * heads + head) * p.hm_S + spx) * p.hm_cm + (col - head * p.hm_cm)) = v;
+      }
+      return;
+    }
     for (int e = tid; e < BM * C4; e += NT) {
       const int rl = e / C4, c4 = e - rl * C4;
       const int m = m0 + rl, col = n0 + c4 * 4;
@@ -1046,9 +1067,9 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
 // y[rows, Cout] = x[rows, Cin] @ W^T + shift with the row count on the DEVICE: the pair-list stages size their
 // GEMMs by the number of visible (camera, voxel) pairs, which sgc_compact_pairs leaves in totals[] -- reading it
 // back costs a host round trip per level.  The grid covers rows_cap; workgroups past *rows_dev exit at once.
-extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
-                                      float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
-                                      sgc_stream_t stream) {
+static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                       float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout, int hm_S, int hm_cm,
+                       sgc_stream_t stream) {
   if (!x || !w_hi || !w_lo || !y) return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: null pointer");
   if (rows_cap <= 0) return SGC_OK;
   if (Cin % 32 || Cout % 4) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: needs Cin %% 32 == 0 and Cout %% 4 == 0");
@@ -1062,6 +1083,7 @@ extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, cons
   p.Cin = Cin; p.Cout = Cout;
   p.ix = rows_cap; p.iy = 1; p.iz = 1; p.gx = rows_cap; p.gy = 1; p.gz = 1;
   p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1; p.splitk = 1; p.M = rows_cap; p.m_dev = rows_dev_or_null;
+  p.hm_S = hm_S; p.hm_cm = hm_cm;
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
@@ -1080,4 +1102,23 @@ extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, cons
   else
     hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
   return check_launch("conv3d_igemm_bf16x3_kernel (linear rows)");
+}
+
+extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                      float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                                      sgc_stream_t stream) {
+  return linear_rows(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, 0, stream);
+}
+
+// The same GEMM with a HEAD-MAJOR result: x holds N * S rows (camera-major pixels), the Cout columns are M heads of
+// Cm channels, and y is [N][M][S][Cm] -- the layout the LDS-tiled deformable gather stages one head's window from
+// (dfa3d_tile.hip).  Same arithmetic per element as sgc_linear_rows_bf16x3: only the store address differs.
+extern "C" int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
+                                                const float *shift, float *y, int N, int S, int Cin, int M, int Cm,
+                                                sgc_stream_t stream) {
+  if (N <= 0 || S <= 0 || M <= 0 || Cm <= 0 || Cm % 4 || (int64_t)N * S >= (1ll << 31))
+    return set_error(SGC_EINVAL, "sgc_linear_rows_headmajor_bf16x3: bad size (Cm %% 4 == 0 required)");
+  if (128 % Cm && Cm % 128)
+    return set_error(SGC_EUNSUP, "sgc_linear_rows_headmajor_bf16x3: Cm must divide the 128-column tile (got %d)", Cm);
+  return linear_rows(x, w_hi, w_lo, shift, y, nullptr, N * S, Cin, M * Cm, S, Cm, stream);
 }

@@ -410,6 +410,11 @@ extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile
 extern int g_tune_halo_min_cout;
 extern int g_tune_halo_min_m;
 extern int g_tune_halo_brick;
+extern int g_tune_tile_nw;          // dfa3d_tile.hip
+extern int g_tune_tile_depth_lds;
+extern int g_tune_tile_diag;
+extern int g_tune_tile_nbuf;
+extern int g_tune_tile_hg;
 extern int g_tune_conv_halo;    // conv3d.hip: halo-resident kernel for the 3x3x3 stride-1 layers   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
 static int pick_tp(int SPI, int LPI) {
@@ -582,6 +587,11 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "halo_min_cout")) { g_tune_halo_min_cout = value; return SGC_OK; }
   if (!strcmp(key, "halo_min_m")) { g_tune_halo_min_m = value; return SGC_OK; }
   if (!strcmp(key, "halo_brick")) { g_tune_halo_brick = value; return SGC_OK; }
+  if (!strcmp(key, "tile_nw")) { g_tune_tile_nw = value; return SGC_OK; }
+  if (!strcmp(key, "tile_depth_lds")) { g_tune_tile_depth_lds = value; return SGC_OK; }
+  if (!strcmp(key, "tile_diag")) { g_tune_tile_diag = value; return SGC_OK; }
+  if (!strcmp(key, "tile_nbuf")) { g_tune_tile_nbuf = value; return SGC_OK; }
+  if (!strcmp(key, "tile_hg")) { g_tune_tile_hg = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }
 

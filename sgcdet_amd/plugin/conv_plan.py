@@ -130,3 +130,10 @@ class LinearSpec:
         else:
             y, _ = ext.ops().conv3d_cl(x, self.wt, (M, 1, 1), 1, 1, False, None, self.shift)
         return y if self.cout_p == self.cout else y[:, :self.cout]
+
+    def headmajor(self, x, N, S, M):
+        """x [N*S, in] -> [N, M, S, out/M]: the same GEMM with the result stored head-major (the layout the LDS-tiled
+        gather stages a head's window from); bf16x3 path only."""
+        if CONV_MODE != "bf16x3" or self.cout_p != self.cout:
+            raise NotImplementedError("head-major output needs the bf16x3 path and out_features % 4 == 0")
+        return ext.ops().linear_rows_headmajor_bf16x3(x, self.w_hi, self.w_lo, self.shift, N, S, M)

@@ -52,6 +52,39 @@ def _ops():
     return ext.ops()
 
 
+# LDS-tiled deformable gather (csrc/dfa3d_tile.hip): which levels take it and how their windows are cut.  Results never
+# depend on these numbers (tests/test_gpu_kernels.py::test_tiled_gather_against_oracle); they were chosen by
+# tools/tile_bench.py sweeps on MI355X.  ``min_pixels``: smaller maps keep the wave kernel.
+TILED_GATHER = dict(enabled=True, min_pixels=2048,
+                    cm32=dict(bin=(16, 22), halo=(3, 3), depth_in_lds=False),
+                    cm16=dict(bin=(27, 30), halo=(3, 3), depth_in_lds=True))
+
+
+def _tiled_env_overrides():
+    """Sweeps without editing the file: SGC_TILED=0|1, SGC_TILED_CM32 / SGC_TILED_CM16 = "bin_w,bin_h,halo_x,halo_y,depth_in_lds"."""
+    import os
+    if "SGC_TILED" in os.environ:
+        TILED_GATHER["enabled"] = os.environ["SGC_TILED"] != "0"
+    for key in ("cm32", "cm16"):
+        spec = os.environ.get("SGC_TILED_" + key.upper())
+        if spec:
+            bw, bh, hx, hy, dl = (int(v) for v in spec.split(","))
+            TILED_GATHER[key] = dict(bin=(bw, bh), halo=(hx, hy), depth_in_lds=bool(dl))
+
+
+_tiled_env_overrides()
+
+
+def _head_major_raw_rows(M, P):
+    """Row order of the fused [uv | dz | logit] projection that makes the GEMM emit [pairs][M][P][(du, dv, dz, logit)]."""
+    idx = []
+    for m in range(M):
+        for p in range(P):
+            mp = m * P + p
+            idx += [mp * 2, mp * 2 + 1, M * P * 2 + mp, M * P * 3 + mp]
+    return torch.tensor(idx, dtype=torch.long)
+
+
 # ----------------------------------------------------------------------------------------
 @ATTENTION.register_module()
 class MSDeformableAttention3D_DFA3D(BaseModule):
@@ -185,12 +218,18 @@ class DeformCrossAttention_DFA3D(BaseModule):
         if self.__dict__.get("_gemm_cache") is not None and self._gemm_cache[0] == fp:
             return self._gemm_cache[1]
         da, mha, C = self.deformable_attention, self.attention_pooling, self.embed_dims
+        raw_w = torch.cat([da.sampling_offsets.weight, da.sampling_offsets_depth.weight, da.attention_weights.weight], 0)
+        raw_b = torch.cat([da.sampling_offsets.bias, da.sampling_offsets_depth.bias, da.attention_weights.bias], 0)
+        hm = _head_major_raw_rows(da.num_heads, da.num_points).to(raw_w.device) if da.num_levels == 1 else None
+        # a head's mean sampling offset in pixels (the bias of sampling_offsets; the weights add a data-dependent part
+        # around it): the tiled gather shifts that head's LDS window by it.  Speed only.
+        off = da.sampling_offsets.bias.detach().float().view(da.num_heads, -1, 2).mean(1).round().clamp(-8, 8)
         plan = dict(
             value=LinearSpec(da.value_proj.weight, da.value_proj.bias),
-            raw=LinearSpec(torch.cat([da.sampling_offsets.weight, da.sampling_offsets_depth.weight,
-                                      da.attention_weights.weight], 0),
-                           torch.cat([da.sampling_offsets.bias, da.sampling_offsets_depth.bias,
-                                      da.attention_weights.bias], 0)),
+            raw=LinearSpec(raw_w, raw_b),
+            raw_hm=LinearSpec(raw_w[hm], raw_b[hm]) if hm is not None else None,
+            head_shift=off.to(torch.int32).contiguous(),
+            max_shift=(int(off[:, 0].abs().max()), int(off[:, 1].abs().max())),
             kv=LinearSpec(mha.in_proj_weight[C:], mha.in_proj_bias[C:]),
             out=LinearSpec(self.output_proj.weight, self.output_proj.bias),
             # the pooled feature only feeds the query projection (:826-833): q = W_q (W_out mean + b_out) + b_q as ONE
@@ -228,21 +267,43 @@ class DeformCrossAttention_DFA3D(BaseModule):
         if n_pairs == 0:
             return out if zero_query else self.dropout(out) + query
         pair_cam, pair_q = pc["pair_cam"], pc["pair_q"]
-        geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=totals)
         gemm = self._gemm_plan() if use_mfma else None
+        da = self.deformable_attention
+        S = feat.shape[1]              # == H*W, or the camera stride of channels-last maps that kept the cropped rows
+        Cm = C // da.num_heads
+        tiled = None
+        if (self.deformable_attn and use_mfma and CONV_MODE == "bf16x3" and TILED_GATHER["enabled"] and da.num_levels == 1
+                and da.num_points == 4 and Cm in (16, 32) and TILED_GATHER["min_pixels"] <= H * W < 32767
+                and dist.shape[-1] >= 2):
+            tiled = TILED_GATHER["cm32" if Cm == 32 else "cm16"]
+            bw, bh = min(tiled["bin"][0], W), min(tiled["bin"][1], H)
+            # every camera's pairs regrouped by the feature pixel of their reference point; everything below runs in
+            # that order (slot is rewritten, so the inter-view stages do not notice)
+            pc = ops.bin_pairs(ref_cam, pc, H, W, bw, bh)
+            pair_q = pc["pair_q"]
+        geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=totals)
         if self.deformable_attn:
-            da = self.deformable_attention
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
-            zero_row = use_mfma and CONV_MODE == "bf16x3"
-            S = feat.shape[1]          # == H*W, or the camera stride of channels-last maps that kept the cropped rows
-            value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
-            raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
-            del geo                                   # capacity-sized in static mode: let the allocator reuse it
-            per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,
-                                               ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
-                                               da.num_heads, da.num_points, totals=totals,
-                                               dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
+            if tiled is not None:
+                value = gemm["value"].headmajor(feat.view(N * S, C), N, S, da.num_heads)
+                raw = gemm["raw_hm"](geo, count=pairs_cnt)
+                del geo
+                per_pair = ops.pairs_deform_gather_tiled(value, dist, pc["pair_ref"], pc["bin_offset"], raw, H, W,
+                                                         da.num_points, bw, bh, tiled["halo"][0], tiled["halo"][1],
+                                                         head_shift=gemm["head_shift"], max_shift=gemm["max_shift"],
+                                                         depth_in_lds=tiled["depth_in_lds"])
+                if n_pairs >= 0:
+                    per_pair = per_pair[:n_pairs]
+            else:
+                zero_row = use_mfma and CONV_MODE == "bf16x3"
+                value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
+                raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
+                del geo                                   # capacity-sized in static mode: let the allocator reuse it
+                per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,
+                                                   ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
+                                                   da.num_heads, da.num_points, totals=totals,
+                                                   dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
             del raw, value
         else:
             per_pair = geo

@@ -271,6 +271,83 @@ class TensorOps:
                    _meta=dict(N=N, H=H, W=W, C=Cc, D=D, M=M, P=P, n_pairs=rows))
         return out
 
+    # ---- 4b. LDS-tiled gather: binning, head-major operands ---------------------------------
+    def tile_window(self, H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, max_shift=(0, 0), depth_in_lds=True):
+        """dict(tw, th, lds_bytes, nbuf, depth_in_lds) of what ``pairs_deform_gather_tiled`` would stage."""
+        import ctypes
+        v = [ctypes.c_int() for _ in range(5)]
+        self.lib._dll.sgc_tile_window(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, int(max_shift[0]), int(max_shift[1]),
+                                      int(bool(depth_in_lds)), *[ctypes.byref(x) for x in v])
+        return dict(zip(("tw", "th", "lds_bytes", "nbuf", "depth_in_lds"), (x.value for x in v)))
+
+    def bin_pairs(self, ref_cam, pc, H, W, bin_w, bin_h):
+        """Reorders every camera's visible pairs by the feature pixel of their reference point (``sgc_bin_pairs``).
+        ``pc``: the dict of ``compact_pairs``; returns a new dict with ``pair_q`` replaced, ``slot`` REWRITTEN IN PLACE
+        to the new pair indices and two more entries, ``pair_ref`` [cap,4] fp32 and ``bin_offset`` [N*nb+1] int32.
+        The pair counts stay on the device."""
+        pair_cam, pair_q, cam_offset, slot = pc["pair_cam"], pc["pair_q"], pc["cam_offset"], pc["slot"]
+        self._check(ref_cam=ref_cam, pair_cam=pair_cam, pair_q=pair_q, cam_offset=cam_offset, slot=slot)
+        self._f32(ref_cam=ref_cam)
+        self._i32(pair_cam=pair_cam, pair_q=pair_q, cam_offset=cam_offset, slot=slot)
+        N, Nq, three = ref_cam.shape
+        cap = pair_q.numel()
+        if three != 3 or cam_offset.numel() != N + 1 or slot.shape != (N, Nq) or pair_cam.numel() != cap:
+            raise RuntimeError("bin_pairs: inconsistent shapes")
+        nb = -(-W // bin_w) * -(-H // bin_h)
+        dev = ref_cam.device
+        out = dict(pc)
+        out["pair_q"] = torch.empty_like(pair_q)
+        out["pair_ref"] = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        out["bin_offset"] = torch.empty(N * nb + 1, dtype=torch.int32, device=dev)
+        out["bin"] = (bin_w, bin_h)
+        if cap == 0:
+            out["bin_offset"].zero_()
+            return out
+        nbytes = int(self.lib._dll.sgc_bin_pairs_workspace_bytes(N, Nq, cap, H, W, bin_w, bin_h))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        self._call("sgc_bin_pairs", ref_cam, pair_cam, pair_q, cam_offset, out["pair_q"], slot, out["pair_ref"],
+                   out["bin_offset"], ws, N, Nq, cap, H, W, bin_w, bin_h)
+        return out
+
+    def pairs_deform_gather_tiled(self, value_hm, dist, pair_ref, bin_offset, raw_hm, H, W, P, bin_w, bin_h, halo_x,
+                                  halo_y, head_shift=None, max_shift=(0, 0), depth_in_lds=True, out=None):
+        """value_hm [N,M,S,Cm]; dist [N,S,D]; raw_hm [cap, M*P*4] head-major (du, dv, dz, logit) per point, rows in
+        the binned pair order; returns out [cap, M*Cm] (rows past the pair count are not written)."""
+        self._check(value_hm=value_hm, dist=dist, pair_ref=pair_ref, bin_offset=bin_offset, raw_hm=raw_hm,
+                    head_shift=head_shift, out=out)
+        self._f32(value_hm=value_hm, dist=dist, pair_ref=pair_ref, raw_hm=raw_hm, out=out)
+        self._i32(bin_offset=bin_offset, head_shift=head_shift)
+        N, M, S, Cm = value_hm.shape
+        D = dist.shape[-1]
+        nb = -(-W // bin_w) * -(-H // bin_h)
+        if S < H * W or dist.shape[:2] != (N, S) or raw_hm.shape[-1] != M * P * 4 or bin_offset.numel() != N * nb + 1 \
+                or (head_shift is not None and head_shift.numel() != 2 * M) or pair_ref.shape[0] < raw_hm.shape[0]:
+            raise RuntimeError("pairs_deform_gather_tiled: inconsistent shapes")
+        rows = raw_hm.shape[0]
+        if out is None:
+            out = torch.empty((rows, M * Cm), dtype=torch.float32, device=value_hm.device)
+        if rows == 0:
+            return out
+        self._call("sgc_pairs_deform_gather_tiled", value_hm, dist, pair_ref, bin_offset, raw_hm, head_shift, out,
+                   N, H, W, M, Cm, D, P, S, bin_w, bin_h, halo_x, halo_y, int(max_shift[0]), int(max_shift[1]),
+                   int(bool(depth_in_lds)),
+                   _meta=dict(N=N, H=H, W=W, C=M * Cm, D=D, M=M, P=P, n_pairs=rows, bin=(bin_w, bin_h), halo=(halo_x, halo_y)))
+        return out
+
+    def linear_rows_headmajor_bf16x3(self, x, w_hi, w_lo, shift, N, S, M):
+        """x [N*S, Cin] -> y [N, M, S, Cm] head-major (``sgc_linear_rows_headmajor_bf16x3``)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, shift=shift)
+        self._f32(x=x, shift=shift)
+        rows, Cin = x.shape
+        Cout = w_hi.shape[-2]
+        if rows != N * S or Cout % M or w_hi.shape[-1] != Cin or w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16:
+            raise RuntimeError("linear_rows_headmajor_bf16x3: inconsistent shapes")
+        Cm = Cout // M
+        y = torch.empty((N, M, S, Cm), dtype=torch.float32, device=x.device)
+        self._call("sgc_linear_rows_headmajor_bf16x3", x, w_hi, w_lo, shift, y, N, S, Cin, M, Cm,
+                   _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
+        return y
+
     # ---- 5. inter-view aggregation ------------------------------------------
     def view_mean(self, feat, slot, valid_index, n_valid, count=None):
         """``count``: optional int32 device tensor holding the live row count (an element of compact_pairs'

@@ -451,3 +451,82 @@ def test_full_size_properties_of_the_path_kernels(gpu_ops):
     b = gpu_ops.assign_targets(pts, scl, tb[perm].contiguous().to(dev), tl[perm].contiguous().to(dev), False, 3, 27, 18)
     pos = a[2] >= 0
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[1][pos], b[1][pos]) and torch.equal(a[0][pos], b[0][pos])
+
+
+@pytest.mark.parametrize("C,HW,bins,halo,scale", [
+    (256, (15, 20), (7, 5), (2, 2), 3.0),        # small window, offsets of several pixels: the global fix-up pass runs
+    (256, (30, 40), (13, 10), (4, 3), 1.0),      # hot shape family (Cm = 32)
+    (128, (14, 20), (20, 14), (0, 0), 2.0),      # Cm = 16, one bin per camera (window = whole map)
+    (128, (29, 40), (8, 29), (1, 0), 6.0),       # Cm = 16, column bins, large offsets
+])
+def test_tiled_gather_against_oracle(C, HW, bins, halo, scale, oracle_ops, gpu_ops):
+    """sgc_bin_pairs (bit-exact) and sgc_pairs_deform_gather_tiled (1e-5) against the oracle; results must not depend
+    on the bin size, the halo, the per-head window shift, the workgroup size, the number of value buffers, the head
+    grouping or where the depth taps are read from."""
+    from tests.tile_contract import check_bins, raw_to_headmajor, value_to_headmajor
+    N, Nq, D, M, P = 6, 900, 12, 8, 4
+    H, W = HW
+    ref3d, origin, proj = _scene(N, Nq, 4)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = oracle_ops.compact_pairs(mk)
+    n_pairs, cap = int(pc["totals"][0]), pc["pair_q"].numel()
+    g = torch.Generator().manual_seed(21)
+    value = torch.randn(N, H * W, M, C // M, generator=g)
+    dist = torch.randn(N, H * W, D, generator=g).mul(2).softmax(-1).contiguous()
+    raw = torch.randn(cap, M * P * 4, generator=g)
+    raw[:, :M * P * 3] *= scale
+    want = oracle_ops.pairs_deform_gather(value, dist, rc, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P)
+    cu = lambda t: t.cuda()
+    gpc = {k: cu(v) for k, v in pc.items()}
+    bw, bh = bins
+    before = dict(pc, slot=pc["slot"].clone())
+    b_c = oracle_ops.bin_pairs(rc, dict(pc, slot=pc["slot"].clone()), H, W, bw, bh)
+    b_g = gpu_ops.bin_pairs(cu(rc), dict(gpc, slot=gpc["slot"].clone()), H, W, bw, bh)
+    for k in ("bin_offset", "slot"):
+        assert torch.equal(b_g[k].cpu(), b_c[k]), k
+    assert torch.equal(b_g["pair_q"][:n_pairs].cpu(), b_c["pair_q"][:n_pairs])
+    assert torch.equal(b_g["pair_ref"][:n_pairs].cpu().view(torch.int32), b_c["pair_ref"][:n_pairs].view(torch.int32))
+    old = check_bins(b_g, before, rc, n_pairs, H, W, bw, bh)
+    raw_new = torch.zeros_like(raw)
+    raw_new[:n_pairs] = raw[old]
+    vhm, rhm = cu(value_to_headmajor(value)), cu(raw_to_headmajor(raw_new, M, P))
+    shift = torch.randint(-3, 4, (M, 2), generator=g, dtype=torch.int32)
+    knobs = ("tile_nw", "tile_depth_lds", "tile_nbuf", "tile_hg")
+    try:
+        for nw, dl, nbuf, hg, hs in [(16, 1, 2, 0, None), (8, 1, 1, 2, shift), (16, 0, 2, 4, shift), (8, 0, 1, 1, None),
+                                     (16, 1, 2, 8, shift)]:
+            for key, val in zip(knobs, (nw, dl, nbuf, hg)):
+                gpu_ops.lib.call("sgc_set_tuning", key.encode(), val)
+            got = gpu_ops.pairs_deform_gather_tiled(vhm, cu(dist), b_g["pair_ref"], b_g["bin_offset"], rhm, H, W, P, bw, bh,
+                                                    halo[0], halo[1], head_shift=None if hs is None else cu(hs),
+                                                    max_shift=(3, 3))
+            close(got[:n_pairs], want[old])
+    finally:
+        for key, val in zip(knobs, (0, -1, 0, 0)):
+            gpu_ops.lib.call("sgc_set_tuning", key.encode(), val)
+    # a different binning of the same pairs: same operator
+    bw2, bh2 = max(1, bw // 2), bh + 3
+    b2 = gpu_ops.bin_pairs(cu(rc), dict(gpc, slot=gpc["slot"].clone()), H, W, bw2, bh2)
+    old2 = check_bins(b2, before, rc, n_pairs, H, W, bw2, bh2)
+    raw2 = torch.zeros_like(raw)
+    raw2[:n_pairs] = raw[old2]
+    got2 = gpu_ops.pairs_deform_gather_tiled(vhm, cu(dist), b2["pair_ref"], b2["bin_offset"], cu(raw_to_headmajor(raw2, M, P)),
+                                             H, W, P, bw2, bh2, 1, 1)
+    close(got2[:n_pairs], want[old2])
+
+
+def test_headmajor_value_projection_is_the_row_gemm_permuted(oracle_ops, gpu_ops):
+    """sgc_linear_rows_headmajor_bf16x3 == sgc_linear_rows_bf16x3 with the store address permuted: bit-identical
+    elements; and within the bf16x3 bound (1e-4 of the scale) of the fp32 oracle."""
+    N, S, Cin, M = 3, 333, 64, 8
+    g = torch.Generator().manual_seed(3)
+    for Cm in (32, 16):
+        x = torch.randn(N * S, Cin, generator=g)
+        w = torch.randn(M * Cm, Cin, generator=g) * 0.2
+        b = torch.randn(M * Cm, generator=g)
+        hi, lo = gpu_ops.split_bf16(w.view(1, M * Cm, Cin))
+        y_rows = gpu_ops.linear_rows_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), b.cuda())
+        y_hm = gpu_ops.linear_rows_headmajor_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), b.cuda(), N, S, M)
+        assert torch.equal(y_hm, y_rows.view(N, S, M, Cm).permute(0, 2, 1, 3).contiguous())
+        y_c = oracle_ops.linear_rows_headmajor_bf16x3(x, hi, lo, b, N, S, M)
+        close(y_hm, y_c, tol=1e-4)

@@ -82,3 +82,31 @@ def test_unreplicated_depth_equals_replicated(oracle_ops):
     gr = oracle_ops.dfa3d_backward(value, drep, shapes3, lsi, loc, attn, go)
     assert (g1[1] - gr[1].sum(2, keepdim=True)).abs().max() < 1e-5
     assert torch.equal(g1[0], gr[0]) and torch.equal(g1[2], gr[2])
+
+
+def test_tiled_gather_restatement_equals_the_plain_pair_list_form(oracle_ops):
+    """The binned / head-major operator (sgc_bin_pairs + sgc_pairs_deform_gather_tiled) is the pair-list gather on a
+    reordered pair list with permuted operands: identical rows (the oracle uses the same arithmetic order for both),
+    for several bin sizes."""
+    from tests.tile_contract import check_bins, raw_to_headmajor, value_to_headmajor
+    from tests.test_gpu_kernels import _scene
+    N, Nq, D, M, P, C, H, W = 5, 600, 12, 8, 4, 64, 15, 20
+    ref3d, origin, proj = _scene(N, Nq, 4)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = oracle_ops.compact_pairs(mk)
+    n_pairs = int(pc["totals"][0])
+    g = torch.Generator().manual_seed(5)
+    value = torch.randn(N, H * W, M, C // M, generator=g)
+    dist = torch.randn(N, H * W, D, generator=g).mul(2).softmax(-1).contiguous()
+    raw = torch.randn(pc["pair_q"].numel(), M * P * 4, generator=g)
+    raw[:, :M * P * 3] *= 3.0
+    want = oracle_ops.pairs_deform_gather(value, dist, rc, raw, pc["pair_cam"], pc["pair_q"], n_pairs, H, W, M, P)
+    for bw, bh in [(20, 15), (7, 4), (3, 16), (1, 1)]:
+        before = dict(pc, slot=pc["slot"].clone())
+        binned = oracle_ops.bin_pairs(rc, dict(pc, slot=pc["slot"].clone()), H, W, bw, bh)
+        old = check_bins(binned, before, rc, n_pairs, H, W, bw, bh)
+        raw_new = torch.zeros_like(raw)
+        raw_new[:n_pairs] = raw[old]
+        got = oracle_ops.pairs_deform_gather_tiled(value_to_headmajor(value), dist, binned["pair_ref"], binned["bin_offset"],
+                                                   raw_to_headmajor(raw_new, M, P), H, W, P, bw, bh, 2, 2)
+        assert torch.equal(got[:n_pairs], want[old])
