@@ -67,6 +67,9 @@ def parse():
                          "(default, what the metric is quoted on); nhwc = channels-last producer contract "
                          "(SURVEY.md 8 f-1): consumed in place, no transpose pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="seconds of the extra `sustained` leg (same configuration, back to back; 0 = skip)")
+    ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short `strict_fp32` leg (--conv-mode f32)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     return ap.parse_args()
 
@@ -91,18 +94,28 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 
 
 def cpu_baseline(w, n_views, seed):
-    """The CPU oracle (port) timed on the host cores on a bounded sample (~12 s) of scenes of the same workload."""
+    """The CPU oracle (a port: the reference has no CPU implementation of this path) timed on the host cores on a
+    bounded sample of scenes of the same workload: all cores (~12 s), then one thread (one scene), plus the per-stage
+    split SURVEY.md 8(d) asks for.  OpenMP threads are set through omp_set_num_threads in the oracle library (torch has
+    already initialised its own pool by now; OMP_NUM_THREADS in os.environ would come too late)."""
+    import ctypes
     import oracle
     from oracle.ref_path import RefPath
     from sgcdet_amd.scene import make_scene, model_config
     from sgcdet_amd.mmcv_lite import build_detector
     import sgcdet_amd.plugin  # noqa: F401
     oracle.build()
-    # threads actually used: all cores up to 32 (beyond that the small per-level torch ops and the
-    # static OpenMP schedule stop scaling on the many-core GPU hosts); override with SGC_CPU_THREADS
-    cores = int(os.environ.get("SGC_CPU_THREADS", min(os.cpu_count() or 1, 32)))
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    all_cores = int(os.environ.get("SGC_CPU_THREADS", os.cpu_count() or 1))
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+
+    def set_threads(n):
+        torch.set_num_threads(n)
+        if gomp is not None:
+            gomp.omp_set_num_threads(n)
+
     torch.manual_seed(0)
     det = build_detector(model_config(w)).eval()
     feats, dpt, meta = make_scene(n_views, w["embed_dims"], kind=w["kind"], seed=seed)
@@ -116,18 +129,36 @@ def cpu_baseline(w, n_views, seed):
     import torch.nn.functional as F
     dpts = [dpt, F.interpolate(dpt, scale_factor=(1, 0.5, 0.5), mode="nearest"),
             F.interpolate(dpt, scale_factor=(1, 0.25, 0.25), mode="nearest")]
+
     def one_scene():
         vol, valid, occ = rp.adaptive_sparse_head(feats, meta, dpts)
-        rp.head(rp.neck(vol, prefix="neck."), prefix="head.")
-    one_scene()                                     # warm-up (thread pools, oneDNN primitive caches)
-    n, t0 = 0, time.perf_counter()
-    while n < 64 and (n < 2 or time.perf_counter() - t0 < 12.0):      # a bounded sample: ~12 s of CPU work
-        one_scene()
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="scenes/sec", cores=cores, kind="port",
-                sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels + "
-                       f"torch-CPU), {dt:.1f} s")
+        with rp._t("neck"):
+            f3 = rp.neck(vol, prefix="neck.")
+        with rp._t("head"):
+            rp.head(f3, prefix="head.")
+
+    def run(threads, budget_s, max_scenes):
+        set_threads(threads)
+        one_scene()                                     # warm-up (thread pools, oneDNN primitive caches)
+        rp.timing = {}
+        n, t0 = 0, time.perf_counter()
+        while n < max_scenes and (n < 1 or time.perf_counter() - t0 < budget_s):
+            one_scene()
+            n += 1
+        dt = time.perf_counter() - t0
+        stages, rp.timing = rp.timing, None
+        return n, dt, {k: round(v / n * 1e3, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+
+    n, dt, stages = run(all_cores, 12.0, 64)
+    out = dict(value=n / dt, unit="scenes/sec", cores=all_cores, kind="port",
+               sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels + "
+                      f"torch-CPU), {dt:.1f} s", stages_ms_per_scene=stages)
+    if all_cores > 1 and not os.environ.get("SGC_CPU_SKIP_1T"):
+        n1, dt1, stages1 = run(1, 0.0, 1)               # one scene on one thread (tens of seconds at config 2)
+        out["one_thread"] = dict(value=n1 / dt1, unit="scenes/sec", cores=1,
+                                 sample=f"{n1} scene after 1 warm-up, {dt1:.1f} s", stages_ms_per_scene=stages1)
+    set_threads(all_cores)
+    return out
 
 
 def main():
@@ -223,6 +254,23 @@ def main():
     elapsed = time.perf_counter() - t0
     log, ops.event_log = ops.event_log, None
     elapsed = sgc_dist.max_over_ranks(elapsed, device=device)
+    # ---- sustained leg (untimed for `value`): the same configuration for >= 2 s, so that DVFS shows (a 50 ms burst of
+    #      bf16 MFMA work runs at boost clocks) ----
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)) + 1)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(n_sus):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el_s = sgc_dist.max_over_ranks(time.perf_counter() - ts, device=device)
+        sustained = dict(value=round(world * n_sus / el_s, 3), unit="scenes/sec", steps=n_sus, seconds=round(el_s, 2),
+                         ms_per_step=round(el_s / n_sus * 1e3, 3))
     roofline_pass = "HIP events on the launch stream over the timed region"
     if not eager_events:
         # same scenes, same streams, same kernels launched eagerly right after the timed region: the deformable
@@ -261,6 +309,9 @@ def main():
         n_runs = int(os.environ.get("SGC_SELF_CHECK_RUNS", 10 * n_scenes))
         flags = torch.zeros(n_runs, dtype=torch.int32, device=device)
         devs = torch.zeros((n_runs, 2), dtype=torch.float32, device=device)
+        if streams:                                     # the fills above ran on the default stream
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
         for i in range(n_runs):
             r = step(i)
             ref = serial[i % n_scenes]
@@ -299,13 +350,15 @@ def main():
         achieved = b_avg / t_avg / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_gather_pmc_v5.json" if args.img == "256x320" else
-                                "r01_gather_pmc_v2.json" if args.img == "config" else "none")
+        traffic, traffic_source = None, None
+        pmc_name = ("r02_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
+        pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if args.workload == "cfg2_scannet" and args.views in (None, 40) and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            traffic_source = (f"offline PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, "
+                              f"FETCH_SIZE doubled per the gfx950 correction), profiles/{pmc_name}; NOT measured in this run")
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         kernel=("sgc::dfa3d_fwd_tile_kernel (LDS-staged head windows, finest level)" if tiled_finest else
                                 "sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8> (finest level)"),
                         measured=roofline_pass,
@@ -327,6 +380,8 @@ def main():
                              kernel=("sgc::conv3d_halo_bf16x3_kernel" if bf else "sgc::conv3d_igemm_f32_kernel") +
                                     f" ({m0['Cin']}->{m0['Cout']} ch, 3x3x3, {m0['OV']} voxels)",
                              algorithmic_gflop=round(top / 1e9, 1), fp32_equivalent_tflops=round(top / t_c / 1e12, 1),
+                             fp32_equivalent_note=("algorithmic fp32 FLOPs / time; it can exceed the 157 TFLOP/s fp32 MFMA peak "
+                                                   "because the work runs as three bf16 products on the bf16 pipe" if bf else None),
                              avg_launch_us=round(t_c * 1e6, 1), launches=len(big_c),
                              note=("achieved = MFMA work actually issued (three bf16 products per fp32 multiply-add: lo*hi + "
                                    "hi*lo + hi*hi); fp32_equivalent_tflops = algorithmic FLOPs of the fp32 convolution / time")
@@ -335,6 +390,31 @@ def main():
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
             tot = sum(t for t, _ in items)
             print(f"  {name:32s} {len(items):5d} launches  {tot * 1e3 / args.steps:8.3f} ms/step", file=sys.stderr)
+
+    # ---- strict-fp32 leg: the same scenes with exact fp32 products on the fp32 MFMA (--conv-mode f32), so that the
+    #      bf16x3 headline never hides what IEEE-fp32 arithmetic costs ----
+    strict = None
+    if args.conv_mode == "bf16x3" and not args.no_strict_fp32:
+        set_conv_mode("f32")
+        sg, ug = det.scene_graph, det.use_graph
+        det.scene_graph, det.use_graph = False, True        # eager view transform + hipGraph tail (no device-count GEMMs in f32)
+        n_f32 = max(4, min(args.steps, 10))
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tf = time.perf_counter()
+        for i in range(n_f32):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el_f = sgc_dist.max_over_ranks(time.perf_counter() - tf, device=device)
+        strict = dict(value=round(world * n_f32 / el_f, 3), unit="scenes/sec", steps=n_f32, ms_per_step=round(el_f / n_f32 * 1e3, 3),
+                      dtype="f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every convolution and Linear; wave-kernel gather)")
+        set_conv_mode("bf16x3")
+        det.scene_graph, det.use_graph = sg, ug
 
     if rank == 0:
         out = {
@@ -362,6 +442,8 @@ def main():
                        "sharding": "scenes across ranks, no collective"},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
+            "strict_fp32": strict,
+            "sustained": sustained,
             "self_check": self_check,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -373,6 +455,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and self_check and self_check["mismatching"] > 0:
+        sys.exit(f"bench.py: {self_check['mismatching']} of {self_check['scene_runs']} overlapped scene runs differ from "
+                 "the serial eager result -- the number above is invalid")
 
 
 if __name__ == "__main__":

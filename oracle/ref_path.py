@@ -34,6 +34,24 @@ class RefPath:
                    for k, v in state_dict.items()}
         self.cfg = cfg
         self.ops = _oracle_ops(omp=omp)
+        self.timing = None          # dict stage -> seconds when enabled (bench.py's cpu_baseline per-stage split)
+
+    def _t(self, stage):
+        """with self._t("stage"): ...  accumulates wall time into self.timing[stage] when timing is enabled."""
+        import contextlib
+        import time
+        if self.timing is None:
+            return contextlib.nullcontext()
+        rp = self
+
+        class _Timer:
+            def __enter__(self_):
+                self_.t0 = time.perf_counter()
+
+            def __exit__(self_, *exc):
+                rp.timing[stage] = rp.timing.get(stage, 0.0) + time.perf_counter() - self_.t0
+                return False
+        return _Timer()
 
     # ---------------------------------------------------------------- helpers
     def lin(self, x, prefix):
@@ -63,58 +81,64 @@ class RefPath:
         N, Nq = mask.shape
         S = H * W
         D = dist_flat.shape[-1]
-        indexes = [mask[i].nonzero().squeeze(-1) for i in range(N)]            # :759-762
-        max_len = max(len(ix) for ix in indexes)
-        ref_rebatch = torch.zeros(N, max_len, 1, 3)                           # :766-773
-        for i, ix in enumerate(indexes):
-            ref_rebatch[i, :len(ix), 0] = ref_cam[i, ix]
+        with self._t("project_compact"):
+            indexes = [mask[i].nonzero().squeeze(-1) for i in range(N)]            # :759-762
+            max_len = max(len(ix) for ix in indexes)
+            ref_rebatch = torch.zeros(N, max_len, 1, 3)                           # :766-773
+            for i, ix in enumerate(indexes):
+                ref_rebatch[i, :len(ix), 0] = ref_cam[i, ix]
         shapes3 = torch.tensor([[H, W, D]], dtype=torch.int64)
         lsi = torch.zeros(1, dtype=torch.int64)
         # Grid_Sample_3D_Feature (:67-116): one head, one point, weight one, replicated depth
         loc = ref_rebatch.view(N, max_len, 1, 1, 1, 3).contiguous()
         ones = torch.ones(N, max_len, 1, 1, 1)
-        q_img, _ = self.ops.dfa3d_forward(feat_flat.view(N, S, 1, C).contiguous(), dist_flat.view(N, S, 1, D).contiguous(),
-                                          shapes3, lsi, loc, ones)
+        with self._t("geometry_sample"):
+            q_img, _ = self.ops.dfa3d_forward(feat_flat.view(N, S, 1, C).contiguous(), dist_flat.view(N, S, 1, D).contiguous(),
+                                              shapes3, lsi, loc, ones)
         da = pre + ".deformable_attention"
         # MSDeformableAttention3D_DFA3D.forward (:364-501)
-        value = self.lin(feat_flat, da + ".value_proj").view(N, S, M, C // M).contiguous()
-        dist_rep = dist_flat.view(N, S, 1, D).repeat(1, 1, M, 1).contiguous()  # :422
-        off_uv = self.lin(q_img, da + ".sampling_offsets").view(N, max_len, M, 1, P, 2)
-        off_d = self.lin(q_img, da + ".sampling_offsets_depth").view(N, max_len, M, 1, P, 1)
-        offs = torch.cat([off_uv, off_d], -1)
-        attn = self.lin(q_img, da + ".attention_weights").view(N, max_len, M, P).softmax(-1).view(N, max_len, M, 1, P)
-        normalizer = torch.tensor([[W, H, D]], dtype=torch.int64)
-        offs = offs / normalizer[None, None, None, :, None, :]
-        loc = (ref_rebatch[:, :, None, None, None, :, :] + offs.view(N, max_len, M, 1, P, 1, 3)).view(N, max_len, M, 1, P, 3)
-        queries, _ = self.ops.dfa3d_forward(value, dist_rep, shapes3, lsi, loc.contiguous(), attn.contiguous())
+        with self._t("gemms"):
+            value = self.lin(feat_flat, da + ".value_proj").view(N, S, M, C // M).contiguous()
+            dist_rep = dist_flat.view(N, S, 1, D).repeat(1, 1, M, 1).contiguous()  # :422
+            off_uv = self.lin(q_img, da + ".sampling_offsets").view(N, max_len, M, 1, P, 2)
+            off_d = self.lin(q_img, da + ".sampling_offsets_depth").view(N, max_len, M, 1, P, 1)
+            offs = torch.cat([off_uv, off_d], -1)
+            attn = self.lin(q_img, da + ".attention_weights").view(N, max_len, M, P).softmax(-1).view(N, max_len, M, 1, P)
+            normalizer = torch.tensor([[W, H, D]], dtype=torch.int64)
+            offs = offs / normalizer[None, None, None, :, None, :]
+            loc = (ref_rebatch[:, :, None, None, None, :, :] + offs.view(N, max_len, M, 1, P, 1, 3)).view(N, max_len, M, 1, P, 3)
+        with self._t("deform_gather"):
+            queries, _ = self.ops.dfa3d_forward(value, dist_rep, shapes3, lsi, loc.contiguous(), attn.contiguous())
         # dense slots, masked mean, attention over views (:815-837)
-        slots = torch.zeros(N, 1, Nq, C)
-        for i, ix in enumerate(indexes):
-            slots[i, 0, ix] = queries[i, :len(ix)]
-        count = mask.sum(0)
-        valid_index = count.nonzero()[:, 0]
-        valid_slots = slots[:, :, valid_index, :]
-        valid_mask = mask[:, None, valid_index, None]
-        mean = (valid_slots * valid_mask).sum(dim=0) / count[None, valid_index, None]
-        mean = self.lin(mean, pre + ".output_proj")
-        mha = pre + ".attention_pooling"
-        pooled, _ = F.multi_head_attention_forward(
-            mean, valid_slots.squeeze(1), valid_slots.squeeze(1), C, 8,
-            self.sd[mha + ".in_proj_weight"], self.sd[mha + ".in_proj_bias"], None, None, False, 0.0,
-            self.sd[mha + ".out_proj.weight"], self.sd[mha + ".out_proj.bias"], training=False,
-            key_padding_mask=~mask[:, valid_index].t(), need_weights=True)
-        out = torch.zeros(1, Nq, C)
-        out[:, valid_index, :] = pooled
+        with self._t("view_pooling"):
+            slots = torch.zeros(N, 1, Nq, C)
+            for i, ix in enumerate(indexes):
+                slots[i, 0, ix] = queries[i, :len(ix)]
+            count = mask.sum(0)
+            valid_index = count.nonzero()[:, 0]
+            valid_slots = slots[:, :, valid_index, :]
+            valid_mask = mask[:, None, valid_index, None]
+            mean = (valid_slots * valid_mask).sum(dim=0) / count[None, valid_index, None]
+            mean = self.lin(mean, pre + ".output_proj")
+            mha = pre + ".attention_pooling"
+            pooled, _ = F.multi_head_attention_forward(
+                mean, valid_slots.squeeze(1), valid_slots.squeeze(1), C, 8,
+                self.sd[mha + ".in_proj_weight"], self.sd[mha + ".in_proj_bias"], None, None, False, 0.0,
+                self.sd[mha + ".out_proj.weight"], self.sd[mha + ".out_proj.bias"], training=False,
+                key_padding_mask=~mask[:, valid_index].t(), need_weights=True)
+            out = torch.zeros(1, Nq, C)
+            out[:, valid_index, :] = pooled
         return out                                                            # dropout(0) + zero queries
 
     def layer(self, pre, feat_flat, dist_flat, H, W, ref_cam, mask):
         """VoxFormerLayer, order cross_attn -> norm -> ffn -> norm (encoder.py:310-338)."""
         C = self.cfg["embed_dims"]
         x = self.cross_attention(pre + ".attentions.0", feat_flat, dist_flat, H, W, ref_cam, mask)
-        x = F.layer_norm(x, (C,), self.sd[pre + ".norms.0.weight"], self.sd[pre + ".norms.0.bias"])
-        h = F.relu(self.lin(x, pre + ".ffns.0.layers.0.0"))
-        x = x + self.lin(h, pre + ".ffns.0.layers.1")
-        return F.layer_norm(x, (C,), self.sd[pre + ".norms.1.weight"], self.sd[pre + ".norms.1.bias"])
+        with self._t("ln_ffn"):
+            x = F.layer_norm(x, (C,), self.sd[pre + ".norms.0.weight"], self.sd[pre + ".norms.0.bias"])
+            h = F.relu(self.lin(x, pre + ".ffns.0.layers.0.0"))
+            x = x + self.lin(h, pre + ".ffns.0.layers.1")
+            return F.layer_norm(x, (C,), self.sd[pre + ".norms.1.weight"], self.sd[pre + ".norms.1.bias"])
 
     def dense_head(self, i, feat, dpt, img_meta, proposal=None):
         """DenseHead.forward (DenseHead.py:50-84). feat [1,N,C,h,w], dpt [1,N,D,h,w]."""
@@ -127,9 +151,11 @@ class RefPath:
         idx = torch.nonzero(proposal > 0).view(-1)
         ref3d = self.sd[pre + ".ref_3d"][self.sd[pre + ".vox_coords"][idx, 3]]
         _, N, _, h, w = feat.shape
-        feat_flat = feat[0].flatten(2).permute(0, 2, 1).contiguous()          # transformer.py:154-169
-        dist_flat = dpt[0].flatten(2).permute(0, 2, 1).contiguous()
-        ref_cam, mask = self.project(ref3d.float(), img_meta)
+        with self._t("flatten_permute"):
+            feat_flat = feat[0].flatten(2).permute(0, 2, 1).contiguous()          # transformer.py:154-169
+            dist_flat = dpt[0].flatten(2).permute(0, 2, 1).contiguous()
+        with self._t("project_compact"):
+            ref_cam, mask = self.project(ref3d.float(), img_meta)
         x = self.layer(pre + ".cross_transformer.encoder.layers.0", feat_flat, dist_flat, h, w, ref_cam, mask.bool())
         vol = torch.zeros(n_vox, C)
         vol[idx] = x[0]
@@ -150,11 +176,12 @@ class RefPath:
             if i == 0:
                 v, a = self.dense_head(0, feat, dpt, img_meta)
             else:
-                up = F.interpolate(volumes[-1], scale_factor=2, mode="trilinear", align_corners=False)
-                occ = torch.sigmoid(self.lin(up.permute(0, 2, 3, 4, 1), f"occ_pred_heads.{i - 1}.0")).reshape(1, -1)
-                occ_list.append(occ)
-                _, top = torch.topk(occ, k=self.cfg["topk_list"][i - 1], dim=1)
-                mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
+                with self._t("upsample_occ_topk"):
+                    up = F.interpolate(volumes[-1], scale_factor=2, mode="trilinear", align_corners=False)
+                    occ = torch.sigmoid(self.lin(up.permute(0, 2, 3, 4, 1), f"occ_pred_heads.{i - 1}.0")).reshape(1, -1)
+                    occ_list.append(occ)
+                    _, top = torch.topk(occ, k=self.cfg["topk_list"][i - 1], dim=1)
+                    mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
                 v, a = self.dense_head(i, feat, dpt, img_meta, proposal=mask)
                 a["occ"] = occ
                 v = up + v
@@ -166,6 +193,19 @@ class RefPath:
         if return_aux:
             return volumes[-1], valid, occ_preds, aux, volumes
         return volumes[-1], valid, occ_preds
+
+    def coarse_topk_gap(self, mlvl_feats, img_meta, mlvl_dpt_dists):
+        """Gap between the k-th and (k+1)-th occupancy score at the FIRST top-k of AdaptiveSparseHead (levels 0 and 1
+        only: cheap).  A gap at rounding-noise level means two correct fp32 implementations may refine different voxels."""
+        n_lvl = len(self.cfg["n_voxels_list"])
+        ds = 4 * (2 ** (n_lvl - 1))
+        h, w = img_meta["img_shape"][0] // ds, img_meta["img_shape"][1] // ds
+        v0, _ = self.dense_head(0, mlvl_feats[n_lvl - 1][:, :, :, :h, :w], mlvl_dpt_dists[n_lvl - 1][:, :, :, :h, :w], img_meta)
+        up = F.interpolate(v0, scale_factor=2, mode="trilinear", align_corners=False)
+        occ = torch.sigmoid(self.lin(up.permute(0, 2, 3, 4, 1), "occ_pred_heads.0.0")).flatten()
+        srt = occ.sort(descending=True).values
+        k = self.cfg["topk_list"][0]
+        return float(srt[k - 1] - srt[k])
 
     # ---------------------------------------------------------------- neck + head
     def _bn(self, x, pre):

@@ -21,11 +21,16 @@
  * rows are pinned directly: sgc_aligned_nms3d against kept indices of the reference's
  * own aligned_3d_nms (tests/golden/make_golden_nms.py), sgc_plane_sweep_corr against the
  * correlation volume of the reference's own homo_warping loop
- * (tests/golden/make_golden_planesweep.py).  sgc_nms_rotated_bev / sgc_box_iou_rotated
- * restate mmcv-full 1.5.3's nms_rotated, a pip dependency that is neither vendored in
- * the reference nor installed here: PARITY UNPINNED against mmcv; the class-loop glue
- * around it is pinned to the reference's own box3d_multiclass_nms / nms_bev and the IoU
- * is cross-checked against a float64 polygon clip (tests/golden/make_golden_nms_rotated.py).
+ * (tests/golden/make_golden_planesweep.py).  sgc_box_iou_rotated (the IoU inside
+ * sgc_nms_rotated_bev) restates box_iou_rotated_utils.hpp, which the reference DOES carry:
+ * the DFA3D package vendors mmcv's header (CS/common/box_iou_rotated_utils.hpp).  It is plain
+ * C++, so oracle/Makefile's `_ref` target compiles it with g++ from where it lies
+ * (oracle/_ref/libref_box_iou.so, its __CUDACC__ branch = what the GPU NMS of the reference
+ * executes) and tests/golden/make_golden_iou.py turns it into box_iou_rotated.npz: PINNED to
+ * 1e-6 (tests/test_oracle_golden.py).  The greedy suppression loop around it restates
+ * mmcv-full 1.5.3's nms_rotated_cuda.cuh (mask = IoU > thr, then a sweep; that file is not in
+ * the reference tree); the class-loop glue is pinned to the reference's own
+ * box3d_multiclass_nms / nms_bev (tests/golden/make_golden_nms_rotated.py).
  *
  * Reference files restated (paths relative to /root/reference; CS = packages/
  * 3D-deformable-attention/DFA3D/dfa3D/ops/csrc):
@@ -37,7 +42,8 @@
  *   target assignment mmdet3d_plugin/models/dense_heads/imvoxel_head_v2.py:334-343,361-435,485-561
  *                    (pinned: tests/golden/make_golden_targets.py runs the reference's own get_targets)
  *   rotated BEV NMS  packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:52-68,231-268
- *                    (+ mmcv-full 1.5.3 box_iou_rotated_utils.hpp / nms_rotated_cuda.cuh, published algorithm)
+ *                    + CS/common/box_iou_rotated_utils.hpp:55-341 (the IoU; built as oracle/_ref) and mmcv-full
+ *                    1.5.3's nms_rotated_cuda.cuh (the suppression sweep; published algorithm, not in the tree)
  *   plane sweep      mmdet3d_plugin/models/im2voxel/depth_utils/depth_est_fusion.py:87-126,233-240
  *
  * All arithmetic is fp32 in the reference's operation order; compile with
@@ -98,7 +104,7 @@ int sgc_depth_score_forward(const float *dist, const int64_t *shapes3, const int
                             int B, int S, int M, int D, int L, int Q, int P, sgc_stream_t stream) {
   (void)stream;
   if (!dist || !shapes3 || !lsi || !loc3 || !score) return fail(SGC_EINVAL, "null pointer");
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(dynamic, 32)
   for (int b = 0; b < B; ++b)
     for (int q = 0; q < Q; ++q)
       for (int m = 0; m < M; ++m) {
@@ -140,7 +146,7 @@ int sgc_wms_forward(const float *value, const int64_t *shapes2, const int64_t *l
   if (!value || !shapes2 || !lsi || !loc2 || !attn || !score || !out)
     return fail(SGC_EINVAL, "null pointer");
   const int MC = M * Cm;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(dynamic, 32)
   for (int b = 0; b < B; ++b)
     for (int q = 0; q < Q; ++q)
       for (int m = 0; m < M; ++m) {
@@ -311,7 +317,7 @@ int sgc_dfa3d_forward(const float *value, const float *dist, const int64_t *shap
   if (!value || !dist || !shapes3 || !lsi || !loc3 || !out) return fail(SGC_EINVAL, "null pointer");
   if (dist_heads != 1 && dist_heads != M) return fail(SGC_EINVAL, "dist_heads must be 1 or M");
   const int MC = M * Cm;
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(dynamic, 32)
   for (int b = 0; b < B; ++b)
     for (int q = 0; q < Q; ++q)
       for (int m = 0; m < M; ++m) {
@@ -487,7 +493,7 @@ int sgc_pairs_geometry_sample(const float *feat, const float *dist, const float 
   if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
   if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
   const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;   /* pixels between cameras */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 64)
   for (int i = 0; i < np; ++i) {
     const int n = pair_cam[i], q = pair_q[i];
     const float *r = ref_cam + ((int64_t)n * Nq + q) * 3;
@@ -537,7 +543,7 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
   if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
   const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;   /* pixels between cameras */
   const int MC = M * Cm, MP = M * P;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 64)
   for (int i = 0; i < np; ++i) {
     const int n = pair_cam[i], q = pair_q[i];
     const float *r = ref_cam + ((int64_t)n * Nq + q) * 3;
@@ -1010,13 +1016,12 @@ int sgc_aligned_nms3d(const float *boxes, const int64_t *order, const int64_t *l
 
 
 /* ---- 8b. rotated BEV NMS: mmdet3d nms_bev (box3d_nms.py:231-268) -> mmcv.ops.nms_rotated -------------------
- * mmcv-full 1.5.3 is a pip dependency of the reference (docs/install.md:6) and is NOT vendored: what follows
- * restates its published algorithm (mmcv/ops/csrc/common/box_iou_rotated_utils.hpp: get_rotated_vertices,
- * get_intersection_points, convex_hull_graham [device branch: O(n^2) exchange sort], polygon_area,
- * single_box_iou_rotated; mmcv/ops/csrc/common/cuda/nms_rotated_cuda.cuh: mask = IoU(row, col) > thr for
- * col after row in descending score; host sweep) in T = float exactly as the CUDA kernel instantiates it.
- * PARITY UNPINNED against mmcv itself (not importable here); cross-checked in tests/ against an independent
- * float64 polygon clip.                                                                                    */
+ * The IoU follows the reference's own copy of mmcv's header, CS/common/box_iou_rotated_utils.hpp (get_rotated_vertices
+ * :55-72, get_intersection_points :74-156, convex_hull_graham :158-261 [its __CUDACC__ branch: the O(n^2) exchange
+ * sort the GPU kernels run], polygon_area :263-275, single_box_iou_rotated :307-341) in T = float as the CUDA kernel
+ * instantiates it; PINNED to that header built with g++ (oracle/_ref, tests/golden/box_iou_rotated.npz, <= 1e-6).
+ * The suppression itself restates mmcv-full 1.5.3's nms_rotated_cuda.cuh (mask = IoU(row, col) > thr for col after
+ * row in descending score; host sweep) -- that file is a pip dependency (docs/install.md:6), not in the tree.   */
 typedef struct { float x, y; } rpt_t;
 static inline float rcross(rpt_t a, rpt_t b) { return a.x * b.y - b.x * a.y; }
 static inline float rdot(rpt_t a, rpt_t b) { return a.x * b.x + a.y * b.y; }

@@ -1,7 +1,8 @@
 // Rotated BEV NMS for all classes of a scene in two launches == the class loop of mmdet3d `box3d_multiclass_nms`
 // (packages/mmdetection3d/mmdet3d/core/post_processing/box3d_nms.py:52-68) over `nms_bev` (:231-268) ->
-// mmcv.ops.nms_rotated (mmcv-full 1.5.3, not vendored in the reference: box_iou_rotated_utils.hpp,
-// nms_rotated_cuda.cuh); called from SunRgbdImVoxelHeadV2._nms (imvoxel_head_v2.py:565-584, ARKit configs:
+// mmcv.ops.nms_rotated (the IoU: box_iou_rotated_utils.hpp, which the reference's DFA3D package vendors under
+// packages/3D-deformable-attention/DFA3D/dfa3D/ops/csrc/common/ -- tests pin this file to a g++ build of it,
+// tests/golden/box_iou_rotated.npz; the sweep: mmcv-full 1.5.3 nms_rotated_cuda.cuh, a pip dependency); called from SunRgbdImVoxelHeadV2._nms (imvoxel_head_v2.py:565-584, ARKit configs:
 // score_thr 0, 17 classes x up to 3000 candidates each -- the reference launches 17 mask kernels, copies 17 bit
 // matrices to the host and sweeps them on the CPU).
 //   1. rnms_mask_kernel, grid (column block, row block, class): bit (p, q) = IoU(box at sorted position p, box at

@@ -11,8 +11,8 @@ losses of ``plugin/losses.py``.
 NMS (row f-4): ScanNet's ``aligned_3d_nms`` (mmdet3d, a Python while-loop in the reference) runs on the GPU
 (``sgc_aligned_nms3d``: one mask kernel + one sweep, same keep/drop arithmetic); ARKit's
 ``box3d_multiclass_nms`` + mmcv ``nms_rotated`` runs all classes in two launches (``sgc_nms_rotated_bev``: exact
-rotated-rectangle intersection in the reference kernel's fp32 operation order; mmcv is not vendored in the
-reference, so that restatement is unpinned against mmcv itself -- see the oracle's header).
+rotated-rectangle intersection in the reference kernel's fp32 operation order, pinned to the copy of mmcv's
+``box_iou_rotated_utils.hpp`` the reference carries in its DFA3D package -- tests/golden/box_iou_rotated.npz).
 """
 import torch
 from torch import nn

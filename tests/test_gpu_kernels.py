@@ -288,7 +288,12 @@ def test_rotated_nms_matches_reference_golden_and_oracle(oracle_ops, gpu_ops):
     check_multiclass_golden(gpu_ops, "cuda")
     check_iou_against_float64_clip(gpu_ops, "cuda")
     check_mask_sweep_equals_textbook_loop(gpu_ops, "cuda")
-    # pairwise IoU: the same fp32 operation order on both sides (cos / sin evaluated in double as the reference does)
+    # pairwise IoU against the REFERENCE's own header (its __CUDACC__ branch built with g++, tests/golden/make_golden_iou.py)
+    from golden_util import load
+    gd, _ = load("box_iou_rotated")
+    iou_ref = gpu_ops.box_iou_rotated(gd["a"].cuda(), gd["b"].cuda()).cpu()
+    assert (iou_ref - gd["iou"]).abs().max() <= 1e-6 and (iou_ref == gd["iou"]).float().mean() > 0.95
+    # and against the oracle at NMS size: the same fp32 operation order on both sides (cos / sin in double as the reference)
     boxes, scores = arkit_like(700, 3, seed=8)
     bev = bev_of(boxes)
     xywhr = torch.stack(((bev[:, 0] + bev[:, 2]) / 2, (bev[:, 1] + bev[:, 3]) / 2, bev[:, 2] - bev[:, 0],

@@ -132,12 +132,120 @@ def test_hot_path_against_oracle(name, n_views):
                    **{"head." + k: v for k, v in det.bbox_head.state_dict().items()}},
                   dict(head="scannet" if w["head"].startswith("ScanNet") else "sunrgbd", n_classes=w["n_classes"],
                        nms_pre=1000))
-    if res["tie_flips"]:      # a flipped voxel changes its neighbourhood through the 3x3x3 convs: compare the
-        return                # neck/head only when both sides refined exactly the same voxels
+    # neck + head: the HIP modules on the ORACLE's volume (a near-tie flip in the top-k changes a voxel's whole 3x3x3
+    # neighbourhood, so the product's own volume is only comparable when tie_flips == 0; the oracle's volume always is)
+    _check_neck_head_on(det, vol_c, rp2)
+    if res["tie_flips"] == 0:
+        feats3d = rp2.neck(vol_c, prefix="neck.")
+        ctr, reg, cls = rp2.head(feats3d, prefix="head.")
+        for a, b in zip(r["centerness"] + r["bbox_pred"] + r["cls_score"], ctr + reg + cls):
+            assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
+
+
+def _check_neck_head_on(det, vol_c, rp2):
+    """FastIndoorImVoxelNeck + ImVoxelHeadV2 of the product (HIP convolutions) against the oracle's torch-CPU
+    restatement on the SAME input volume: every head tensor within 1e-3 of its scale (north-star bar)."""
     feats3d = rp2.neck(vol_c, prefix="neck.")
     ctr, reg, cls = rp2.head(feats3d, prefix="head.")
-    for a, b in zip(r["centerness"] + r["bbox_pred"] + r["cls_score"], ctr + reg + cls):
+    with torch.no_grad():
+        outs = det._neck_head_eager(vol_c.cuda())
+    got = list(outs[0]) + list(outs[1]) + list(outs[2])
+    assert len(got) == len(ctr + reg + cls) == 9
+    for a, b in zip(got, ctr + reg + cls):
+        assert a.shape == b.shape
         assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
+
+
+def _neck_head_oracle(det, w):
+    from oracle.ref_path import RefPath
+    return RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},
+                    **{"head." + k: v for k, v in det.bbox_head.state_dict().items()}},
+                   dict(head="scannet" if w["head"].startswith("ScanNet") else "sunrgbd", n_classes=w["n_classes"],
+                        nms_pre=1000))
+
+
+@pytest.mark.parametrize("name,img_hw", [("cfg3_arkit", None), ("cfg4_scannet200_large", None), ("cfg5_arkit_large", None)])
+def test_full_view_count_scenes_against_the_oracle(name, img_hw):
+    """BASELINE.json configs[2..4] at their FULL view counts (60 / 50 / 100 views; 48x48x16, 80x80x32 with 189
+    classes, 96x96x32) -- GPU vs the OpenMP build of the oracle: selected voxel sets identical up to near ties at the
+    cut, voxel features and occupancy within 1e-3, and neck + head (HIP) on the oracle's volume within 1e-3.
+    These are the C = 128 (Cm = 16) shapes of the LDS-tiled gather at full pair counts (0.8 M / 2.4 M pairs)."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from oracle.ref_path import RefPath
+    from oracle.compare import check_sparse_head, topk_cut
+    w = workload(name)
+    torch.manual_seed(23)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(29)
+    with torch.no_grad():
+        for n, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.02)
+    rp = RefPath(det.voxel_head.state_dict(), dict(embed_dims=w["embed_dims"], n_voxels_list=w["n_voxels_list"],
+                                                   voxel_size_list=w["voxel_size_list"], topk_list=w["topk_list"],
+                                                   dbound=(0.2, 5.0), num_heads=8, num_points=4), omp=True)
+    # top-k is discontinuous in the fp32 scores.  Whether the coarse cut of a scene is resolvable (gap above rounding
+    # noise) is a property of the oracle's scene, decided here on the CPU from levels 0-1 only; the first resolvable
+    # seed of a fixed list is used, else the last one (then only the tie-independent checks below apply)
+    gaps = []
+    for seed in (31, 32, 33, 34):
+        feats, dpt, meta = make_scene(w["n_views"], w["embed_dims"], kind=w["kind"], seed=seed, img_hw=img_hw)
+        gaps.append((seed, rp.coarse_topk_gap(feats, meta, depth_pyramid(dpt))))
+        if gaps[-1][1] > 2e-6:
+            break
+    vol_c, valid_c, occ_c, aux, volumes_c = rp.adaptive_sparse_head(feats, meta, depth_pyramid(dpt), return_aux=True)
+    det = det.cuda()
+    # (1) level by level, every level fed with the ORACLE's previous volume and the ORACLE's selection: every kernel of
+    #     the view transform at full size, independent of how a top-k tie is broken
+    _check_levels_against_oracle(det.voxel_head, [f.cuda() for f in feats], meta, [t.cuda() for t in depth_pyramid(dpt)],
+                                 aux, volumes_c)
+    # (2) end to end.  top-k is discontinuous in the fp32 scores: with 9 216 of 36 864 coarse candidates (config 5) the
+    #     gap at the coarse cut is routinely ~1e-7, i.e. rounding noise decides which voxel is refined and the two
+    #     volumes then legitimately differ around it.  Whether the cut is resolvable is a property of the oracle's
+    #     scene, decided here on the CPU; the voxel-by-voxel comparison runs when it is, the structural checks always.
+    with torch.no_grad():
+        r = det.forward_features([f.cuda() for f in feats], [meta], dpt.cuda())
+    n_fin = w["n_voxels_list"][-1][0] * w["n_voxels_list"][-1][1] * w["n_voxels_list"][-1][2]
+    assert int(r["valid"].sum()) == w["topk_list"][1]
+    assert (r["occ"].cpu()[0, n_fin:] - occ_c[0, n_fin:]).abs().max() < 1e-4          # coarse occupancy: no top-k upstream
+    gap = topk_cut(aux[1]["occ"], w["topk_list"][0])[1]
+    if gap > 2e-6:
+        res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"])
+        assert res["tie_flips"] <= max(8, n_fin // 20000), res
+    else:
+        import warnings
+        warnings.warn(f"{name}: coarse top-k gaps of seeds {gaps} are at rounding-noise level; end-to-end voxel comparison "
+                      "skipped, level-wise comparison done")
+    # (3) neck + head (HIP convolutions) on the oracle's volume
+    _check_neck_head_on(det, vol_c, _neck_head_oracle(det, w))
+
+
+def _check_levels_against_oracle(head, feats, meta, dpts, aux, volumes_c):
+    """AdaptiveSparseHead level by level on the GPU with the oracle's inputs per level: dense level 0; then for every
+    finer level the fused trilinear x2 + occupancy kernel on the ORACLE's previous volume (occupancy within 1e-5) and
+    the level's DenseHead on the ORACLE's selected voxels, `upsampled + refined` within 1e-3 of the oracle's volume."""
+    from sgcdet_amd import ext
+    ops = ext.ops()
+    C = head.embed_dims
+    with torch.no_grad():
+        feat, dpt = head._level_inputs(0, feats, meta, dpts)
+        rows = head.base_heads[0].seed_rows([feat], meta, None, mlvl_dpt_dists=[dpt])
+        vc = volumes_c[0][0].permute(1, 2, 3, 0).reshape(-1, C)
+        assert max_err(rows, vc) < 1e-3 * max(1.0, vc.abs().max().item())
+        for i in range(1, len(head.base_heads)):
+            prev = volumes_c[i - 1]
+            grid = tuple(prev.shape[2:])
+            prev_rows = prev[0].permute(1, 2, 3, 0).reshape(-1, C).contiguous().cuda()
+            lin = head.occ_pred_heads[i - 1][0]
+            up, occ, grid = ops.upsample2x_occ(prev_rows, grid, lin.weight.reshape(-1), lin.bias)
+            assert max_err(occ, aux[i]["occ"].reshape(-1)) < 1e-5
+            idx = aux[i]["idx"].cuda()
+            feat, dpt = head._level_inputs(i, feats, meta, dpts)
+            seed = head.base_heads[i].seed_rows([feat], meta, idx, mlvl_dpt_dists=[dpt])
+            ops.scatter_add_rows(seed.contiguous(), idx, up)
+            vc = volumes_c[i][0].permute(1, 2, 3, 0).reshape(-1, C)
+            assert max_err(up, vc) < 1e-3 * max(1.0, vc.abs().max().item()), i
 
 
 def test_full_size_config2_scene_against_the_oracle():
@@ -167,6 +275,8 @@ def test_full_size_config2_scene_against_the_oracle():
     res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, 40 * 40 * 16, w["topk_list"])
     assert res["tie_flips"] <= 8, res
     assert int(r["valid"].sum()) == 6400
+    # neck + head at full size (490 + 5 GFLOP): HIP convolutions on the oracle's volume vs torch-CPU conv3d
+    _check_neck_head_on(det, vol_c, _neck_head_oracle(det, w))
 
 
 def test_training_path_gradients_match_oracle_backward():
