@@ -111,8 +111,13 @@ def cpu_baseline(w, n_views, seed):
     except OSError:
         gomp = None
 
+    # torch's CPU ops (MHA over views, slot scatter, LayerNorm ...) get SLOWER beyond a few dozen threads on the 256-core
+    # GPU hosts (measured: view pooling 1.1 s on 1 thread, 26.7 s on 256): torch intra-op threads are capped at 32, the
+    # oracle's own OpenMP kernels use every core
+    torch_cap = int(os.environ.get("SGC_CPU_TORCH_THREADS", 32))
+
     def set_threads(n):
-        torch.set_num_threads(n)
+        torch.set_num_threads(max(1, min(n, torch_cap)))
         if gomp is not None:
             gomp.omp_set_num_threads(n)
 
@@ -151,8 +156,9 @@ def cpu_baseline(w, n_views, seed):
 
     n, dt, stages = run(all_cores, 12.0, 64)
     out = dict(value=n / dt, unit="scenes/sec", cores=all_cores, kind="port",
-               sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels + "
-                      f"torch-CPU), {dt:.1f} s", stages_ms_per_scene=stages)
+               sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels on "
+                      f"{all_cores} threads + torch-CPU ops on {min(all_cores, torch_cap)}), {dt:.1f} s",
+               stages_ms_per_scene=stages)
     if all_cores > 1 and not os.environ.get("SGC_CPU_SKIP_1T"):
         n1, dt1, stages1 = run(1, 0.0, 1)               # one scene on one thread (tens of seconds at config 2)
         out["one_thread"] = dict(value=n1 / dt1, unit="scenes/sec", cores=1,

@@ -148,12 +148,14 @@ int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *sha
  *     the per-camera nonzero / rebatch loops, TU/deformable_cross_attention.py:759-773)
  * ------------------------------------------------------------------------- */
 
-/* ref3d [Nq,3] voxel reference points (DenseHead.ref_3d rows of the selected voxels,
- * WITHOUT origin), origin[3], proj [N,3,4] = (K' @ E_i[:3]) -- all device fp32.
- * ref_cam [N,Nq,3] OUT = (u/img_w, v/img_h, (z-d_near)/(d_far-d_near));
- * mask [N,Nq] uint8 OUT = z>eps & eps<u<1-eps & eps<v<1-eps  (eps = 1e-5).
+/* ref3d [Nvox,3] voxel reference points (DenseHead.ref_3d, WITHOUT origin); sel_or_null [Nq] int64: the q-th query
+ * is voxel sel[q] (DenseHead.py:66 + transformer.py:145-146 gather; NULL: query q = row q, Nvox = Nq);
+ * origin[3], proj [N,3,4] = (K' @ E_i[:3]) -- all device fp32.
+ * ref_cam [N,Nq,3] OUT = (u/img_w, v/img_h, zn = (z-d_near)/(d_far-d_near));
+ * mask [N,Nq] uint8 OUT = zn>eps & eps<u<1-eps & eps<v<1-eps  (eps = 1e-5; the reference's depth test runs on the
+ * slice it has already overwritten with zn, TU/encoder.py:203-213).
  * Arithmetic order is fixed and documented in DESIGN.md (no FMA contraction).      */
-int sgc_project_points(const float *ref3d, const float *origin, const float *proj,
+int sgc_project_points(const float *ref3d, const int64_t *sel_or_null, const float *origin, const float *proj,
                        float *ref_cam, uint8_t *mask,
                        int N, int Nq, float img_w, float img_h, float d_near, float d_far,
                        sgc_stream_t stream);
@@ -302,9 +304,11 @@ int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_
 
 /* NCHW -> NHWC crop-and-transpose of the FPN / depth maps
  * (TU/transformer.py:151-170 flatten+permute, AdaptiveSparseHead.py:53-59 crop):
- *   src [N,C,Hs,Ws] -> dst [N,H*W,C] taking rows < H, cols < W.                     */
+ *   src [N,C,Hs,Ws] -> dst [N,H*W,C], dst[n, h*W + w, c] = src[n, c, h*step, w*step] for h < H, w < W.
+ *   step 2 / 4 reads the x1/2, x1/4 nearest-neighbour copies of the depth distribution (SGCDet.py:83-85) straight
+ *   from the full-resolution map: they are never materialised.                                     */
 int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
-                          int H, int W, sgc_stream_t stream);
+                          int H, int W, int step, sgc_stream_t stream);
 
 /* Coarse-to-fine glue of AdaptiveSparseHead on channels-last volumes (AdaptiveSparseHead.py:64-82):
  *   up [8*ix*iy*iz, C] = trilinear x2 upsample of vol [ix*iy*iz, C] (F.interpolate, align_corners=False);
@@ -383,6 +387,25 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
  *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128.            */
 int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                      float *y, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * 7b. Row-wise glue of the coarse-to-fine head (no library kernels inside the scene graphs)
+ * ------------------------------------------------------------------------- */
+
+/* Hard top-k selection == topk_wo_grad + nonzero + get_valid (AdaptiveSparseHead.py:9-13,74,95-98; DenseHead.py:66):
+ *   score [n] fp32 (occupancy of every voxel), 0 < k <= n;
+ *   OUT idx_out [k] int64: flat indices of the k largest scores in ASCENDING index order (= nonzero(mask));
+ *   OUT valid_or_null [n] int64 {0,1}, mask_or_null [n] fp32 {0,1}: the selection as a dense mask.
+ * Ties at the cut are broken by the lowest flat index (torch.topk leaves that order implementation-defined; NaN
+ * counts as the largest value, as in torch).  One launch, one workgroup, deterministic.                          */
+int sgc_topk_select(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
+                    sgc_stream_t stream);
+
+/* nn.LayerNorm(C) over the first min(rows_cap, *rows_dev_or_null) rows of x [rows_cap, C] (the two norms of
+ * VoxFormerLayer, TU/encoder.py:311-338): y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance,
+ * fp32 two-pass statistics.  y may alias x.                                                                    */
+int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
+                        const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 8. Post-processing

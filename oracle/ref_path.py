@@ -180,8 +180,10 @@ class RefPath:
                     up = F.interpolate(volumes[-1], scale_factor=2, mode="trilinear", align_corners=False)
                     occ = torch.sigmoid(self.lin(up.permute(0, 2, 3, 4, 1), f"occ_pred_heads.{i - 1}.0")).reshape(1, -1)
                     occ_list.append(occ)
-                    _, top = torch.topk(occ, k=self.cfg["topk_list"][i - 1], dim=1)
-                    mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
+                    # topk_wo_grad (AdaptiveSparseHead.py:9-13): torch.topk's order among EQUAL scores is implementation-
+                    # defined and voxels no camera sees carry bit-identical scores, so the tie rule is pinned here
+                    # (lowest flat index first) -- the same set as torch.topk whenever the cut is not an exact tie
+                    _, _, mask = self.ops.topk_select(occ.contiguous(), self.cfg["topk_list"][i - 1], want_mask=True)
                 v, a = self.dense_head(i, feat, dpt, img_meta, proposal=mask)
                 a["occ"] = occ
                 v = up + v

@@ -422,7 +422,7 @@ int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *sha
  *   den = max(cam_z, eps);  u = (cam_x/den) * (1/img_w);  v = (cam_y/den) * (1/img_h);
  *   zn = (cam_z - d_near) * (1/(d_far - d_near))
  * (torch's GPU `tensor / python_scalar` multiplies by the fp32 reciprocal).         */
-int sgc_project_points(const float *ref3d, const float *origin, const float *proj,
+int sgc_project_points(const float *ref3d, const int64_t *sel_or_null, const float *origin, const float *proj,
                        float *ref_cam, uint8_t *mask,
                        int N, int Nq, float img_w, float img_h, float d_near, float d_far,
                        sgc_stream_t stream) {
@@ -434,7 +434,8 @@ int sgc_project_points(const float *ref3d, const float *origin, const float *pro
   for (int n = 0; n < N; ++n) {
     const float *Pm = proj + (int64_t)n * 12;
     for (int q = 0; q < Nq; ++q) {
-      const float x = ref3d[q * 3] + origin[0], y = ref3d[q * 3 + 1] + origin[1], z = ref3d[q * 3 + 2] + origin[2];
+      const int64_t r = sel_or_null ? sel_or_null[q] : q;
+      const float x = ref3d[r * 3] + origin[0], y = ref3d[r * 3 + 1] + origin[1], z = ref3d[r * 3 + 2] + origin[2];
       float cam[3];
       for (int r = 0; r < 3; ++r) cam[r] = ((Pm[r * 4] * x + Pm[r * 4 + 1] * y) + Pm[r * 4 + 2] * z) + Pm[r * 4 + 3];
       const float den = fmaxf(cam[2], eps);
@@ -767,15 +768,15 @@ int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_
 }
 
 int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
-                          int H, int W, sgc_stream_t stream) {
+                          int H, int W, int step, sgc_stream_t stream) {
   (void)stream;
   if (!src || !dst) return fail(SGC_EINVAL, "null pointer");
-  if (H > Hs || W > Ws) return fail(SGC_EINVAL, "crop larger than source");
+  if (step < 1 || (int64_t)(H - 1) * step >= Hs || (int64_t)(W - 1) * step >= Ws) return fail(SGC_EINVAL, "crop larger than source");
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < C; ++c)
       for (int h = 0; h < H; ++h)
         for (int w = 0; w < W; ++w)
-          dst[(((int64_t)n * H + h) * W + w) * C + c] = src[(((int64_t)n * C + c) * Hs + h) * Ws + w];
+          dst[(((int64_t)n * H + h) * W + w) * C + c] = src[(((int64_t)n * C + c) * Hs + (int64_t)h * step) * Ws + (int64_t)w * step];
   return SGC_OK;
 }
 
@@ -881,6 +882,60 @@ int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const
         y[(((r / S) * M + c / Cm) * S + r % S) * Cm + c % Cm] = tmp[r * C + c];
   free(tmp);
   return rc;
+}
+
+/* ---- 7b. top-k selection with a DEFINED tie rule, LayerNorm ------------------------------------------------ */
+typedef struct { float v; int32_t i; } topk_item_t;
+static int cmp_topk_item(const void *a, const void *b) {      /* value descending (NaN first), index ascending */
+  const topk_item_t *x = (const topk_item_t *)a, *y = (const topk_item_t *)b;
+  const int xn = x->v != x->v, yn = y->v != y->v;
+  if (xn != yn) return yn - xn;
+  if (!xn) {
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+  }
+  return (x->i > y->i) - (x->i < y->i);
+}
+
+/* topk_wo_grad + nonzero (AdaptiveSparseHead.py:9-13,74; DenseHead.py:66) with ties at the cut broken by the lowest
+ * flat index -- the rule the product's kernel implements (torch.topk's own tie order is implementation-defined) */
+int sgc_topk_select(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
+                    sgc_stream_t stream) {
+  (void)stream;
+  if (!score || !idx_out) return fail(SGC_EINVAL, "null pointer");
+  if (n <= 0 || k <= 0 || k > n) return fail(SGC_EINVAL, "need 0 < k <= n");
+  topk_item_t *it = (topk_item_t *)malloc(sizeof(topk_item_t) * (size_t)n);
+  uint8_t *sel = (uint8_t *)calloc((size_t)n, 1);
+  if (!it || !sel) { free(it); free(sel); return fail(SGC_EINVAL, "out of memory"); }
+  for (int i = 0; i < n; ++i) { it[i].v = score[i]; it[i].i = i; }
+  qsort(it, (size_t)n, sizeof(topk_item_t), cmp_topk_item);
+  for (int j = 0; j < k; ++j) sel[it[j].i] = 1;
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    if (sel[i]) idx_out[c++] = i;
+    if (valid_or_null) valid_or_null[i] = sel[i];
+    if (mask_or_null) mask_or_null[i] = sel[i] ? 1.f : 0.f;
+  }
+  free(it); free(sel);
+  return SGC_OK;
+}
+
+int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
+                        const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream) {
+  (void)stream;
+  if (!x || !gamma || !beta || !y) return fail(SGC_EINVAL, "null pointer");
+  int rows = rows_cap;
+  if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
+  for (int r = 0; r < rows; ++r) {
+    const float *xr = x + (int64_t)r * C;
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < C; ++c) s += xr[c];
+    const double mean = s / C;
+    for (int c = 0; c < C; ++c) q += (xr[c] - mean) * (xr[c] - mean);
+    const double rstd = 1.0 / sqrt(q / C + (double)eps);
+    for (int c = 0; c < C; ++c) y[(int64_t)r * C + c] = (float)((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+  }
+  return SGC_OK;
 }
 
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */

@@ -19,7 +19,7 @@ SIGNATURES = {
     "sgc_depth_score_backward": [_p] * 7 + [_i] * 7 + [_p],
     "sgc_dfa3d_forward": [_p] * 8 + [_i] * 9 + [_p],
     "sgc_dfa3d_backward": [_p] * 11 + [_i] * 9 + [_p],
-    "sgc_project_points": [_p] * 5 + [_i, _i, _f, _f, _f, _f, _p],
+    "sgc_project_points": [_p] * 6 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 9 + [_p],
     "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 12 + [_p],
@@ -31,10 +31,12 @@ SIGNATURES = {
     "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
-    "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 6 + [_p],
+    "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 7 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
+    "sgc_topk_select": [_p, _i, _i, _p, _p, _p, _p],
+    "sgc_layer_norm_rows": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
     "sgc_aligned_nms3d": [_p] * 3 + [_f] + [_p] * 3 + [_i] + [_p],
     "sgc_nms_rotated_bev": [_p] * 3 + [_f] + [_p] * 3 + [_i, _i] + [_p],
     "sgc_box_iou_rotated": [_p] * 3 + [_i, _i] + [_p],

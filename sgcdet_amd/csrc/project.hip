@@ -15,7 +15,8 @@ namespace sgc {
 //   zn = (cam_z - d_near) * (1/(d_far - d_near));  mask = zn > eps & eps < u < 1-eps & eps < v < 1-eps
 // torch's GPU `tensor / python_scalar` (TU/encoder.py:209-211) multiplies by the fp32
 // reciprocal, which is what rw/rh/rd reproduce.  The oracle uses the same order.
-__global__ void project_points_kernel(const float *__restrict__ ref3d, const float *__restrict__ origin,
+__global__ void project_points_kernel(const float *__restrict__ ref3d, const int64_t *__restrict__ sel,
+                                      const float *__restrict__ origin,
                                       const float *__restrict__ proj, float *__restrict__ ref_cam,
                                       uint8_t *__restrict__ mask, int N, int Nq, float rw, float rh,
                                       float d_near, float rd) {
@@ -25,9 +26,10 @@ __global__ void project_points_kernel(const float *__restrict__ ref3d, const flo
   if (q >= Nq) return;
   const float eps = 1e-5f;
   const float hi = 1.0f - eps;
-  const float x = ref3d[q * 3] + origin[0];
-  const float y = ref3d[q * 3 + 1] + origin[1];
-  const float z = ref3d[q * 3 + 2] + origin[2];
+  const int64_t r = sel ? sel[q] : q;             // the q-th query is voxel sel[q] (DenseHead.py:66, transformer.py:145-146)
+  const float x = ref3d[r * 3] + origin[0];
+  const float y = ref3d[r * 3 + 1] + origin[1];
+  const float z = ref3d[r * 3 + 2] + origin[2];
   const float *P = proj + (int64_t)n * 12;
   float cam[3];
 #pragma unroll
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(1024) void valid_index_kernel(const int32_t *__rest
 
 using namespace sgc;
 
-extern "C" int sgc_project_points(const float *ref3d, const float *origin, const float *proj,
+extern "C" int sgc_project_points(const float *ref3d, const int64_t *sel_or_null, const float *origin, const float *proj,
                                   float *ref_cam, uint8_t *mask,
                                   int N, int Nq, float img_w, float img_h, float d_near, float d_far,
                                   sgc_stream_t stream) {
@@ -149,7 +151,7 @@ extern "C" int sgc_project_points(const float *ref3d, const float *origin, const
   if (Nq == 0) return SGC_OK;
   const float rw = 1.0f / img_w, rh = 1.0f / img_h, rd = 1.0f / (d_far - d_near);
   hipLaunchKernelGGL(project_points_kernel, dim3(ceil_div(Nq, 256), N), dim3(256), 0, (hipStream_t)stream, ref3d,
-                     origin, proj, ref_cam, mask, N, Nq, rw, rh, d_near, rd);
+                     sel_or_null, origin, proj, ref_cam, mask, N, Nq, rw, rh, d_near, rd);
   return check_launch("project_points_kernel");
 }
 

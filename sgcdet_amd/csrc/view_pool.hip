@@ -139,7 +139,7 @@ __global__ void scatter_rows_kernel(const float *__restrict__ rows, const int32_
 // [N,C,Hs,Ws] -> [N,H*W,C] crop + transpose through a padded 32x33 LDS tile:
 // reads coalesced along w, writes coalesced along c.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                           int C, int Hs, int Ws, int H, int W) {
+                                                           int C, int Hs, int Ws, int H, int W, int step) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int p0 = blockIdx.x * 32;  // pixel tile over the cropped H*W
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
     float v = 0.f;
     if (c < C && px < HW) {
       const int h = px / W, w = px - h * W;
-      v = src[(((int64_t)n * C + c) * Hs + h) * Ws + w];
+      v = src[(((int64_t)n * C + c) * Hs + (int64_t)h * step) * Ws + (int64_t)w * step];
     }
     tile[j][tx] = v;
   }
@@ -329,18 +329,18 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel64(const float *__rest
 }  // namespace sgc
 
 extern "C" int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
-                                     int H, int W, sgc_stream_t stream) {
+                                     int H, int W, int step, sgc_stream_t stream) {
   if (!src || !dst) return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: null pointer");
-  if (H > Hs || W > Ws || N <= 0 || C <= 0 || H <= 0 || W <= 0)
+  if (step < 1 || (int64_t)(H - 1) * step >= Hs || (int64_t)(W - 1) * step >= Ws || N <= 0 || C <= 0 || H <= 0 || W <= 0)
     return set_error(SGC_EINVAL, "sgc_nchw_to_nhwc_crop: bad sizes");
   if (N > 65535) return set_error(SGC_EUNSUP, "sgc_nchw_to_nhwc_crop: N > 65535");
-  if (C % 64 == 0 && W % 4 == 0 && Ws % 4 == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
+  if (step == 1 && C % 64 == 0 && W % 4 == 0 && Ws % 4 == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15)) {
     hipLaunchKernelGGL(nchw_to_nhwc_kernel64, dim3(ceil_div(H * W, 64), C / 64, N), dim3(256), 0, (hipStream_t)stream, src,
                        dst, C, Hs, Ws, H, W);
     return check_launch("nchw_to_nhwc_kernel64");
   }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(256), 0,
-                     (hipStream_t)stream, src, dst, C, Hs, Ws, H, W);
+                     (hipStream_t)stream, src, dst, C, Hs, Ws, H, W, step);
   return check_launch("nchw_to_nhwc_kernel");
 }
 

@@ -46,6 +46,11 @@ class SGCDet(nn.Module):
             return [dpt_dist,
                     F.interpolate(dpt_dist[0], scale_factor=0.5, mode="nearest").unsqueeze(0),
                     F.interpolate(dpt_dist[0], scale_factor=0.25, mode="nearest").unsqueeze(0)]
+        if dpt_dist.is_cuda and not torch.is_grad_enabled() and dpt_dist.dim() == 5:
+            # nearest x1/2, x1/4 == every 2nd / 4th pixel (src index = floor(dst * 2)): strided VIEWS of the full-resolution
+            # map; the per-level crop + transpose kernel reads them in place (sgc_nchw_to_nhwc_crop, `step`)
+            H, W = dpt_dist.shape[-2:]
+            return [dpt_dist, dpt_dist[..., ::2, ::2][..., :H // 2, :W // 2], dpt_dist[..., ::4, ::4][..., :H // 4, :W // 4]]
         return [dpt_dist,
                 F.interpolate(dpt_dist, scale_factor=(1, 0.5, 0.5), mode="nearest"),
                 F.interpolate(dpt_dist, scale_factor=(1, 0.25, 0.25), mode="nearest")]

@@ -40,7 +40,11 @@ def trilinear_up2x(x):
 
 
 def topk_wo_grad(occ_preds_flatten, topk=10):
-    """Hard top-k mask, no gradient (AdaptiveSparseHead.py:9-13).  Ties follow torch.topk."""
+    """Hard top-k mask, no gradient (AdaptiveSparseHead.py:9-13).  On the GPU the selection runs in one HIP launch with
+    ties at the cut broken by the lowest flat index; elsewhere (CPU tensors) ties follow torch.topk."""
+    if occ_preds_flatten.is_cuda and occ_preds_flatten.dtype == torch.float32 and occ_preds_flatten.shape[0] == 1:
+        _, _, mask = ext.ops().topk_select(occ_preds_flatten.detach().contiguous(), topk, want_mask=True)
+        return mask.view_as(occ_preds_flatten)
     _, idx = torch.topk(occ_preds_flatten, k=topk, dim=1)
     return torch.zeros_like(occ_preds_flatten).scatter_(1, idx, 1.0)
 
@@ -143,20 +147,21 @@ class AdaptiveSparseHead(nn.Module):
         feat, dpt = self._level_inputs(0, mlvl_feats, img_meta, mlvl_dpt_dists)
         rows = self.base_heads[0].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt], **extra).contiguous()
         grid = tuple(int(v) for v in self.base_heads[0].n_voxels)
-        occ_list, top = [], None
+        occ_list, valid = [], None
         for i in range(1, len(self.base_heads)):
             lin = self.occ_pred_heads[i - 1][0]
             up, occ, grid = ops.upsample2x_occ(rows, grid, lin.weight.reshape(-1), lin.bias)
-            occ = occ.view(1, -1)
-            occ_list.append(occ)
+            occ_list.append(occ.view(1, -1))
             feat, dpt = self._level_inputs(i, mlvl_feats, img_meta, mlvl_dpt_dists)
             if (i - 1) < len(self.topk_list):
-                _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
-                idx = top.squeeze(0).sort().values                          # == nonzero(mask), no host sync
+                # the k highest occupancy scores as an ascending index list (== nonzero(mask)) in ONE launch; ties at the
+                # cut go to the lowest flat index (csrc/rows.hip) -- no topk / sort / scatter library kernels, no host sync
+                last = i == len(self.base_heads) - 1
+                idx, valid, _ = ops.topk_select(occ, self.topk_list[i - 1], want_valid=last)
                 seed = self.base_heads[i].seed_rows([feat], img_meta, idx, mlvl_dpt_dists=[dpt], **extra)
                 ops.scatter_add_rows(seed.contiguous(), idx, up)
             else:
-                top = None
+                valid = None
                 up.add_(self.base_heads[i].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt], **extra))
             rows = up
         nx, ny, nz = grid
@@ -164,8 +169,9 @@ class AdaptiveSparseHead(nn.Module):
         if not occ_list:
             return volume, torch.ones([1, 1, nx, ny, nz], device=volume.device), None
         occ_preds = torch.cat(occ_list[::-1], dim=1)
-        mask = torch.zeros_like(occ_list[-1]).scatter_(1, top, 1.0).squeeze(0)
-        return volume, self.get_valid(mask).unsqueeze(0).unsqueeze(0), occ_preds
+        if valid is None:                       # no top-k at the last level (not an SGCDet config): everything is valid
+            valid = torch.ones(nx * ny * nz, dtype=torch.int64, device=volume.device)
+        return volume, valid.view(1, 1, nx, ny, nz), occ_preds
 
     def forward(self, mlvl_feats, img_meta, mlvl_dpt_dists):
         assert mlvl_feats[0].shape[0] == 1
@@ -190,9 +196,12 @@ class AdaptiveSparseHead(nn.Module):
             occ_preds_list.append(occ)
             mask, idx = None, None
             if (i - 1) < len(self.topk_list):
-                _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
-                mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
-                idx = top.squeeze(0).sort().values                       # == nonzero(mask), no host sync
+                if occ.is_cuda and occ.dtype == torch.float32:
+                    idx, _, mask = ext.ops().topk_select(occ.detach().contiguous(), self.topk_list[i - 1], want_mask=True)
+                else:
+                    _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
+                    mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
+                    idx = top.squeeze(0).sort().values                   # == nonzero(mask), no host sync
             volume = up + self.base_heads[i]([feat], img_meta, proposal=mask, proposal_idx=idx,
                                              mlvl_dpt_dists=[dpt])
         if not occ_preds_list:

@@ -182,16 +182,21 @@ class TensorOps:
         return grad_value, grad_dist, grad_loc3, grad_attn
 
     # ---- 3. projection + compaction ---------------------------------------
-    def project_points(self, ref3d, origin, proj, img_w, img_h, d_near, d_far):
-        self._check(ref3d=ref3d, origin=origin, proj=proj)
+    def project_points(self, ref3d, origin, proj, img_w, img_h, d_near, d_far, sel=None):
+        """``sel``: optional int64 [Nq] -- query q is voxel ``sel[q]`` of ``ref3d`` (the reference gathers
+        ``ref_3d[vox_coords[unmasked_idx, 3]]`` first, transformer.py:145-146)."""
+        self._check(ref3d=ref3d, origin=origin, proj=proj, sel=sel)
         self._f32(ref3d=ref3d, origin=origin, proj=proj)
-        N, Nq = proj.shape[0], ref3d.shape[0]
+        if sel is not None:
+            self._i64(sel=sel)
+        N, Nq = proj.shape[0], (ref3d.shape[0] if sel is None else sel.numel())
         if proj.shape[1:] != (3, 4) or ref3d.shape[1] != 3 or origin.numel() != 3:
             raise RuntimeError("project_points: inconsistent shapes")
         ref_cam = torch.empty((N, Nq, 3), dtype=torch.float32, device=ref3d.device)
         mask = torch.empty((N, Nq), dtype=torch.uint8, device=ref3d.device)
-        self._call("sgc_project_points", ref3d, origin, proj, ref_cam, mask, N, Nq,
-                   float(img_w), float(img_h), float(d_near), float(d_far))
+        if Nq:
+            self._call("sgc_project_points", ref3d, sel, origin, proj, ref_cam, mask, N, Nq,
+                       float(img_w), float(img_h), float(d_near), float(d_far))
         return ref_cam, mask
 
     def compact_pairs(self, mask, cap=None):
@@ -391,26 +396,30 @@ class TensorOps:
         return vol
 
     def nchw_to_nhwc_crop(self, src, H, W):
-        """``src`` [N,C,Hs,Ws] or a top-left crop *view* of it (the reference crops with
-        ``x[..., :height, :width]``, AdaptiveSparseHead.py:58-59); returns [N, H*W, C]."""
+        """``src`` [N,C,Hs,Ws], a top-left crop *view* of it (the reference crops with ``x[..., :height, :width]``,
+        AdaptiveSparseHead.py:58-59) or an every-``step``-th-pixel view of it (``x[..., ::2, ::2]``: the nearest x1/2,
+        x1/4 copies of the depth distribution, SGCDet.py:83-85 -- read in place, never materialised); returns [N, H*W, C]."""
         if src.dim() != 4:
             raise RuntimeError("nchw_to_nhwc_crop expects [N,C,H,W]")
         N, Cc, h_in, w_in = src.shape
         if H > h_in or W > w_in:
             raise RuntimeError("nchw_to_nhwc_crop: crop larger than the map")
         st = src.stride()
-        Ws = st[2] if st[3] == 1 and h_in > 1 else w_in
-        Hs = st[1] // Ws if Ws > 0 and st[1] % max(Ws, 1) == 0 else h_in
-        viewable = (st[3] == 1 and Ws >= w_in and Hs >= h_in and st[1] == Hs * Ws
-                    and (N == 1 or st[0] == Cc * Hs * Ws))
+        step = st[3] if w_in > 1 else 1
+        viewable = False
+        if step >= 1 and h_in > 1 and st[2] % step == 0:
+            Ws = st[2] // step
+            Hs = st[1] // Ws if Ws > 0 and st[1] % Ws == 0 else 0
+            viewable = (Ws >= (w_in - 1) * step + 1 and Hs >= (h_in - 1) * step + 1 and st[1] == Hs * Ws
+                        and (N == 1 or st[0] == Cc * Hs * Ws))
         if not viewable:
             src = src.contiguous()
-            Hs, Ws = h_in, w_in
+            Hs, Ws, step = h_in, w_in, 1
         if src.device.type != self.device_type:
             raise RuntimeError(f"src must be a {self.device_type} tensor")
         self._f32(src=src)
         dst = torch.empty((N, H * W, Cc), dtype=torch.float32, device=src.device)
-        self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W)
+        self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W, step)
         return dst
 
     # ---- 7. channels-last 3D convolution -----------------------------------------------
@@ -475,6 +484,36 @@ class TensorOps:
         if n <= 0:
             return None, 0
         return torch.empty(n, dtype=torch.float32, device=device), n
+
+    # ---- 7b. row-wise glue ---------------------------------------------------------------------
+    def topk_select(self, score, k, want_valid=False, want_mask=False):
+        """score [n] (or [1,n]) fp32 -> (idx [k] int64 ascending, valid [n] int64 | None, mask [n] fp32 | None): the k
+        largest scores, ties at the cut broken by the lowest index (``sgc_topk_select``)."""
+        self._check(score=score)
+        self._f32(score=score)
+        flat = score.reshape(-1)
+        n = flat.numel()
+        if not 0 < k <= n:
+            raise RuntimeError(f"topk_select: need 0 < k <= n (k = {k}, n = {n})")
+        dev = score.device
+        idx = torch.empty(k, dtype=torch.int64, device=dev)
+        valid = torch.empty(n, dtype=torch.int64, device=dev) if want_valid else None
+        mask = torch.empty(n, dtype=torch.float32, device=dev) if want_mask else None
+        self._call("sgc_topk_select", flat, n, int(k), idx, valid, mask)
+        return idx, valid, mask
+
+    def layer_norm_rows(self, x, gamma, beta, eps=1e-5, count=None, out=None):
+        """nn.LayerNorm over the last dim of x [rows, C]; ``count``: int32 device tensor with the live row count."""
+        self._check(x=x, gamma=gamma, beta=beta, count=count, out=out)
+        self._f32(x=x, gamma=gamma, beta=beta, out=out)
+        self._i32(count=count)
+        rows, Cc = x.shape
+        if gamma.numel() != Cc or beta.numel() != Cc:
+            raise RuntimeError("layer_norm_rows: inconsistent shapes")
+        y = out if out is not None else torch.empty_like(x)
+        if rows:
+            self._call("sgc_layer_norm_rows", x, gamma, beta, float(eps), y, count, rows, Cc)
+        return y
 
     # ---- 8. post-processing ----------------------------------------------------------------
     def aligned_nms3d(self, boxes, scores, labels, iou_thr):

@@ -535,3 +535,58 @@ def test_headmajor_value_projection_is_the_row_gemm_permuted(oracle_ops, gpu_ops
         assert torch.equal(y_hm, y_rows.view(N, S, M, Cm).permute(0, 2, 1, 3).contiguous())
         y_c = oracle_ops.linear_rows_headmajor_bf16x3(x, hi, lo, b, N, S, M)
         close(y_hm, y_c, tol=1e-4)
+
+
+@pytest.mark.parametrize("n,k", [(3200, 800), (25600, 6400), (294912, 73728), (1000, 1000), (777, 1)])
+def test_topk_select_matches_oracle_with_the_defined_tie_rule(n, k, oracle_ops, gpu_ops):
+    """sgc_topk_select: same voxel set as torch.topk on tie-free scores; with exact ties at the cut (blocks of voxels no
+    camera sees carry bit-identical occupancy) the lowest flat indices win on both sides: indices, valid and mask
+    bit-exact against the oracle, sizes up to config 5's finest level."""
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.sigmoid(torch.randn(n, generator=g))
+    idx_g, valid_g, mask_g = gpu_ops.topk_select(s.cuda(), k, want_valid=True, want_mask=True)
+    idx_c, valid_c, mask_c = oracle_ops.topk_select(s, k, want_valid=True, want_mask=True)
+    assert torch.equal(idx_g.cpu(), idx_c) and torch.equal(valid_g.cpu(), valid_c) and torch.equal(mask_g.cpu(), mask_c)
+    if k < n:
+        thr = s.sort(descending=True).values
+        if thr[k - 1] > thr[k]:                                    # no tie at the cut: torch.topk picks the same set
+            assert torch.equal(idx_c, torch.topk(s, k).indices.sort().values)
+    # heavy exact ties: 40 % of the scores share the value that ends up at the cut
+    t = s.clone()
+    tie_val = float(s.sort(descending=True).values[min(k, n - 1)])
+    t[torch.randperm(n, generator=g)[: int(0.4 * n)]] = tie_val
+    idx_g, valid_g, _ = gpu_ops.topk_select(t.cuda(), k, want_valid=True)
+    idx_c, valid_c, _ = oracle_ops.topk_select(t, k, want_valid=True)
+    assert torch.equal(idx_g.cpu(), idx_c) and torch.equal(valid_g.cpu(), valid_c)
+    assert int(valid_c.sum()) == k and bool((idx_c[1:] > idx_c[:-1]).all())
+    sel, rest = t[valid_c.bool()], t[~valid_c.bool()]
+    assert rest.numel() == 0 or float(sel.min()) >= float(rest.max())
+    eq = (t == sel.min()).nonzero().flatten()                        # among the tied scores the lowest indices are taken
+    taken = valid_c[eq].bool()
+    assert bool(taken[: int(taken.sum())].all())
+
+
+@pytest.mark.parametrize("rows,C", [(6400, 256), (51200, 128), (333, 64), (100, 96)])
+def test_layer_norm_rows_matches_torch_and_oracle(rows, C, oracle_ops, gpu_ops):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 0.7
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    want = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+    got = gpu_ops.layer_norm_rows(x.cuda(), w.cuda(), b.cuda(), 1e-5)
+    close(got, want, tol=2e-6)
+    close(oracle_ops.layer_norm_rows(x, w, b, 1e-5), want, tol=2e-6)
+    cnt = torch.tensor([rows // 2], dtype=torch.int32)
+    part = gpu_ops.layer_norm_rows(x.cuda(), w.cuda(), b.cuda(), 1e-5, count=cnt.cuda(), out=torch.full((rows, C), 7.0).cuda())
+    close(part[: rows // 2], want[: rows // 2], tol=2e-6)
+    assert bool((part[rows // 2:] == 7.0).all())                     # rows past the device-side count are untouched
+
+
+def test_projection_with_a_query_selection_equals_gather_then_project(oracle_ops, gpu_ops):
+    N, Nvox = 7, 5000
+    ref3d, origin, proj = _scene(N, Nvox, 9)
+    sel = torch.randperm(Nvox, generator=torch.Generator().manual_seed(1))[:1234].sort().values
+    rc_a, mk_a = gpu_ops.project_points(ref3d[sel].contiguous().cuda(), origin.cuda(), proj.cuda(), 320., 239., 0.2, 5.0)
+    rc_b, mk_b = gpu_ops.project_points(ref3d.cuda(), origin.cuda(), proj.cuda(), 320., 239., 0.2, 5.0, sel=sel.cuda())
+    assert torch.equal(rc_a, rc_b) and torch.equal(mk_a, mk_b)
+    rc_c, mk_c = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0, sel=sel)
+    assert torch.equal(rc_b.cpu(), rc_c) and torch.equal(mk_b.cpu(), mk_c)
