@@ -66,6 +66,9 @@ def parse():
                     help="memory layout of the FPN / depth maps handed to the path: nchw = the reference's producer "
                          "(default, what the metric is quoted on); nhwc = channels-last producer contract "
                          "(SURVEY.md 8 f-1): consumed in place, no transpose pass")
+    ap.add_argument("--masked-tail", action="store_true",
+                    help="output-masked finest decoder tail + head convolutions (north star's 'sparse 3D convolution over the "
+                         "occupancy-masked voxels'): head tensors are then defined only where the head's valid pyramid is 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of the extra `sustained` leg (same configuration, back to back; 0 = skip)")
@@ -191,6 +194,7 @@ def main():
         args.graph = "none"
     if args.graph == "scene" and args.conv_mode != "bf16x3":
         args.graph = "tail"                      # the device-count GEMM entry point exists for the bf16x3 path only
+    det.masked_tail = os.environ.get("SGC_MASKED_TAIL", "0") == "1" or args.masked_tail
     det.use_graph = args.graph != "none"
     det.scene_graph = args.graph == "scene"
     if args.img is None and args.workload.startswith("cfg2_scannet"):

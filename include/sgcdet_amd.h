@@ -372,6 +372,24 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
 int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                     int transposed, int bf16x3);
 
+/* Output-masked form of the 3x3x3 stride-1 convolution (north star: "sparse 3D convolution over the occupancy-masked
+ * voxels").  The reference's volume is dense, so its convolutions are dense (necks/imvoxelnet.py:47-64); but the
+ * head's outputs are only consumed where `valid` (dense_heads/imvoxel_head_v2.py:258,301), hence the finest-level
+ * tail needs: the head convolution on valid, out_block_0 on dilate(valid), up_block_1's 3x3x3 on dilate^2(valid).
+ *   out_mask [OX*OY*OZ] uint8 {0,1}: rows with 1 are BIT-IDENTICAL to sgc_conv3d_cl_bf16x3; rows with 0 hold the
+ *   epilogue of a zero accumulator or the dense value (finite, deterministic, not to be consumed).  64-voxel tiles
+ *   without a live row skip their matrix work, 256-voxel bricks without one skip everything.  Layers that do not run
+ *   on the brick kernel (few voxels, narrow outputs) are computed dense.                                          */
+int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                const float *shift, const float *residual_or_null, float *y, const uint8_t *out_mask,
+                                int ix, int iy, int iz, int Cin, int Cout, int relu,
+                                float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream);
+/* mask_out = 3x3x3 dilation of mask_in ([X*Y*Z] uint8 {0,1}, flat index (x*Y + y)*Z + z); must not alias. */
+int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream);
+/* Head valid mask of scale `factor` (1, 2, 4): nn.Upsample(size, mode='trilinear')(valid.float()).round().bool()
+ * (imvoxel_head_v2.py:123,258) as uint8 [(X/f)*(Y/f)*(Z/f)] from valid [X*Y*Z] int64 {0,1}.                     */
+int sgc_valid_pyramid(const int64_t *valid, uint8_t *mask_out, int X, int Y, int Z, int factor, sgc_stream_t stream);
+
 /* nn.Linear over a row list whose length lives on the device (the Linears of
  * MSDeformableAttention3D_DFA3D / nn.MultiheadAttention applied to the visible pairs,
  * TU/deformable_cross_attention.py:423-436,829-833):

@@ -854,6 +854,56 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   return rc;
 }
 
+/* masked form: the oracle computes every row (the mask only licenses the GPU to skip work) */
+int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                const float *shift, const float *residual_or_null, float *y, const uint8_t *out_mask,
+                                int ix, int iy, int iz, int Cin, int Cout, int relu,
+                                float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream) {
+  if (!out_mask) return fail(SGC_EINVAL, "null mask");
+  return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, 3, 1, 0, relu,
+                              workspace_or_null, workspace_floats, stream);
+}
+
+int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream) {
+  (void)stream;
+  if (!mask_in || !mask_out || mask_in == mask_out) return fail(SGC_EINVAL, "null or aliased pointers");
+  for (int x = 0; x < X; ++x)
+    for (int y = 0; y < Y; ++y)
+      for (int z = 0; z < Z; ++z) {
+        uint8_t any = 0;
+        for (int dx = -1; dx <= 1; ++dx)
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+              const int a = x + dx, b = y + dy, c = z + dz;
+              if (a >= 0 && a < X && b >= 0 && b < Y && c >= 0 && c < Z) any |= mask_in[((int64_t)a * Y + b) * Z + c];
+            }
+        mask_out[((int64_t)x * Y + y) * Z + z] = any ? 1 : 0;
+      }
+  return SGC_OK;
+}
+
+/* nn.Upsample(size, mode='trilinear')(valid.float()).round().bool() (imvoxel_head_v2.py:123,258), integer factors:
+ * align_corners=False samples half-way between fine voxels f*d + f/2 - 1 and f*d + f/2; round() is half-to-even */
+int sgc_valid_pyramid(const int64_t *valid, uint8_t *mask_out, int X, int Y, int Z, int factor, sgc_stream_t stream) {
+  (void)stream;
+  if (!valid || !mask_out) return fail(SGC_EINVAL, "null pointer");
+  if (factor < 1 || (factor & (factor - 1)) || X % factor || Y % factor || Z % factor) return fail(SGC_EUNSUP, "bad factor");
+  const int f = factor, cx = X / f, cy = Y / f, cz = Z / f, o = f / 2 - 1;
+  for (int x = 0; x < cx; ++x)
+    for (int y = 0; y < cy; ++y)
+      for (int z = 0; z < cz; ++z) {
+        int cnt = 0;
+        if (f == 1) cnt = valid[((int64_t)x * Y + y) * Z + z] != 0 ? 8 : 0;
+        else
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+              for (int c = 0; c < 2; ++c)
+                cnt += valid[((int64_t)(x * f + o + a) * Y + (y * f + o + b)) * Z + (z * f + o + c)] != 0;
+        mask_out[((int64_t)x * cy + y) * cz + z] = cnt >= 5;
+      }
+  return SGC_OK;
+}
+
 /* Linear over a row list whose length lives on the "device" (here: host memory): fp32 truth of
  * sgc_linear_rows_bf16x3; rows past the count are left untouched. */
 int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,

@@ -60,6 +60,10 @@ struct ConvParams {
   int64_t ws_floats;      // capacity of ws
   const int32_t *m_dev;   // optional: the live row count lives on the device (sgc_linear_rows_*); rows >= *m_dev
                           // are neither read nor written and workgroups past it exit at once
+  const uint8_t *out_mask; // optional [OV] {0,1}: OUTPUT mask of a 3x3x3 stride-1 layer on the halo kernel (sgc_conv3d_cl_bf16x3_masked):
+                          // rows with mask 0 are not needed by the caller.  Tiles of 64 voxels (one wave) without a live row skip
+                          // their MFMAs, bricks without one skip everything; what they store is the epilogue of a zero
+                          // accumulator (finite, deterministic).  Live rows are bit-identical to the dense launch.
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
 };
@@ -585,6 +589,40 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
     arow[i] = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
   }
+  // output mask: does this wave's 64-voxel tile / this brick hold a row the caller needs?
+  bool wave_live = true;
+  if (p.out_mask) {
+    bool mine = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = vox_tab[(wm * 2 + i) * 32 + fr];
+      const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
+      if (x < p.gx && y < p.gy && z < p.gz) mine |= p.out_mask[((int64_t)x * p.gy + y) * p.gz + z] != 0;
+    }
+    wave_live = __ballot(mine) != 0ull;
+    if (!__syncthreads_or(wave_live ? 1 : 0)) {
+      // dead brick: store the epilogue of a zero accumulator and leave (no staging, no taps)
+      if (p.splitk > 1 && !p.ws) return;             // atomics path: y was zero-filled, the epilogue kernel finishes it
+      for (int e = tid; e < 256 * (BNV / 4); e += NT) {
+        const int rl = e / (BNV / 4), c4 = e - rl * (BNV / 4);
+        const int col = n0 + c4 * 4;
+        if (col >= p.Cout) continue;
+        const int x = X0 + rl / (BY * BZ), y = Y0 + (rl / BZ) % BY, z = Z0 + rl % BZ;
+        if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
+        const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
+        for (int q = 0; q < 4 && col + q < p.Cout; ++q) {
+          float v = 0.f;
+          if (p.splitk > 1) { p.ws[(int64_t)blockIdx.z * p.ws_stride + orow * p.Cout + col + q] = 0.f; continue; }
+          v = v * (p.scale ? p.scale[col + q] : 1.f) + (p.shift ? p.shift[col + q] : 0.f);
+          if (p.relu == 2) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[orow * p.Cout + col + q];
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          p.y[orow * p.Cout + col + q] = v;
+        }
+      }
+      return;
+    }
+  }
   // B staging slot of this thread: 8 bf16 at (tid&3)*8 of row bn; the 16 lanes of one ds_write_b128 pass take rows
   // {r, r+4, r+8, r+12} (16 banks apart at the 20-dword pitch) instead of 4 consecutive rows that overlap by 12 banks
   const int bc = tid & 3, rs16 = (tid >> 2) & 15;
@@ -661,7 +699,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
   // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
   //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
-  bf16x8 ah_n[2], al_n[2];
+  bf16x8 ah_n[2] = {}, al_n[2] = {};
   auto read_A0 = [&](int tap) {
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
     const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
@@ -683,6 +721,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
       const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
       const __bf16 *bl_ = bh_ + B_PLANE;
+      if (wave_live) {
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
         bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -711,13 +750,14 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           }
       }
       if (!last_tap) read_A0(tap + 1);
+      }
       if (more) store_B((g + 1) & 1);
       __syncthreads();
     }
     if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
       store_A();
       __syncthreads();
-      read_A0(0);
+      if (wave_live) read_A0(0);
     }
   }
 
@@ -982,12 +1022,13 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
 
 // Same contract with the weights pre-split on the host: w_hi = bf16(w), w_lo = bf16(w - float(w_hi)),
 // both [taps][Cout][Cin] bf16 (raw 16-bit patterns).
-extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
-                                    const float *shift, const float *residual_or_null, float *y,
-                                    int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
-                                    int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
-                                    sgc_stream_t stream) {
+static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                         const float *shift, const float *residual_or_null, float *y,
+                         int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                         int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                         const uint8_t *out_mask_or_null, sgc_stream_t stream) {
   ConvParamsB p = {};
+  p.out_mask = out_mask_or_null;
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
   if (rc) return rc;
@@ -1040,6 +1081,79 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
 
 // Split-K workspace (floats) the convolution above would use for a deterministic reduction; 0 = the layer is not
 // split.  Mirrors the dispatch of sgc_conv3d_cl_f32 (bf16x3 = 0) / sgc_conv3d_cl_bf16x3 (bf16x3 = 1).
+extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                    const float *shift, const float *residual_or_null, float *y,
+                                    int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
+                                    int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
+                                    sgc_stream_t stream) {
+  return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu,
+                       workspace_or_null, workspace_floats, nullptr, stream);
+}
+
+// Output-masked 3x3x3 stride-1 convolution (the decoder tail / head of the neck, where only voxels in -- or next to --
+// the refined set are consumed, necks/imvoxelnet.py:47-64, dense_heads/imvoxel_head_v2.py:258,301): live rows are
+// bit-identical to sgc_conv3d_cl_bf16x3.  Layers the halo kernel does not take run dense (the mask is a licence, not a
+// duty).
+extern "C" int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                           const float *shift, const float *residual_or_null, float *y,
+                                           const uint8_t *out_mask, int ix, int iy, int iz, int Cin, int Cout, int relu,
+                                           float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream) {
+  if (!out_mask) return set_error(SGC_EINVAL, "sgc_conv3d_cl_bf16x3_masked: null mask");
+  return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, 3, 1, 0, relu,
+                       workspace_or_null, workspace_floats, out_mask, stream);
+}
+
+// 3x3x3 dilation of a {0,1} voxel mask (what a 3x3x3 convolution must produce so that its consumer is exact on `in`)
+__global__ void mask_dilate3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int X, int Y, int Z) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= (int64_t)X * Y * Z) return;
+  const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((int64_t)Z * Y));
+  uint8_t any = 0;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int a = x + dx, b = y + dy, c = z + dz;
+        if (a >= 0 && a < X && b >= 0 && b < Y && c >= 0 && c < Z) any |= in[((int64_t)a * Y + b) * Z + c];
+      }
+  out[v] = any ? 1 : 0;
+}
+
+extern "C" int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream) {
+  if (!mask_in || !mask_out || mask_in == mask_out) return set_error(SGC_EINVAL, "sgc_mask_dilate3: null or aliased pointers");
+  if (X <= 0 || Y <= 0 || Z <= 0) return set_error(SGC_EINVAL, "sgc_mask_dilate3: bad size");
+  const int64_t n = (int64_t)X * Y * Z;
+  hipLaunchKernelGGL(mask_dilate3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask_in, mask_out, X, Y, Z);
+  return check_launch("mask_dilate3_kernel");
+}
+
+// valid masks of the head's scales: nn.Upsample(size, mode='trilinear')(valid.float()).round().bool()
+// (dense_heads/imvoxel_head_v2.py:123,258) for integer factors f = 2^s: align_corners=False puts every coarse voxel half-way
+// between fine voxels f*d + f/2 - 1 and f*d + f/2 on each axis, i.e. the mean of 8 fine voxels; round() is half-to-even,
+// so a coarse voxel is valid iff at least 5 of the 8 are.
+__global__ void valid_pyramid_kernel(const int64_t *__restrict__ valid, uint8_t *__restrict__ out, int X, int Y, int Z, int f) {
+  const int cx = X / f, cy = Y / f, cz = Z / f;
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= (int64_t)cx * cy * cz) return;
+  const int z = (int)(v % cz), y = (int)((v / cz) % cy), x = (int)(v / ((int64_t)cz * cy));
+  if (f == 1) { out[v] = valid[v] != 0; return; }
+  const int o = f / 2 - 1;
+  int cnt = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c)
+        cnt += valid[((int64_t)(x * f + o + a) * Y + (y * f + o + b)) * Z + (z * f + o + c)] != 0;
+  out[v] = cnt >= 5;
+}
+
+extern "C" int sgc_valid_pyramid(const int64_t *valid, uint8_t *mask_out, int X, int Y, int Z, int factor, sgc_stream_t stream) {
+  if (!valid || !mask_out) return set_error(SGC_EINVAL, "sgc_valid_pyramid: null pointer");
+  if (X <= 0 || Y <= 0 || Z <= 0 || factor < 1 || (factor & (factor - 1)) || X % factor || Y % factor || Z % factor)
+    return set_error(SGC_EUNSUP, "sgc_valid_pyramid: factor must be a power of two dividing the grid");
+  const int64_t n = (int64_t)(X / factor) * (Y / factor) * (Z / factor);
+  hipLaunchKernelGGL(valid_pyramid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, valid, mask_out, X, Y, Z, factor);
+  return check_launch("valid_pyramid_kernel");
+}
+
 extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                                int transposed, int bf16x3) {
   if (ix <= 0 || iy <= 0 || iz <= 0 || Cin <= 0 || Cout <= 0) return 0;

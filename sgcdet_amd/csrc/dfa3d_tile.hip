@@ -306,7 +306,6 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
     if (NBUF == 2 && hi + 1 < p.HG && p.diag != 2) fill_value(m + 1, buf ^ 1);
     if (p.diag != 1) {
     for (; g0 < cnt; g0 += NW * UPW) {
-      const int iu = min(i0 + g0 + ul, i1 - 1);
       // ---------------- phase 1: lane = (unit, point), branch-free ----------------
       // offset / (W,H,D) as a multiply by the wave-uniform reciprocal, exp / division through v_exp / v_rcp:
       // <= 2 ulp from the reference's IEEE forms (TU/deformable_cross_attention.py:428-455), as the wave kernel

@@ -83,21 +83,23 @@ class ImVoxelHeadV2(nn.Module):
         self._hip_plan = (fp, (spec, n_reg))
         return self._hip_plan[1]
 
-    def _forward_hip(self, feats):
+    def _forward_hip(self, feats, valid_masks=None):
+        """``valid_masks``: per scale a uint8 [X*Y*Z] mask (the head's own valid pyramid, :123,258): the tensors are only
+        consumed there (scores are multiplied by it, :301), so the convolution may skip tiles without a valid voxel."""
         spec, n_reg = self._plan()
         ctr, reg, cls = [], [], []
-        for x, scale in zip(feats, self.scales):
+        for i, (x, scale) in enumerate(zip(feats, self.scales)):
             rows, grid = to_channels_last_rows(x)
-            y, g = spec(rows, grid)
+            y, g = spec(rows, grid, out_mask=None if valid_masks is None else valid_masks[i])
             full = rows_to_ncdhw(y, g, spec.cout)
             ctr.append(full[:, :1])
             reg.append(self._reg_activation(full[:, 1:1 + n_reg], scale))
             cls.append(full[:, 1 + n_reg:])
         return ctr, reg, cls
 
-    def forward(self, x):
+    def forward(self, x, valid_masks=None):
         if not self.training and not torch.is_grad_enabled() and x[0].is_cuda and x[0].shape[0] == 1:
-            return self._forward_hip(x)
+            return self._forward_hip(x, valid_masks)
         return multi_apply(self.forward_single, [t.contiguous() for t in x], self.scales)   # packed NCDHW for MIOpen
 
     def _reg_activation(self, reg, scale):

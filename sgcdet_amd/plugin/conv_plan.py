@@ -56,10 +56,11 @@ class ConvSpec:
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.ksize, self.stride, self.transposed = ksize, stride, transposed
 
-    def __call__(self, x, grid, residual=None, relu=0):
+    def __call__(self, x, grid, residual=None, relu=0, out_mask=None):
+        """``out_mask`` (uint8 [OV], bf16x3 mode, 3x3x3 stride-1 layers): only rows with 1 are needed downstream."""
         if CONV_MODE == "bf16x3":
             return ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, grid, self.ksize, self.stride,
-                                              self.transposed, self.scale, self.shift, residual, relu)
+                                              self.transposed, self.scale, self.shift, residual, relu, out_mask=out_mask)
         return ext.ops().conv3d_cl(x, self.wt, grid, self.ksize, self.stride, self.transposed, self.scale,
                                    self.shift, residual, relu)
 

@@ -68,8 +68,29 @@ class SGCDet(nn.Module):
     # ---- hipGraph replay of the static-shape tail (neck + head: ~30 launches, fixed shapes) -----------
     use_graph = True
 
-    def _neck_head_eager(self, volume):
-        outs = self.bbox_head(self.extract_feat(volume))
+    # opt-in: output-masked decoder tail (north star: "sparse 3D convolution over the occupancy-masked voxels").  The head
+    # tensors are then only defined where the head's valid pyramid is 1 -- exactly where get_bboxes consumes them
+    # (imvoxel_head_v2.py:258,301); decoded boxes are identical to the dense path (tests/test_gpu_modules.py).
+    masked_tail = False
+
+    def _tail_masks(self, valid):
+        """(neck masks, head masks) from the finest valid [1,1,X,Y,Z] int64: head scale s needs valid@s; out_block_0 needs
+        the 3x3x3 dilation of valid@0 (the head conv reads one voxel around every valid one), up_block_1's conv one more."""
+        from .. import ext
+        ops = ext.ops()
+        grid = tuple(valid.shape[-3:])
+        flat = valid.reshape(-1)
+        head = [ops.valid_pyramid(flat, grid, 2 ** s) for s in range(self.bbox_head.n_scales)]
+        d1 = ops.mask_dilate3(head[0], grid)
+        d2 = ops.mask_dilate3(d1, grid)
+        return (d2, d1), head
+
+    def _neck_head_eager(self, volume, valid=None):
+        if valid is not None and self.masked_tail and not self.training and volume.is_cuda:
+            neck_masks, head_masks = self._tail_masks(valid)
+            outs = self.bbox_head(self.neck_3d(volume, neck_masks), head_masks)
+        else:
+            outs = self.bbox_head(self.extract_feat(volume))
         return tuple(list(o) for o in outs)
 
     def _neck_head(self, volume):
@@ -132,7 +153,7 @@ class SGCDet(nn.Module):
 
         def body():
             volume, valid, occ = self.build_volume_from_features(x, [meta], dpt_dist)
-            outs = self._neck_head_eager(volume)
+            outs = self._neck_head_eager(volume, valid)
             return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])
 
         cur = torch.cuda.current_stream()
@@ -193,7 +214,7 @@ class SGCDet(nn.Module):
                 and self.voxel_head is not None):
             return self._forward_scene_graph(x, img_metas, dpt_dist)
         volume, valid, occ = self.build_volume_from_features(x, img_metas, dpt_dist)
-        outs = self._neck_head(volume)
+        outs = self._neck_head_eager(volume, valid) if self.masked_tail else self._neck_head(volume)
         return dict(volume=volume, valid=valid, occ=occ, centerness=outs[0], bbox_pred=outs[1], cls_score=outs[2])
 
     def forward_train_from_features(self, x, img_metas, dpt_dist, gt_bboxes_3d, gt_labels_3d):

@@ -88,7 +88,10 @@ class FastIndoorImVoxelNeck(nn.Module):
         self._hip_plan = (fp, plan)
         return plan
 
-    def _forward_hip(self, x):
+    def _forward_hip(self, x, tail_masks=None):
+        """``tail_masks`` = (mask for up_block_1's 3x3x3, mask for out_block_0), uint8 [X*Y*Z] of the finest grid: the only
+        layers whose outputs feed nothing but the finest head scale (x1 also feeds the next ConvTranspose, so every coarser
+        layer stays dense).  Live rows are bit-identical to the dense launch."""
         plan = self._plan()
         rows, grid = to_channels_last_rows(x)
         skips = []
@@ -103,16 +106,18 @@ class FastIndoorImVoxelNeck(nn.Module):
             if i < self.n_scales - 1:
                 up_t, up_c = plan[f"up_{i + 1}"]
                 h, g = up_t(rows, grid, relu=1)
-                rows, grid = up_c(h, g, residual=skips[i][0], relu=2)      # relu(bn(conv)) + skip
+                m_up = tail_masks[0] if (tail_masks is not None and i == 0) else None
+                rows, grid = up_c(h, g, residual=skips[i][0], relu=2, out_mask=m_up)      # relu(bn(conv)) + skip
             spec = plan[f"out_{i}"]
-            o, g = spec(rows, grid, relu=1)
+            m_out = tail_masks[1] if (tail_masks is not None and i == 0) else None
+            o, g = spec(rows, grid, relu=1, out_mask=m_out)
             outs.append(rows_to_ncdhw(o, g, spec.cout))
         return outs[::-1]
 
-    def forward(self, x):
+    def forward(self, x, tail_masks=None):
         """[1,C,nx,ny,nz] -> [out@1x, out@1/2, out@1/4], finest first (imvoxelnet.py:22-34)."""
         if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.shape[0] == 1:
-            return self._forward_hip(x)
+            return self._forward_hip(x, tail_masks)
         # library convolutions (training / autograd): the voxel head hands over a channels-last strided view, for which
         # MIOpen has only its naive_conv_*_nonpacked kernels (2.6 s per config-2 step instead of ~0.1 s)
         x = x.contiguous()

@@ -431,9 +431,10 @@ class TensorOps:
         return hi.contiguous(), lo.contiguous()
 
     def conv3d_cl_bf16x3(self, x, w_hi, w_lo, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
-                         residual=None, relu=False, out=None):
-        """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``)."""
-        self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual)
+                         residual=None, relu=False, out=None, out_mask=None):
+        """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``).  ``out_mask`` (uint8 [OV], 3x3x3 stride-1
+        layers only): rows with 0 are not needed by the caller (``sgc_conv3d_cl_bf16x3_masked``)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual, out_mask=out_mask)
         self._f32(x=x, scale=scale, shift=shift, residual=residual)
         if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape:
             raise RuntimeError("conv3d_cl_bf16x3: w_hi / w_lo must be bfloat16 tensors of one shape")
@@ -451,6 +452,12 @@ class TensorOps:
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError("conv3d_cl_bf16x3: residual shape mismatch")
         ws, ws_n = self._conv_workspace(x.device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, 1)
+        if out_mask is not None:
+            if transposed or ksize != 3 or stride != 1 or out_mask.dtype != torch.uint8 or out_mask.numel() != y.shape[0]:
+                raise RuntimeError("conv3d_cl_bf16x3: out_mask needs a 3x3x3 stride-1 layer and a uint8 mask of [OV]")
+            self._call("sgc_conv3d_cl_bf16x3_masked", x, w_hi, w_lo, scale, shift, residual, y, out_mask, ix, iy, iz, Cin,
+                       Cout, int(relu), ws, ws_n, _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0], masked=True))
+            return y, og
         self._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize,
                    stride, 1 if transposed else 0, int(relu), ws, ws_n,
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
@@ -514,6 +521,26 @@ class TensorOps:
         if rows:
             self._call("sgc_layer_norm_rows", x, gamma, beta, float(eps), y, count, rows, Cc)
         return y
+
+    def mask_dilate3(self, mask, grid):
+        """3x3x3 dilation of a uint8 {0,1} voxel mask [X*Y*Z]."""
+        self._check(mask=mask)
+        if mask.dtype != torch.uint8 or mask.numel() != grid[0] * grid[1] * grid[2]:
+            raise RuntimeError("mask_dilate3: uint8 mask of [X*Y*Z] expected")
+        out = torch.empty_like(mask)
+        self._call("sgc_mask_dilate3", mask, out, *grid)
+        return out
+
+    def valid_pyramid(self, valid, grid, factor):
+        """Head valid mask of scale ``factor``: nn.Upsample(trilinear)(valid.float()).round().bool() as uint8."""
+        self._check(valid=valid)
+        self._i64(valid=valid)
+        X, Y, Z = grid
+        if valid.numel() != X * Y * Z:
+            raise RuntimeError("valid_pyramid: valid must hold X*Y*Z elements")
+        out = torch.empty((X // factor) * (Y // factor) * (Z // factor), dtype=torch.uint8, device=valid.device)
+        self._call("sgc_valid_pyramid", valid.reshape(-1), out, X, Y, Z, factor)
+        return out
 
     # ---- 8. post-processing ----------------------------------------------------------------
     def aligned_nms3d(self, boxes, scores, labels, iou_thr):

@@ -101,3 +101,28 @@ def test_split_k_layers_are_bitwise_reproducible(cin, cout, grid, stride, gpu_op
     gpu_ops._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, None, None, None, y2, *grid, cin, cout, 3, stride, 0, 0, None, 0)
     torch.cuda.synchronize()
     assert float((y2 - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("grid,cin,cout,relu,res", [((40, 40, 16), 64, 128, 1, False), ((20, 12, 8), 32, 32, 2, True),
+                                                     ((16, 16, 4), 64, 28, 0, False)])
+def test_output_masked_conv_is_bit_identical_on_live_rows(grid, cin, cout, relu, res, gpu_ops):
+    """sgc_conv3d_cl_bf16x3_masked: rows with mask 1 equal the dense launch bit for bit, rows with mask 0 are finite;
+    clustered masks (dead bricks and dead 64-voxel tiles exist), an all-zero mask and an all-one mask."""
+    g = torch.Generator().manual_seed(sum(grid) + cin)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g).cuda()
+    w = (torch.randn(27, cout, cin, generator=g) * 0.05)
+    hi, lo = gpu_ops.split_bf16(w)
+    hi, lo = hi.cuda(), lo.cuda()
+    scale, shift = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    residual = torch.randn(V, cout, generator=g).cuda() if res else None
+    dense, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+    blob = torch.zeros(grid)
+    blob[: grid[0] // 3, grid[1] // 4: grid[1] // 2, :] = 1           # a slab: whole bricks dead elsewhere
+    blob[-3:, -2:, -1:] = 1                                              # and a small corner cluster
+    for mask in (blob, torch.zeros(grid), torch.ones(grid), (torch.rand(grid, generator=g) < 0.02).float()):
+        m = mask.reshape(-1).to(torch.uint8).cuda()
+        got, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=m)
+        assert torch.isfinite(got).all()
+        live = m.bool()
+        assert torch.equal(got[live], dense[live])
