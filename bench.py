@@ -66,6 +66,9 @@ def parse():
                     help="memory layout of the FPN / depth maps handed to the path: nchw = the reference's producer "
                          "(default, what the metric is quoted on); nhwc = channels-last producer contract "
                          "(SURVEY.md 8 f-1): consumed in place, no transpose pass")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16"],
+                    help="value-map storage of the tiled gather: f32 (parity mode, the headline) or bf16 (opt-in storage mode of "
+                         "BASELINE.json configs #2/#5: bf16 value map, fp32 accumulate / outputs; its own line, never the headline)")
     ap.add_argument("--masked-tail", action="store_true",
                     help="output-masked finest decoder tail + head convolutions (north star's 'sparse 3D convolution over the "
                          "occupancy-masked voxels'): head tensors are then defined only where the head's valid pyramid is 1")
@@ -195,6 +198,8 @@ def main():
     if args.graph == "scene" and args.conv_mode != "bf16x3":
         args.graph = "tail"                      # the device-count GEMM entry point exists for the bf16x3 path only
     det.masked_tail = os.environ.get("SGC_MASKED_TAIL", "0") == "1" or args.masked_tail
+    from sgcdet_amd.plugin import voxformer as _vf
+    _vf.TILED_GATHER["storage"] = args.storage
     det.use_graph = args.graph != "none"
     det.scene_graph = args.graph == "scene"
     if args.img is None and args.workload.startswith("cfg2_scannet"):
@@ -355,7 +360,9 @@ def main():
         finest = [(t, m) for t, m in dg if m["n_pairs"] * m["C"] + m["N"] * m["H"] * m["W"] * m["C"] >= 0.5 * big]
         tiled_finest = "bin" in finest[0][1]
         t_avg = sum(t for t, _ in finest) / len(finest)
+        # bf16 storage mode: the value map costs 2 bytes per element, everything else stays fp32
         b_avg = sum(algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"])
+                    - (4 - m.get("value_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["C"]
                     for _, m in finest) / len(finest)
         achieved = b_avg / t_avg / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
@@ -438,7 +445,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)",
+            "dtype": ("bf16 storage (value map of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
+                      if args.storage == "bf16" else
+                      "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)"),
             "data": "synthetic",
             "config": {"workload": f"{w['name']}: {n_views} views x {w['embed_dims']} ch, images "
                                    f"{'x'.join(str(v) for v in scenes[0][2][0]['img_shape'][:2])}, FPN maps "

@@ -232,7 +232,9 @@ int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int 
  * call, TU/deformable_cross_attention.py:423-489; one level, softmax over the P points and `ref + offset/(W,H,D)`
  * fused in) on a BINNED pair list with HEAD-MAJOR operands.  One workgroup per (camera, bin) walks the heads and
  * stages each head's window of the value map (and the camera's depth window) in LDS:
- *   value_hm [N][M][S][Cm]          value_proj output as written by sgc_linear_rows_headmajor_bf16x3
+ *   value_hm [N][M][S][Cm]          value_proj output as written by sgc_linear_rows_headmajor_bf16x3: fp32, or -- with
+ *                                   value_bf16 != 0, the opt-in bf16 STORAGE mode -- bfloat16 (half the map bytes and
+ *                                   half the LDS per window; taps are widened to fp32, accumulation and output fp32)
  *   dist     [N][S][D]
  *   pair_ref / bin_offset           from sgc_bin_pairs with the same (H, W, bin_w, bin_h)
  *   raw_hm   [n_pairs][M][P][4]     per (pair, head, point): (du, dv, dz, attention logit) -- the three Linear
@@ -246,7 +248,7 @@ int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int 
  * depth_in_lds != 0: the depth taps are served from an LDS copy of the camera's depth window as well (when it fits;
  * pays when many pairs share a bin).  D >= 2, H*W < 32767; the windows must fit 160 KB of LDS (sgc_tile_window
  * reports what would be staged).                                                                                 */
-int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, const float *pair_ref,
+int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const float *dist, const float *pair_ref,
                                   const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
                                   float *out, int N, int H, int W, int M, int Cm, int D, int P,
                                   int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,
@@ -254,7 +256,7 @@ int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, cons
 /* (host-side helper, no launch, HOST pointers) value window, LDS bytes, number of value buffers (2 = the next head's
  * window is loaded while the current head is computed) and whether the depth window is staged too */
 int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int max_shift_x,
-                    int max_shift_y, int depth_in_lds, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
+                    int max_shift_y, int depth_in_lds, int value_bf16, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
                     int *depth_in_lds_out);
 
 /* dp [N,H,W+1,D,2]: dp[n][h][wq][d] = (dist[n][h][wq-1][d] or 0, dist[n][h][wq][d] or 0); dist [N,H*W,D]. */
@@ -402,9 +404,10 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
 
 /* value_proj (TU/deformable_cross_attention.py:417) with the result stored HEAD-MAJOR for the tiled gather:
  *   x [N*S][Cin] camera-major pixel rows -> y [N][M][S][Cm], y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j].
- *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128.            */
+ *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128.
+ *   y_bf16 != 0: y is bfloat16 (round-to-nearest-even of the fp32 result) -- the opt-in bf16 storage mode.     */
 int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
-                                     float *y, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);
+                                     void *y, int y_bf16, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 7b. Row-wise glue of the coarse-to-fine head (no library kernels inside the scene graphs)

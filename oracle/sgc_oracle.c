@@ -576,6 +576,8 @@ int sgc_pairs_deform_gather(const float *value, const float *dist, const float *
   return SGC_OK;
 }
 
+static float bf16_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
+
 /* ---- 4b. binned / head-major forms (include/sgcdet_amd.h: sgc_bin_pairs, sgc_pairs_deform_gather_tiled) ---- */
 static int oracle_ref_bin(const float *rc, int H, int W, int bw, int bh, int nbx) {
   const float w_im = rc[0] * (float)W - 0.5f, h_im = rc[1] * (float)H - 0.5f;
@@ -626,11 +628,11 @@ int sgc_bin_pairs(const float *ref_cam, const int32_t *pair_cam, const int32_t *
 }
 
 int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int max_shift_x,
-                    int max_shift_y, int depth_in_lds, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
+                    int max_shift_y, int depth_in_lds, int value_bf16, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
                     int *depth_in_lds_out) {
   const int tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W;
   const int th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
-  (void)max_shift_x; (void)max_shift_y; (void)D; (void)depth_in_lds;
+  (void)max_shift_x; (void)max_shift_y; (void)D; (void)depth_in_lds; (void)value_bf16;
   if (tw_out) *tw_out = tw;
   if (th_out) *th_out = th;
   if (lds_bytes_out) *lds_bytes_out = (tw * th + 1) * Cm * 4;
@@ -642,16 +644,26 @@ int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_
 /* Same arithmetic as sgc_pairs_deform_gather (the reference kernels' order), operands head-major, pairs in the
  * binned order; the window parameters (bin / halo / head_shift) only choose what the GPU stages in LDS and cannot
  * change a result. */
-int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, const float *pair_ref,
+int sgc_pairs_deform_gather_tiled(const void *value_hm_any, int value_bf16, const float *dist, const float *pair_ref,
                                   const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
                                   float *out, int N, int H, int W, int M, int Cm, int D, int P,
                                   int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,
                                   int max_shift_x, int max_shift_y, int depth_in_lds, sgc_stream_t stream) {
   (void)stream; (void)head_shift_or_null; (void)halo_x; (void)halo_y; (void)max_shift_x; (void)max_shift_y; (void)depth_in_lds;
-  if (!value_hm || !dist || !pair_ref || !bin_offset || !raw_hm || !out) return fail(SGC_EINVAL, "null pointer");
+  if (!value_hm_any || !dist || !pair_ref || !bin_offset || !raw_hm || !out) return fail(SGC_EINVAL, "null pointer");
   if (P > 64) return fail(SGC_EUNSUP, "P > 64");
   if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
   const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;
+  const float *value_hm = (const float *)value_hm_any;
+  float *widened = NULL;
+  if (value_bf16) {          /* bf16 storage mode: the taps are the bf16 values widened to fp32 (exact) */
+    const int64_t n = (int64_t)N * M * S * Cm;
+    widened = (float *)malloc(sizeof(float) * (size_t)n);
+    if (!widened) return fail(SGC_EINVAL, "out of memory");
+    const uint16_t *h = (const uint16_t *)value_hm_any;
+    for (int64_t i = 0; i < n; ++i) widened[i] = bf16_to_f32(h[i]);
+    value_hm = widened;
+  }
   const int nb = ((W + bin_w - 1) / bin_w) * ((H + bin_h - 1) / bin_h);
   const int MC = M * Cm;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -682,6 +694,7 @@ int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, cons
       }
     }
   }
+  free(widened);
   return SGC_OK;
 }
 
@@ -829,7 +842,6 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
 
 /* bf16x3 entry point: the oracle is the fp32 truth -- it rebuilds w = float(hi) + float(lo) and runs
  * the naive fp32 convolution above. */
-static float bf16_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
 int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                     int transposed, int bf16x3) {
   (void)ix; (void)iy; (void)iz; (void)Cin; (void)Cout; (void)ksize; (void)stride; (void)transposed; (void)bf16x3;
@@ -917,8 +929,15 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
 }
 
 /* value_proj with a head-major result: y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j] */
+static uint16_t f32_to_bf16_rne(float f) {
+  union { float f; uint32_t u; } c; c.f = f;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((c.u >> 16) | 0x40);      /* NaN stays NaN */
+  return (uint16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+
 int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
-                                     float *y, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream) {
+                                     void *y_any, int y_bf16, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream) {
+  float *y = (float *)y_any;
   if (!x || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
   if (N <= 0 || S <= 0 || M <= 0 || Cm <= 0) return fail(SGC_EINVAL, "bad size");
   const int64_t rows = (int64_t)N * S;
@@ -929,7 +948,11 @@ int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const
   if (rc == SGC_OK)
     for (int64_t r = 0; r < rows; ++r)
       for (int c = 0; c < C; ++c)
-        y[(((r / S) * M + c / Cm) * S + r % S) * Cm + c % Cm] = tmp[r * C + c];
+        {
+          const int64_t o = (((r / S) * M + c / Cm) * S + r % S) * Cm + c % Cm;
+          if (y_bf16) ((uint16_t *)y_any)[o] = f32_to_bf16_rne(tmp[r * C + c]);
+          else y[o] = tmp[r * C + c];
+        }
   free(tmp);
   return rc;
 }

@@ -25,9 +25,9 @@ SIGNATURES = {
     "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 12 + [_p],
     "sgc_depth_pairs": [_p, _p] + [_i] * 5 + [_p],
     "sgc_bin_pairs": [_p] * 9 + [_i] * 7 + [_p],
-    "sgc_pairs_deform_gather_tiled": [_p] * 7 + [_i] * 15 + [_p],
-    "sgc_linear_rows_headmajor_bf16x3": [_p] * 5 + [_i] * 5 + [_p],
-    "sgc_tile_window": [_i] * 11 + [C.POINTER(C.c_int)] * 5,
+    "sgc_pairs_deform_gather_tiled": [_p, _i] + [_p] * 6 + [_i] * 15 + [_p],
+    "sgc_linear_rows_headmajor_bf16x3": [_p] * 5 + [_i] * 6 + [_p],
+    "sgc_tile_window": [_i] * 12 + [C.POINTER(C.c_int)] * 5,
     "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],

@@ -64,6 +64,7 @@ struct ConvParams {
                           // rows with mask 0 are not needed by the caller.  Tiles of 64 voxels (one wave) without a live row skip
                           // their MFMAs, bricks without one skip everything; what they store is the epilogue of a zero
                           // accumulator (finite, deterministic).  Live rows are bit-identical to the dense launch.
+  int hm_bf16;            // head-major output stored as bfloat16 (RNE of the fp32 result)
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
 };
@@ -440,7 +441,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
           v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
         }
         const int ncam = m / p.hm_S, spx = m - ncam * p.hm_S, head = col / p.hm_cm;
-        *reinterpret_cast<float4 *>(p.y + (((int64_t)ncam * heads + head) * p.hm_S + spx) * p.hm_cm + (col - head * p.hm_cm)) = v;
+        const int64_t o = (((int64_t)ncam * heads + head) * p.hm_S + spx) * p.hm_cm + (col - head * p.hm_cm);
+        if (p.hm_bf16) {
+          bf16x4 h;
+          h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+          *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(p.y) + o) = h;
+        } else {
+          *reinterpret_cast<float4 *>(p.y + o) = v;
+        }
       }
       return;
     }
@@ -1183,7 +1191,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
 // back costs a host round trip per level.  The grid covers rows_cap; workgroups past *rows_dev exit at once.
 static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                        float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout, int hm_S, int hm_cm,
-                       sgc_stream_t stream) {
+                       int hm_bf16, sgc_stream_t stream) {
   if (!x || !w_hi || !w_lo || !y) return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: null pointer");
   if (rows_cap <= 0) return SGC_OK;
   if (Cin % 32 || Cout % 4) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: needs Cin %% 32 == 0 and Cout %% 4 == 0");
@@ -1197,7 +1205,7 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
   p.Cin = Cin; p.Cout = Cout;
   p.ix = rows_cap; p.iy = 1; p.iz = 1; p.gx = rows_cap; p.gy = 1; p.gz = 1;
   p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1; p.splitk = 1; p.M = rows_cap; p.m_dev = rows_dev_or_null;
-  p.hm_S = hm_S; p.hm_cm = hm_cm;
+  p.hm_S = hm_S; p.hm_cm = hm_cm; p.hm_bf16 = hm_bf16;
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
@@ -1221,18 +1229,18 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
 extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                       float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
                                       sgc_stream_t stream) {
-  return linear_rows(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, 0, stream);
+  return linear_rows(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, 0, 0, stream);
 }
 
 // The same GEMM with a HEAD-MAJOR result: x holds N * S rows (camera-major pixels), the Cout columns are M heads of
 // Cm channels, and y is [N][M][S][Cm] -- the layout the LDS-tiled deformable gather stages one head's window from
 // (dfa3d_tile.hip).  Same arithmetic per element as sgc_linear_rows_bf16x3: only the store address differs.
 extern "C" int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
-                                                const float *shift, float *y, int N, int S, int Cin, int M, int Cm,
+                                                const float *shift, void *y, int y_bf16, int N, int S, int Cin, int M, int Cm,
                                                 sgc_stream_t stream) {
   if (N <= 0 || S <= 0 || M <= 0 || Cm <= 0 || Cm % 4 || (int64_t)N * S >= (1ll << 31))
     return set_error(SGC_EINVAL, "sgc_linear_rows_headmajor_bf16x3: bad size (Cm %% 4 == 0 required)");
   if (128 % Cm && Cm % 128)
     return set_error(SGC_EUNSUP, "sgc_linear_rows_headmajor_bf16x3: Cm must divide the 128-column tile (got %d)", Cm);
-  return linear_rows(x, w_hi, w_lo, shift, y, nullptr, N * S, Cin, M * Cm, S, Cm, stream);
+  return linear_rows(x, w_hi, w_lo, shift, reinterpret_cast<float *>(y), nullptr, N * S, Cin, M * Cm, S, Cm, y_bf16 ? 1 : 0, stream);
 }

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(const int32_t *__restric
 
 // ---------------------------------------------------------------------------------------------
 struct TileParams {
-  const float *value;         // [N][M][S][CM] head-major
+  const void *value;          // [N][M][S][CM] head-major, fp32 or bf16 (the kernel's VB template argument)
   const float *dist;          // [N][S][D]
   const float4 *pair_ref;     // [pairs] (u, v, zn, q bits) in (camera, bin) order
   const int32_t *bin_offset;  // [N*nb + 1]
@@ -226,13 +226,22 @@ template <int S> __device__ __forceinline__ unsigned quad_bcast_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true);
 }
 
-template <int CM, int NW, bool DL, int NBUF>
+// one 4-channel chunk of a value row: 16 bytes of fp32, or 8 bytes of bf16 widened to fp32 (bf16 -> fp32 is exact)
+template <int VB> __device__ __forceinline__ float4 load_chunk(const unsigned char *p);
+template <> __device__ __forceinline__ float4 load_chunk<4>(const unsigned char *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 load_chunk<2>(const unsigned char *p) {
+  const uint2 u = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int CM, int NW, bool DL, int NBUF, int VB>
 __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParams p) {
   constexpr int P = 4;
   constexpr int NCH = CM / 16;          // 16-byte chunks of a row per lane in phase 2 (a unit's 4 lanes cover the row)
   constexpr int CV = CM / 4;            // 16-byte chunks per row
   constexpr int UPW = 64 / P;           // units per wave step (16)
-  constexpr int R16 = CM / 4;           // a value row in 16-byte units
+  constexpr int R16 = CM / 4;           // a value row in 4-channel chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ngrp = p.M / p.HG;
@@ -248,9 +257,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   const int n = t / nb, b = t - n * nb;
   const int by = b / p.nbx, bx = b - by * p.nbx;
   const int npx = p.tw * p.th;
-  const int buf_floats = (npx + 1) * CM;                            // window + one all-zero row
-  float *val0 = reinterpret_cast<float *>(tile_smem);
-  float *dep = val0 + NBUF * buf_floats;                            // [dh][dw][D]
+  constexpr int CHB = 4 * VB;                                       // bytes of a 4-channel chunk
+  const int buf_bytes = (npx + 1) * CM * VB;                        // window + one all-zero row
+  unsigned char *val0 = tile_smem;
+  float *dep = reinterpret_cast<float *>(tile_smem + ((NBUF * buf_bytes + 15) & ~15));   // [dh][dw][D]
   const float *dcam = p.dist + (int64_t)n * p.S * p.D;
   const int xd0 = max(0, min(bx * p.bw - p.hx - p.smx, p.W - p.dw));
   const int yd0 = max(0, min(by * p.bh - p.hy - p.smy, p.H - p.dh));
@@ -264,9 +274,9 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   auto fill_value = [&](int m, int buf) {
     int x0, y0;
     window_origin(m, x0, y0);
-    const float *plane = p.value + ((int64_t)n * p.M + m) * p.S * CM;
-    lds_dma_rows<NW>(reinterpret_cast<const char *>(plane + ((int64_t)y0 * p.W + x0) * CM), (int64_t)p.W * CM * 4, p.th,
-                     p.tw * CM * 4, reinterpret_cast<unsigned char *>(val0 + buf * buf_floats), wid, lane);
+    const char *plane = reinterpret_cast<const char *>(p.value) + ((int64_t)n * p.M + m) * p.S * CM * VB;
+    lds_dma_rows<NW>(plane + ((int64_t)y0 * p.W + x0) * CM * VB, (int64_t)p.W * CM * VB, p.th,
+                     p.tw * CM * VB, val0 + buf * buf_bytes, wid, lane);
   };
 
   const int m_first = hg * p.HG;
@@ -276,9 +286,11 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
                        p.dw * p.D * 4, reinterpret_cast<unsigned char *>(dep), wid, lane);
     fill_value(m_first, 0);
   }
-  if (tid < NBUF * CV) {                                            // the zero rows
+  if (tid < NBUF * CV) {                                            // the zero rows (one 4-channel chunk per thread)
     const int bsel = tid / CV;
-    reinterpret_cast<float4 *>(val0 + bsel * buf_floats + npx * CM)[tid - bsel * CV] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned char *z = val0 + bsel * buf_bytes + npx * CM * VB + (tid - bsel * CV) * CHB;
+    if (VB == 4) *reinterpret_cast<float4 *>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else *reinterpret_cast<uint2 *>(z) = make_uint2(0u, 0u);
   }
 
   const float rW = 1.0f / (float)p.W, rH = 1.0f / (float)p.H, rD = 1.0f / (float)p.D;
@@ -289,10 +301,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   for (int hi = 0; hi < p.HG; ++hi) {
     const int m = m_first + hi;
     const int buf = NBUF == 2 ? (hi & 1) : 0;
-    const float *val = val0 + buf * buf_floats;
+    const unsigned char *val = val0 + buf * buf_bytes;
     int x0, y0;
     window_origin(m, x0, y0);
-    const float *plane = p.value + ((int64_t)n * p.M + m) * p.S * CM;
+    const unsigned char *plane = reinterpret_cast<const unsigned char *>(p.value) + ((int64_t)n * p.M + m) * p.S * CM * VB;
     // first step's operands: issued before the wait below, they travel with the window
     int g0 = wid * UPW;
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f), r4 = rec;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       // LDS-crossbar shuffles.  One sample (4 corner rows x NCH 16-byte chunks) is in flight at a time per lane.
       {
         const int c16 = lane % P;                         // 16-byte chunk of the row this lane reads (and chunk c16 + 4 j)
-        const float4 *vrow = reinterpret_cast<const float4 *>(val) + c16;
+        const unsigned char *vrow = val + c16 * CHB;
         float4 acc[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) v[k][j] = vrow[r[k] + 4 * j];
+            for (int j = 0; j < NCH; ++j) v[k][j] = load_chunk<VB>(vrow + (r[k] + 4 * j) * CHB);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -429,10 +441,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
               const unsigned sl = (unsigned)__shfl((int)fbs[k], src + s);
               const float wk = __shfl(wgt[k], src + s);
               if (sl & kFallbackBit) {
-                const float4 *grow = reinterpret_cast<const float4 *>(plane + (int64_t)(sl & 0x7fffu) * CM) + c16;
+                const unsigned char *grow = plane + (int64_t)(sl & 0x7fffu) * CM * VB + c16 * CHB;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                  const float4 gv = grow[4 * j];
+                  const float4 gv = load_chunk<VB>(grow + 4 * j * CHB);
                   acc[j].x += wk * gv.x; acc[j].y += wk * gv.y; acc[j].z += wk * gv.z; acc[j].w += wk * gv.w;
                 }
               }
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       if (p.diag != 2) fill_value(m + 1, 0);
     }
   }
-  if (p.diag == 1 && tid == 0) p.out[(int64_t)i0 * p.M * CM] = val0[0] + (DL ? dep[0] : 0.f);
+  if (p.diag == 1 && tid == 0) p.out[(int64_t)i0 * p.M * CM] = (float)val0[0] + (DL ? dep[0] : 0.f);
 }
 
 // A/B knobs (sgc_set_tuning); 0 = the library's own choice.  Results never depend on them.
@@ -510,7 +522,7 @@ struct TileGeom { int tw, th, dw, dh, smx, smy, nbuf; bool dl; size_t lds; };
 
 // window sizes and LDS bytes for a (bin, halo, max shift) choice; nbuf falls back to 1 when two value buffers do not fit
 static TileGeom tile_geometry(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int smx, int smy,
-                              int depth_in_lds) {
+                              int depth_in_lds, int vb = 4) {
   TileGeom g;
   g.tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W;
   g.th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
@@ -518,18 +530,18 @@ static TileGeom tile_geometry(int H, int W, int Cm, int D, int bin_w, int bin_h,
   g.dw = bin_w + 2 * (halo_x + smx) < W ? bin_w + 2 * (halo_x + smx) : W;
   g.dh = bin_h + 2 * (halo_y + smy) < H ? bin_h + 2 * (halo_y + smy) : H;
   g.dl = (g_tune_tile_depth_lds >= 0 ? g_tune_tile_depth_lds : depth_in_lds) != 0 && D % 4 == 0 && D >= 2;
-  const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * 4, dbuf = (size_t)g.dw * g.dh * D * 4;
+  const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * vb, dbuf = (size_t)g.dw * g.dh * D * 4;
   g.nbuf = g_tune_tile_nbuf == 2 ? 2 : 1;
   if (g.nbuf == 2 && 2 * vbuf + (g.dl ? dbuf : 0) > 160 * 1024) g.nbuf = 1;
   if (g.dl && g.nbuf * vbuf + dbuf > 160 * 1024) g.dl = false;       // depth taps from global memory instead
-  g.lds = g.nbuf * vbuf + (g.dl ? dbuf : 0);
+  g.lds = ((g.nbuf * vbuf + 15) & ~(size_t)15) + (g.dl ? dbuf : 0);
   return g;
 }
 
 extern "C" int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y, int max_shift_x,
-                               int max_shift_y, int depth_in_lds, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
+                               int max_shift_y, int depth_in_lds, int value_bf16, int *tw_out, int *th_out, int *lds_bytes_out, int *nbuf_out,
                                int *depth_in_lds_out) {
-  const TileGeom g = tile_geometry(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, max_shift_x, max_shift_y, depth_in_lds);
+  const TileGeom g = tile_geometry(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, max_shift_x, max_shift_y, depth_in_lds, value_bf16 ? 2 : 4);
   if (tw_out) *tw_out = g.tw;
   if (th_out) *th_out = g.th;
   if (lds_bytes_out) *lds_bytes_out = (int)g.lds;
@@ -538,16 +550,16 @@ extern "C" int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h
   return SGC_OK;
 }
 
-template <int CM, int NW, bool DL, int NBUF>
+template <int CM, int NW, bool DL, int NBUF, int VB>
 static int launch_tile(const TileParams &p, size_t smem, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF>, 160 * 1024, attr_done);
+  ensure_dynamic_lds((const void *)dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>, 160 * 1024, attr_done);
   const int64_t grid = (int64_t)p.N * p.nbx * p.nby * (p.M / p.HG);
-  hipLaunchKernelGGL((dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
+  hipLaunchKernelGGL((dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
   return check_launch("dfa3d_fwd_tile_kernel");
 }
 
-extern "C" int sgc_pairs_deform_gather_tiled(const float *value_hm, const float *dist, const float *pair_ref,
+extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const float *dist, const float *pair_ref,
                                              const int32_t *bin_offset, const float *raw_hm,
                                              const int32_t *head_shift_or_null, float *out, int N, int H, int W, int M,
                                              int Cm, int D, int P, int cam_stride_or_0, int bin_w, int bin_h, int halo_x,
@@ -566,7 +578,7 @@ extern "C" int sgc_pairs_deform_gather_tiled(const float *value_hm, const float 
        reinterpret_cast<uintptr_t>(raw_hm) | reinterpret_cast<uintptr_t>(out)) & 15)
     return set_error(SGC_EINVAL, "sgc_pairs_deform_gather_tiled: pointers must be 16-byte aligned");
   const int smx = head_shift_or_null ? max_shift_x : 0, smy = head_shift_or_null ? max_shift_y : 0;
-  const TileGeom g = tile_geometry(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, smx, smy, depth_in_lds);
+  const TileGeom g = tile_geometry(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, smx, smy, depth_in_lds, value_bf16 ? 2 : 4);
   TileParams p = {};
   p.value = value_hm; p.dist = dist; p.pair_ref = reinterpret_cast<const float4 *>(pair_ref); p.bin_offset = bin_offset;
   p.raw = reinterpret_cast<const float4 *>(raw_hm); p.out = out; p.head_shift = head_shift_or_null;
@@ -581,8 +593,9 @@ extern "C" int sgc_pairs_deform_gather_tiled(const float *value_hm, const float 
     return set_error(SGC_EUNSUP, "sgc_pairs_deform_gather_tiled: window too large for 16-bit row offsets");
   hipStream_t st = (hipStream_t)stream;
   const int nw = g_tune_tile_nw == 8 ? 8 : g_tune_tile_nw == 16 ? 16 : (g.lds <= 80 * 1024 ? 8 : 16);
-#define SGC_TILE_CASE(CMV, NWV, DLV, NB) \
-  if (Cm == CMV && nw == NWV && g.dl == DLV && g.nbuf == NB) return launch_tile<CMV, NWV, DLV, NB>(p, g.lds, st)
+#define SGC_TILE_CASE(CMV, NWV, DLV, NB)                                                             \
+  if (Cm == CMV && nw == NWV && g.dl == DLV && g.nbuf == NB)                                         \
+    return value_bf16 ? launch_tile<CMV, NWV, DLV, NB, 2>(p, g.lds, st) : launch_tile<CMV, NWV, DLV, NB, 4>(p, g.lds, st)
   SGC_TILE_CASE(32, 16, true, 2); SGC_TILE_CASE(32, 16, false, 2); SGC_TILE_CASE(32, 8, true, 2); SGC_TILE_CASE(32, 8, false, 2);
   SGC_TILE_CASE(16, 16, true, 2); SGC_TILE_CASE(16, 16, false, 2); SGC_TILE_CASE(16, 8, true, 2); SGC_TILE_CASE(16, 8, false, 2);
   SGC_TILE_CASE(32, 16, true, 1); SGC_TILE_CASE(32, 16, false, 1); SGC_TILE_CASE(32, 8, true, 1); SGC_TILE_CASE(32, 8, false, 1);

@@ -132,9 +132,9 @@ class LinearSpec:
             y, _ = ext.ops().conv3d_cl(x, self.wt, (M, 1, 1), 1, 1, False, None, self.shift)
         return y if self.cout_p == self.cout else y[:, :self.cout]
 
-    def headmajor(self, x, N, S, M):
+    def headmajor(self, x, N, S, M, out_dtype=torch.float32):
         """x [N*S, in] -> [N, M, S, out/M]: the same GEMM with the result stored head-major (the layout the LDS-tiled
-        gather stages a head's window from); bf16x3 path only."""
+        gather stages a head's window from); bf16x3 path only.  ``out_dtype=torch.bfloat16``: bf16 storage mode."""
         if CONV_MODE != "bf16x3" or self.cout_p != self.cout:
             raise NotImplementedError("head-major output needs the bf16x3 path and out_features % 4 == 0")
-        return ext.ops().linear_rows_headmajor_bf16x3(x, self.w_hi, self.w_lo, self.shift, N, S, M)
+        return ext.ops().linear_rows_headmajor_bf16x3(x, self.w_hi, self.w_lo, self.shift, N, S, M, out_dtype=out_dtype)

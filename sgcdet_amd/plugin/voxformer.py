@@ -55,7 +55,10 @@ def _ops():
 # LDS-tiled deformable gather (csrc/dfa3d_tile.hip): which levels take it and how their windows are cut.  Results never
 # depend on these numbers (tests/test_gpu_kernels.py::test_tiled_gather_against_oracle); they were chosen by
 # tools/tile_bench.py sweeps on MI355X.  ``min_pixels``: smaller maps keep the wave kernel.
-TILED_GATHER = dict(enabled=True, min_pixels=2048,
+# ``storage``: "f32" (parity mode, the default) or "bf16" -- OPT-IN storage mode (BASELINE.json configs #2/#5): value_proj's
+# epilogue writes the head-major value map as bfloat16, the gather widens the taps and accumulates in fp32, outputs fp32.
+# Not parity-exact (one bf16 rounding of every value, bound stated in tests/test_gpu_kernels.py); never the headline.
+TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
                     cm32=dict(bin=(16, 22), halo=(3, 3), depth_in_lds=False),
                     cm16=dict(bin=(27, 30), halo=(3, 3), depth_in_lds=True))
 
@@ -65,6 +68,8 @@ def _tiled_env_overrides():
     import os
     if "SGC_TILED" in os.environ:
         TILED_GATHER["enabled"] = os.environ["SGC_TILED"] != "0"
+    if os.environ.get("SGC_STORAGE") in ("f32", "bf16"):
+        TILED_GATHER["storage"] = os.environ["SGC_STORAGE"]
     for key in ("cm32", "cm16"):
         spec = os.environ.get("SGC_TILED_" + key.upper())
         if spec:
@@ -286,7 +291,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
             if tiled is not None:
-                value = gemm["value"].headmajor(feat.view(N * S, C), N, S, da.num_heads)
+                value = gemm["value"].headmajor(feat.view(N * S, C), N, S, da.num_heads,
+                                                out_dtype=torch.bfloat16 if TILED_GATHER["storage"] == "bf16" else torch.float32)
                 raw = gemm["raw_hm"](geo, count=pairs_cnt)
                 del geo
                 per_pair = ops.pairs_deform_gather_tiled(value, dist, pc["pair_ref"], pc["bin_offset"], raw, H, W,

@@ -277,12 +277,12 @@ class TensorOps:
         return out
 
     # ---- 4b. LDS-tiled gather: binning, head-major operands ---------------------------------
-    def tile_window(self, H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, max_shift=(0, 0), depth_in_lds=True):
+    def tile_window(self, H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, max_shift=(0, 0), depth_in_lds=True, value_bf16=False):
         """dict(tw, th, lds_bytes, nbuf, depth_in_lds) of what ``pairs_deform_gather_tiled`` would stage."""
         import ctypes
         v = [ctypes.c_int() for _ in range(5)]
         self.lib._dll.sgc_tile_window(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y, int(max_shift[0]), int(max_shift[1]),
-                                      int(bool(depth_in_lds)), *[ctypes.byref(x) for x in v])
+                                      int(bool(depth_in_lds)), int(bool(value_bf16)), *[ctypes.byref(x) for x in v])
         return dict(zip(("tw", "th", "lds_bytes", "nbuf", "depth_in_lds"), (x.value for x in v)))
 
     def bin_pairs(self, ref_cam, pc, H, W, bin_w, bin_h):
@@ -320,7 +320,9 @@ class TensorOps:
         the binned pair order; returns out [cap, M*Cm] (rows past the pair count are not written)."""
         self._check(value_hm=value_hm, dist=dist, pair_ref=pair_ref, bin_offset=bin_offset, raw_hm=raw_hm,
                     head_shift=head_shift, out=out)
-        self._f32(value_hm=value_hm, dist=dist, pair_ref=pair_ref, raw_hm=raw_hm, out=out)
+        if value_hm.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("pairs_deform_gather_tiled: value_hm must be float32 or bfloat16 (bf16 storage mode)")
+        self._f32(dist=dist, pair_ref=pair_ref, raw_hm=raw_hm, out=out)
         self._i32(bin_offset=bin_offset, head_shift=head_shift)
         N, M, S, Cm = value_hm.shape
         D = dist.shape[-1]
@@ -333,14 +335,17 @@ class TensorOps:
             out = torch.empty((rows, M * Cm), dtype=torch.float32, device=value_hm.device)
         if rows == 0:
             return out
-        self._call("sgc_pairs_deform_gather_tiled", value_hm, dist, pair_ref, bin_offset, raw_hm, head_shift, out,
+        self._call("sgc_pairs_deform_gather_tiled", value_hm, int(value_hm.dtype == torch.bfloat16), dist, pair_ref,
+                   bin_offset, raw_hm, head_shift, out,
                    N, H, W, M, Cm, D, P, S, bin_w, bin_h, halo_x, halo_y, int(max_shift[0]), int(max_shift[1]),
                    int(bool(depth_in_lds)),
-                   _meta=dict(N=N, H=H, W=W, C=M * Cm, D=D, M=M, P=P, n_pairs=rows, bin=(bin_w, bin_h), halo=(halo_x, halo_y)))
+                   _meta=dict(N=N, H=H, W=W, C=M * Cm, D=D, M=M, P=P, n_pairs=rows, bin=(bin_w, bin_h), halo=(halo_x, halo_y),
+                              value_bytes=value_hm.element_size()))
         return out
 
-    def linear_rows_headmajor_bf16x3(self, x, w_hi, w_lo, shift, N, S, M):
-        """x [N*S, Cin] -> y [N, M, S, Cm] head-major (``sgc_linear_rows_headmajor_bf16x3``)."""
+    def linear_rows_headmajor_bf16x3(self, x, w_hi, w_lo, shift, N, S, M, out_dtype=torch.float32):
+        """x [N*S, Cin] -> y [N, M, S, Cm] head-major (``sgc_linear_rows_headmajor_bf16x3``); ``out_dtype`` bfloat16 = the
+        opt-in bf16 storage mode (RNE of the fp32 result)."""
         self._check(x=x, w_hi=w_hi, w_lo=w_lo, shift=shift)
         self._f32(x=x, shift=shift)
         rows, Cin = x.shape
@@ -348,8 +353,10 @@ class TensorOps:
         if rows != N * S or Cout % M or w_hi.shape[-1] != Cin or w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16:
             raise RuntimeError("linear_rows_headmajor_bf16x3: inconsistent shapes")
         Cm = Cout // M
-        y = torch.empty((N, M, S, Cm), dtype=torch.float32, device=x.device)
-        self._call("sgc_linear_rows_headmajor_bf16x3", x, w_hi, w_lo, shift, y, N, S, Cin, M, Cm,
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("linear_rows_headmajor_bf16x3: out_dtype must be float32 or bfloat16")
+        y = torch.empty((N, M, S, Cm), dtype=out_dtype, device=x.device)
+        self._call("sgc_linear_rows_headmajor_bf16x3", x, w_hi, w_lo, shift, y, int(out_dtype == torch.bfloat16), N, S, Cin, M, Cm,
                    _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
         return y
 

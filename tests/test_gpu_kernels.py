@@ -590,3 +590,49 @@ def test_projection_with_a_query_selection_equals_gather_then_project(oracle_ops
     assert torch.equal(rc_a, rc_b) and torch.equal(mk_a, mk_b)
     rc_c, mk_c = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0, sel=sel)
     assert torch.equal(rc_b.cpu(), rc_c) and torch.equal(mk_b.cpu(), mk_c)
+
+
+@pytest.mark.parametrize("C,HW,bins", [(256, (30, 40), (13, 10)), (128, (29, 40), (20, 15))])
+def test_bf16_storage_mode_of_the_tiled_gather(C, HW, bins, oracle_ops, gpu_ops):
+    """Opt-in bf16 STORAGE mode (row N2; BASELINE.json configs #2 / #5): the head-major value map is bfloat16, taps are
+    widened to fp32, accumulation and outputs stay fp32.  (1) Against the oracle fed the SAME bf16 map: 1e-5 (it is the
+    same arithmetic).  (2) Against the fp32 oracle: every value carries one bf16 rounding (relative 2^-9), the output is a
+    convex-ish combination of <= 16 taps with weights summing to <= 1, so |err| <= 2^-9 * max|value|; measured ~1e-3 of
+    the value scale -- asserted at 4e-3 (2^-8)."""
+    from tests.tile_contract import check_bins, raw_to_headmajor, value_to_headmajor
+    N, Nq, D, M, P = 5, 800, 12, 8, 4
+    H, W = HW
+    ref3d, origin, proj = _scene(N, Nq, 6)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = oracle_ops.compact_pairs(mk)
+    n_pairs, cap = int(pc["totals"][0]), pc["pair_q"].numel()
+    g = torch.Generator().manual_seed(33)
+    value = torch.randn(N, H * W, M, C // M, generator=g)
+    dist = torch.randn(N, H * W, D, generator=g).mul(2).softmax(-1).contiguous()
+    raw = torch.randn(cap, M * P * 4, generator=g)
+    raw[:, :M * P * 3] *= 1.5
+    bw, bh = bins
+    before = dict(pc, slot=pc["slot"].clone())
+    b_c = oracle_ops.bin_pairs(rc, dict(pc, slot=pc["slot"].clone()), H, W, bw, bh)
+    old = check_bins(b_c, before, rc, n_pairs, H, W, bw, bh)
+    raw_new = torch.zeros_like(raw)
+    raw_new[:n_pairs] = raw[old]
+    rhm = raw_to_headmajor(raw_new, M, P)
+    vhm = value_to_headmajor(value)
+    vhm16 = vhm.to(torch.bfloat16)
+    want_f32 = oracle_ops.pairs_deform_gather_tiled(vhm, dist, b_c["pair_ref"], b_c["bin_offset"], rhm, H, W, P, bw, bh, 3, 3)
+    want_b16 = oracle_ops.pairs_deform_gather_tiled(vhm16, dist, b_c["pair_ref"], b_c["bin_offset"], rhm, H, W, P, bw, bh, 3, 3)
+    cu = lambda t: t.cuda()
+    got = gpu_ops.pairs_deform_gather_tiled(cu(vhm16), cu(dist), cu(b_c["pair_ref"]), cu(b_c["bin_offset"]), cu(rhm), H, W, P,
+                                            bw, bh, 3, 3)
+    close(got[:n_pairs], want_b16[:n_pairs])
+    scale = float(value.abs().max())
+    err = float((got[:n_pairs].cpu() - want_f32[:n_pairs]).abs().max())
+    assert err <= 2.0 ** -8 * scale, (err, scale)
+    # the producer: value_proj's epilogue writing bf16 == RNE of the fp32 head-major result
+    x = torch.randn(N * H * W, 64, generator=g)
+    w = torch.randn(C, 64, generator=g) * 0.2
+    hi, lo = gpu_ops.split_bf16(w.view(1, C, 64))
+    y32 = gpu_ops.linear_rows_headmajor_bf16x3(cu(x), cu(hi), cu(lo), None, N, H * W, M)
+    y16 = gpu_ops.linear_rows_headmajor_bf16x3(cu(x), cu(hi), cu(lo), None, N, H * W, M, out_dtype=torch.bfloat16)
+    assert torch.equal(y16, y32.to(torch.bfloat16))
