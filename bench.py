@@ -407,6 +407,19 @@ def main():
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
             tot = sum(t for t, _ in items)
             print(f"  {name:32s} {len(items):5d} launches  {tot * 1e3 / args.steps:8.3f} ms/step", file=sys.stderr)
+            shapes = {}
+            for t, m in items:                                   # per-shape split of the GEMM / convolution entry points
+                if "Cin" in m:
+                    key = (m.get("V"), m.get("Cin"), m.get("Cout"), m.get("taps"), m.get("OV"))
+                    a = shapes.setdefault(key, [0, 0.0])
+                    a[0] += 1
+                    a[1] += t
+            n_eager = max(6, min(args.steps, 20)) if not eager_events else args.steps
+            for key, (cnt, tt) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
+                V, Cin, Cout, taps, OV = key
+                gf = 2.0 * (taps or 1) * Cin * Cout * (OV or V) / 1e9
+                print(f"      V={V:7d} Cin={Cin:5d} Cout={Cout:5d} taps={taps:3d} -> {cnt / n_eager:4.1f}/scene {tt / cnt * 1e6:8.1f} us  "
+                      f"{gf:7.1f} GF  {gf / (tt / cnt) / 1e3:7.1f} TF-equiv", file=sys.stderr)
 
     # ---- strict-fp32 leg: the same scenes with exact fp32 products on the fp32 MFMA (--conv-mode f32), so that the
     #      bf16x3 headline never hides what IEEE-fp32 arithmetic costs ----

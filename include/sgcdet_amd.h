@@ -142,6 +142,22 @@ int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *sha
                        int B, int S, int M, int Cm, int D, int dist_heads,
                        int L, int Q, int P, sgc_stream_t stream);
 
+/* Item-list forms of the fused operator and its backward (training path): item i samples map item_batch[i] (int32,
+ * a camera index < B) -- the reference's padded [N, max_len] rebatch (TU/deformable_cross_attention.py:759-773) without
+ * its padding rows.  loc3 [n_items,M,L,P,3], attn [n_items,M,L,P] (NULL = 1), out / grad_out [n_items, M*Cm];
+ * grad_value [B,S,M,Cm] and grad_dist [B,S,dist_heads,D] are ACCUMULATED (caller zeroes), grad_loc3 / grad_attn are
+ * fully written.  Same arithmetic as sgc_dfa3d_forward / sgc_dfa3d_backward.                                       */
+int sgc_dfa3d_forward_items(const float *value, const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                            const float *loc3, const float *attn_or_null, const int32_t *item_batch, float *out,
+                            float *score_or_null, int B, int S, int M, int Cm, int D, int dist_heads, int L,
+                            int n_items, int P, sgc_stream_t stream);
+int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_t *shapes3,
+                             const int64_t *lsi, const float *loc3, const float *attn_or_null,
+                             const int32_t *item_batch, const float *grad_out, float *grad_value, float *grad_dist,
+                             float *grad_loc3, float *grad_attn_or_null,
+                             int B, int S, int M, int Cm, int D, int dist_heads,
+                             int L, int n_items, int P, sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 3. Voxel -> pixel projection and per-camera compaction
  *    (replaces VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223, and

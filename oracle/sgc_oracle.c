@@ -416,6 +416,46 @@ int sgc_dfa3d_backward(const float *value, const float *dist, const int64_t *sha
   return SGC_OK;
 }
 
+/* item-list forms: item i samples map item_batch[i]; one (B = 1, Q = 1) call of the batch form per item */
+int sgc_dfa3d_forward_items(const float *value, const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                            const float *loc3, const float *attn_or_null, const int32_t *item_batch, float *out,
+                            float *score_or_null, int B, int S, int M, int Cm, int D, int dist_heads, int L,
+                            int n_items, int P, sgc_stream_t stream) {
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !item_batch || !out) return fail(SGC_EINVAL, "null pointer");
+  const int64_t MC = (int64_t)M * Cm, SPI = (int64_t)M * L * P;
+  for (int i = 0; i < n_items; ++i) {
+    const int b = item_batch[i];
+    if (b < 0 || b >= B) return fail(SGC_EINVAL, "item_batch out of range");
+    const int rc = sgc_dfa3d_forward(value + (int64_t)b * S * MC, dist + (int64_t)b * S * dist_heads * D, shapes3, lsi,
+                                     loc3 + i * SPI * 3, attn_or_null ? attn_or_null + i * SPI : NULL, out + i * MC,
+                                     score_or_null ? score_or_null + i * SPI * 4 : NULL, 1, S, M, Cm, D, dist_heads, L, 1, P, stream);
+    if (rc) return rc;
+  }
+  return SGC_OK;
+}
+
+int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_t *shapes3,
+                             const int64_t *lsi, const float *loc3, const float *attn_or_null,
+                             const int32_t *item_batch, const float *grad_out, float *grad_value, float *grad_dist,
+                             float *grad_loc3, float *grad_attn_or_null,
+                             int B, int S, int M, int Cm, int D, int dist_heads,
+                             int L, int n_items, int P, sgc_stream_t stream) {
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !item_batch || !grad_out || !grad_value || !grad_dist || !grad_loc3)
+    return fail(SGC_EINVAL, "null pointer");
+  const int64_t MC = (int64_t)M * Cm, SPI = (int64_t)M * L * P;
+  for (int i = 0; i < n_items; ++i) {
+    const int b = item_batch[i];
+    if (b < 0 || b >= B) return fail(SGC_EINVAL, "item_batch out of range");
+    const int rc = sgc_dfa3d_backward(value + (int64_t)b * S * MC, dist + (int64_t)b * S * dist_heads * D, shapes3, lsi,
+                                      loc3 + i * SPI * 3, attn_or_null ? attn_or_null + i * SPI : NULL, grad_out + i * MC,
+                                      grad_value + (int64_t)b * S * MC, grad_dist + (int64_t)b * S * dist_heads * D,
+                                      grad_loc3 + i * SPI * 3, grad_attn_or_null ? grad_attn_or_null + i * SPI : NULL,
+                                      1, S, M, Cm, D, dist_heads, L, 1, P, stream);
+    if (rc) return rc;
+  }
+  return SGC_OK;
+}
+
 /* ---- 3. projection + compaction ------------------------------------------ */
 /* VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223.  Fixed order:
  *   p = ref + origin;  cam_r = ((P_r0*x + P_r1*y) + P_r2*z) + P_r3  (no FMA);

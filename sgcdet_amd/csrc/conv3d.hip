@@ -430,6 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       // head-major store: the lanes of a wave instruction walk ROWS of one head (a head's rows are hm_cm * 4 bytes apart in
       // its plane), so a wave writes one contiguous 1 KiB run instead of 8 head segments 1 plane apart
       const int cvh = p.hm_cm / 4, per_head = BM * cvh, heads = p.Cout / p.hm_cm;
+      const int ncam0 = m0 / p.hm_S, s0 = m0 - ncam0 * p.hm_S;
       for (int e = tid; e < BM * C4; e += NT) {
         const int hl = e / per_head, rr = e - hl * per_head;
         const int rl = rr / cvh, c4 = hl * cvh + (rr - rl * cvh);
@@ -440,7 +441,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
           const float4 sh4 = *reinterpret_cast<const float4 *>(p.shift + col);
           v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
         }
-        const int ncam = m / p.hm_S, spx = m - ncam * p.hm_S, head = col / p.hm_cm;
+        int ncam = ncam0, spx = s0 + rl;             // rows of one tile straddle at most a few cameras: no division per element
+        while (spx >= p.hm_S) { spx -= p.hm_S; ++ncam; }
+        const int head = (n0 / p.hm_cm) + hl;
         const int64_t o = (((int64_t)ncam * heads + head) * p.hm_S + spx) * p.hm_cm + (col - head * p.hm_cm);
         if (p.hm_bf16) {
           bf16x4 h;

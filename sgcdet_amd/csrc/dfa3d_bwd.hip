@@ -366,6 +366,26 @@ extern "C" int sgc_dfa3d_backward(const float *value, const float *dist, const i
   return launch_bwd(p, (hipStream_t)stream);
 }
 
+extern "C" int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_t *shapes3,
+                                        const int64_t *lsi, const float *loc3, const float *attn_or_null,
+                                        const int32_t *item_batch, const float *grad_out, float *grad_value, float *grad_dist,
+                                        float *grad_loc3, float *grad_attn_or_null,
+                                        int B, int S, int M, int Cm, int D, int dist_heads,
+                                        int L, int n_items, int P, sgc_stream_t stream) {
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !item_batch || !grad_out || !grad_value || !grad_dist || !grad_loc3)
+    return set_error(SGC_EINVAL, "sgc_dfa3d_backward_items: null pointer");
+  if (dist_heads != 1 && dist_heads != M) return set_error(SGC_EINVAL, "sgc_dfa3d_backward_items: dist_heads must be 1 or M");
+  if (B <= 0 || n_items < 0) return set_error(SGC_EINVAL, "sgc_dfa3d_backward_items: bad size");
+  if (n_items == 0) return SGC_OK;
+  BwdParams p = {};
+  p.value = value; p.dist = dist; p.shapes = shapes3; p.shape_stride = 3; p.lsi = lsi; p.loc = loc3; p.loc_stride = 3;
+  p.attn = attn_or_null; p.grad_out = grad_out; p.grad_value = grad_value; p.grad_dist = grad_dist; p.grad_loc = grad_loc3;
+  p.grad_attn = grad_attn_or_null; p.grad_loc_stride = 3; p.item_batch = item_batch;
+  p.S = S; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = dist_heads; p.L = L; p.Q = 1; p.P = P;
+  p.n_items = n_items; p.fused = 1;
+  return launch_bwd(p, (hipStream_t)stream);
+}
+
 extern "C" int sgc_wms_backward(const float *value, const int64_t *shapes2, const int64_t *lsi,
                                 const float *loc2, const float *attn, const float *score,
                                 const float *grad_out, float *grad_value, float *grad_loc2,

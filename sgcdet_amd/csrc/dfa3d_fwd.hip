@@ -40,6 +40,7 @@ struct FwdParams {
   const float *ref_cam;     // [N,Nq,3]
   const float *raw;         // [pairs, M*P*4]
   const int32_t *pair_cam, *pair_q, *totals;
+  const int32_t *item_batch; // batch mode, optional: per-item index of the map it samples (item lists: sgc_dfa3d_forward_items)
   // outputs
   float *out;               // [items, M*Cm]
   float *score;             // optional [items,M,L,P,4]
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
     int b, H, W, D, lvl0;
     float x, y, z, aw;
     if (MODE == kBatch) {
-      b = item / p.Q;
+      b = p.item_batch ? p.item_batch[item] : item / p.Q;
       H = (int)p.shapes3[l * 3]; W = (int)p.shapes3[l * 3 + 1]; D = (int)p.shapes3[l * 3 + 2];
       lvl0 = (int)p.lsi[l];
       const int64_t g = (int64_t)item * SPI + r;
@@ -610,6 +611,25 @@ extern "C" int sgc_dfa3d_forward(const float *value, const float *dist, const in
   p.out = out; p.score = score_or_null;
   p.S = S; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = dist_heads; p.L = L; p.Q = Q; p.P = P;
   p.n_items = B * Q;
+  return launch_fwd<kBatch>(p, p.n_items, (hipStream_t)stream);
+}
+
+// Item-list form of the fused operator: item i samples map item_batch[i] (a camera) -- the padded [N, max_len] rebatch of
+// the reference (TU/deformable_cross_attention.py:759-773) without its padding rows; used by the training path.
+extern "C" int sgc_dfa3d_forward_items(const float *value, const float *dist, const int64_t *shapes3, const int64_t *lsi,
+                                       const float *loc3, const float *attn_or_null, const int32_t *item_batch, float *out,
+                                       float *score_or_null, int B, int S, int M, int Cm, int D, int dist_heads, int L,
+                                       int n_items, int P, sgc_stream_t stream) {
+  if (!value || !dist || !shapes3 || !lsi || !loc3 || !item_batch || !out) return set_error(SGC_EINVAL, "sgc_dfa3d_forward_items: null pointer");
+  if (B <= 0 || S <= 0 || M <= 0 || Cm <= 0 || D <= 0 || L <= 0 || n_items < 0 || P <= 0)
+    return set_error(SGC_EINVAL, "sgc_dfa3d_forward_items: non-positive size");
+  if (dist_heads != 1 && dist_heads != M) return set_error(SGC_EINVAL, "sgc_dfa3d_forward_items: dist_heads must be 1 or M");
+  if (n_items == 0) return SGC_OK;
+  FwdParams p = {};
+  p.value = value; p.dist = dist; p.shapes3 = shapes3; p.lsi = lsi; p.loc3 = loc3; p.attn = attn_or_null;
+  p.item_batch = item_batch; p.out = out; p.score = score_or_null;
+  p.S = S; p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = dist_heads; p.L = L; p.Q = 1; p.P = P;
+  p.n_items = n_items;
   return launch_fwd<kBatch>(p, p.n_items, (hipStream_t)stream);
 }
 

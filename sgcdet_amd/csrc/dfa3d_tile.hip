@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(const int32_t *__restric
     unsigned long long rem = __ballot(act);
     while (rem) {
       const int l = __ffsll((long long)rem) - 1;
-      const int b0 = __shfl(b, l);
+      const int b0 = __builtin_amdgcn_readlane(b, l);      // l is wave-uniform: a VALU read, no LDS round trip
       const unsigned long long same = __ballot(act && b == b0);
       if (lane == l) mine[b0] += __popcll(same);
       rem &= ~same;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(const int32_t *__restric
     int pos = 0;
     while (rem) {
       const int l = __ffsll((long long)rem) - 1;
-      const int b0 = __shfl(b, l);
+      const int b0 = __builtin_amdgcn_readlane(b, l);      // l is wave-uniform: a VALU read, no LDS round trip
       const unsigned long long same = __ballot(act && b == b0);
       const int bs = mine[b0];                      // every lane of the wave reads before the leader writes
       __builtin_amdgcn_wave_barrier();

@@ -46,6 +46,10 @@ __device__ __forceinline__ int block_scan_1024(int v, int *total, int *wave_sums
   return base + incl - v;
 }
 
+// KPT > 0: the workgroup keeps all keys in registers (n <= 1024 * KPT): ONE pass over global memory with every load of a
+// thread in flight together; the first version re-read the scores in each of its 5 loops, one dependent ~1 us load per
+// iteration (76 us per launch at n = 25 600).  KPT == 0: any n, keys re-read from global memory in batches of 8.
+template <int KPT>
 __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restrict__ score, int n, int k,
                                                            int64_t *__restrict__ idx_out, int64_t *__restrict__ valid_out,
                                                            float *__restrict__ mask_out) {
@@ -54,6 +58,17 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
   __shared__ uint32_t s_prefix;
   __shared__ int s_remaining;
   const int tid = threadIdx.x;
+  constexpr int B = KPT > 0 ? KPT : 8;          // keys per thread per batch
+  uint32_t keys[B];
+  const int n_batches = KPT > 0 ? 1 : (n + 1024 * B - 1) / (1024 * B);
+  auto load_batch = [&](int bi) {               // element j of the batch: i = (bi * B + j) * 1024 + tid (coalesced)
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int i = (bi * B + j) * 1024 + tid;
+      keys[j] = i < n ? float_key(score[i]) : 0u;
+    }
+  };
+  if (KPT > 0) load_batch(0);
   if (tid == 0) { s_prefix = 0; s_remaining = k; }
   // ---- radix select, most significant byte first: after pass p the top (p+1) bytes of the k-th largest key are known
   for (int pass = 0; pass < 4; ++pass) {
@@ -62,28 +77,29 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
     __syncthreads();
     const uint32_t prefix = s_prefix;
     const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-      const int i = i0 + tid;
-      bool act = false;
-      unsigned digit = 0;
-      if (i < n) {
-        const uint32_t key = float_key(score[i]);
-        act = (key & hi_mask) == prefix;
-        digit = (key >> shift) & 255u;
-      }
-      // occupancy scores share their leading bytes, so most lanes of a wave hit ONE bin (a same-address LDS atomic runs
-      // lane by lane): the wave's three most common digits are counted by ballot and added once, the rest individually
+    for (int bi = 0; bi < n_batches; ++bi) {
+      if (KPT == 0) load_batch(bi);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const unsigned long long rem = __ballot(act);
-        if (!rem) break;
-        const int l = __ffsll((long long)rem) - 1;
-        const unsigned d0 = (unsigned)__shfl((int)digit, l);
-        const unsigned long long same = __ballot(act && digit == d0);
-        if ((int)(threadIdx.x & 63) == l) atomicAdd(&hist[d0], __popcll(same));
-        if (digit == d0) act = false;
+      for (int j = 0; j < B; ++j) {
+        const int i = (bi * B + j) * 1024 + tid;
+        if ((bi * B + j) * 1024 >= n) break;                  // wave-uniform
+        const uint32_t key = keys[j];
+        bool act = i < n && (key & hi_mask) == prefix;
+        const unsigned digit = (key >> shift) & 255u;
+        // occupancy scores share their leading bytes, so most lanes of a wave hit ONE bin (a same-address LDS atomic runs
+        // lane by lane): the wave's three most common digits are counted by ballot and added once, the rest individually
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const unsigned long long rem = __ballot(act);
+          if (!rem) break;
+          const int l = __ffsll((long long)rem) - 1;
+          const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, l);   // l is wave-uniform: a VALU read, no LDS round trip
+          const unsigned long long same = __ballot(act && digit == d0);
+          if ((int)(threadIdx.x & 63) == l) atomicAdd(&hist[d0], __popcll(same));
+          if (digit == d0) act = false;
+        }
+        if (act) atomicAdd(&hist[digit], 1);
       }
-      if (act) atomicAdd(&hist[digit], 1);
     }
     __syncthreads();
     if (tid == 0) {
@@ -99,25 +115,45 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
   }
   const uint32_t thr = s_prefix;                // key of the k-th largest score
   const int need_eq = s_remaining;              // elements equal to it that belong to the selection (lowest indices first)
-  // ---- ordered compaction: ascending flat index, ties by lowest index
-  int out_base = 0, eq_base = 0;
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + tid;
-    uint32_t key = 0;
-    if (i < n) key = float_key(score[i]);
-    const int is_eq = (i < n && key == thr) ? 1 : 0;
-    int eq_tot;
-    const int eq_rank = eq_base + block_scan_1024(is_eq, &eq_tot, wave_sums);
-    const int sel = (i < n && (key > thr || (is_eq && eq_rank < need_eq))) ? 1 : 0;
-    int sel_tot;
-    const int pos = out_base + block_scan_1024(sel, &sel_tot, wave_sums);
-    if (sel) idx_out[pos] = i;
-    if (i < n) {
-      if (valid_out) valid_out[i] = sel;
-      if (mask_out) mask_out[i] = sel ? 1.f : 0.f;
+  // ---- ordered compaction: ascending flat index, ties by lowest index.  Per chunk of 1024 consecutive elements ONE
+  //      packed scan over the 16 waves: (elements above the cut) << 16 | (elements equal to it); inside a wave the ranks are
+  //      popcounts of ballots.  Equal elements are taken in index order until need_eq is used up, so the output position is
+  //      out_base + greater_before + min(eq_rank, need_eq) - min(eq_base, need_eq).
+  __shared__ int wave_cnt[2][16];
+  const int lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int out_base = 0, eq_base = 0, parity = 0;
+  for (int bi = 0; bi < n_batches; ++bi) {
+    if (KPT == 0) load_batch(bi);
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int i = (bi * B + j) * 1024 + tid;
+      if ((bi * B + j) * 1024 >= n) break;                    // wave- and block-uniform
+      const uint32_t key = keys[j];
+      const bool is_gt = i < n && key > thr, is_eq = i < n && key == thr;
+      const unsigned long long bg = __ballot(is_gt), be = __ballot(is_eq);
+      if (lane == 0) wave_cnt[parity][wid] = (__popcll(bg) << 16) | __popcll(be);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int c = wave_cnt[parity][w];
+        if (w < wid) before += c;
+        total += c;
+      }
+      parity ^= 1;                                            // the other buffer is free: every wave has passed the barrier since
+      const int gt_before = (before >> 16) + __popcll(bg & lt);
+      const int eq_rank = eq_base + (before & 0xffff) + __popcll(be & lt);
+      const bool sel = is_gt || (is_eq && eq_rank < need_eq);
+      if (sel) idx_out[out_base + gt_before + min(eq_rank, need_eq) - min(eq_base, need_eq)] = i;
+      if (i < n) {
+        if (valid_out) valid_out[i] = sel;
+        if (mask_out) mask_out[i] = sel ? 1.f : 0.f;
+      }
+      const int eq_tot = total & 0xffff;
+      out_base += (total >> 16) + min(eq_base + eq_tot, need_eq) - min(eq_base, need_eq);
+      eq_base += eq_tot;
     }
-    out_base += sel_tot;
-    eq_base += eq_tot;
   }
 }
 
@@ -203,8 +239,12 @@ extern "C" int sgc_topk_select(const float *score, int n, int k, int64_t *idx_ou
                                float *mask_or_null, sgc_stream_t stream) {
   if (!score || !idx_out) return set_error(SGC_EINVAL, "sgc_topk_select: null pointer");
   if (n <= 0 || k <= 0 || k > n) return set_error(SGC_EINVAL, "sgc_topk_select: need 0 < k <= n (k = %d, n = %d)", k, n);
-  hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, n, k, idx_out, valid_or_null,
-                     mask_or_null);
+  if (n <= 1024 * 8)
+    hipLaunchKernelGGL(topk_select_kernel<8>, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, n, k, idx_out, valid_or_null, mask_or_null);
+  else if (n <= 1024 * 32)
+    hipLaunchKernelGGL(topk_select_kernel<32>, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, n, k, idx_out, valid_or_null, mask_or_null);
+  else
+    hipLaunchKernelGGL(topk_select_kernel<0>, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, n, k, idx_out, valid_or_null, mask_or_null);
   return check_launch("topk_select_kernel");
 }
 

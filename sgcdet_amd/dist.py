@@ -187,3 +187,101 @@ class OverlappedGradAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SyncBN.  The reference trains with ``sync_batchnorm=True`` (main.py:81: Lightning converts the 15 BatchNorm3d layers of
+# FastIndoorImVoxelNeck to torch.nn.SyncBatchNorm) at ONE scene per GPU, so the batch statistics of every layer are
+# taken over the scenes of all ranks.  torch's SyncBatchNorm only accepts CUDA tensors and does three collectives per
+# layer; this one is plain tensor arithmetic around one all_gather in forward ([mean, biased var, count] per rank, 2C+1
+# floats, merged with the parallel-variance formula) and one all_reduce in backward ([sum dy, sum dy*(x-mean)], 2C
+# floats), works on any backend (RCCL on the GPU, gloo in the CPU tests), and is bit-compatible with nn.BatchNorm3d
+# in a single process.
+class _SyncBatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        n_local = x.numel() // C
+        xf = x.float()
+        mean_l = xf.mean(dims)
+        var_l = xf.var(dims, unbiased=False)
+        packed = torch.cat([mean_l, var_l, xf.new_tensor([float(n_local)])])
+        world = dist.get_world_size(group) if _dist_on() else 1
+        if world > 1:
+            gathered = [torch.empty_like(packed) for _ in range(world)]
+            dist.all_gather(gathered, packed, group=group)
+            allp = torch.stack(gathered)
+        else:
+            allp = packed[None]
+        means, vars_, counts = allp[:, :C], allp[:, C:2 * C], allp[:, 2 * C:]
+        n_tot = counts.sum()
+        mean = (means * counts).sum(0) / n_tot
+        var = ((vars_ + (means - mean) ** 2) * counts).sum(0) / n_tot            # biased, over all ranks
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                unbiased = var * (n_tot / (n_tot - 1).clamp(min=1.0))
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (xf - mean.view(shape)) * invstd.view(shape)
+        y = xhat * weight.float().view(shape) + bias.float().view(shape)
+        ctx.save_for_backward(xhat, weight, invstd, n_tot)
+        ctx.group = group
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xhat, weight, invstd, n_tot = ctx.saved_tensors
+        C = gy.shape[1]
+        dims = [0] + list(range(2, gy.dim()))
+        shape = [1, C] + [1] * (gy.dim() - 2)
+        gyf = gy.float()
+        sum_dy = gyf.sum(dims)
+        sum_dy_xhat = (gyf * xhat).sum(dims)
+        packed = torch.cat([sum_dy, sum_dy_xhat])
+        if _dist_on() and dist.get_world_size(ctx.group) > 1:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
+        g_sum, g_dot = packed[:C], packed[C:]
+        w = weight.float()
+        gx = (gyf - (g_sum / n_tot).view(shape) - xhat * (g_dot / n_tot).view(shape)) * (invstd * w).view(shape)
+        # weight / bias gradients are LOCAL sums: the gradient all-reduce of the step averages them like every other parameter
+        return gx.to(gy.dtype), sum_dy_xhat.to(weight.dtype), sum_dy.to(weight.dtype), None, None, None, None, None
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+class SyncBatchNorm3d(torch.nn.BatchNorm3d):
+    """nn.BatchNorm3d whose TRAINING statistics are taken over the batch elements of all ranks (see above).  Same
+    parameters / buffers / state-dict keys; eval mode is the parent's."""
+
+    process_group = None
+
+    def forward(self, x):
+        if not self.training or not self.track_running_stats and not self.training:
+            return super().forward(x)
+        if self.momentum is None:
+            raise NotImplementedError("SyncBatchNorm3d: cumulative moving average (momentum=None) is not used by SGCDet")
+        if self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return _SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                      self.momentum, self.process_group)
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """Replaces every nn.BatchNorm3d under ``module`` (the neck's 15 layers) by ``SyncBatchNorm3d`` sharing its parameters
+    and buffers -- what ``pl.Trainer(sync_batchnorm=True)`` does in the reference (main.py:81).  Returns ``module``."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.BatchNorm3d) and not isinstance(child, SyncBatchNorm3d):
+            sbn = SyncBatchNorm3d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+            sbn.weight, sbn.bias = child.weight, child.bias
+            sbn.running_mean, sbn.running_var, sbn.num_batches_tracked = child.running_mean, child.running_var, child.num_batches_tracked
+            sbn.process_group = process_group
+            sbn.train(child.training)
+            setattr(module, name, sbn)
+        else:
+            convert_sync_batchnorm(child, process_group)
+    return module

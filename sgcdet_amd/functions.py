@@ -104,6 +104,35 @@ class WeightedMultiScaleDeformableAttnFunction_fp32(Function):
         return grad_value, None, None, grad_loc, grad_attn, grad_score, None
 
 
+class PairListDeformAttnFunction(Function):
+    """The fused DFA3D operator over an ITEM LIST: item i = (camera ``item_batch[i]``, its sampling locations / weights).
+    Training-path counterpart of ``MultiScale3DDeformableAttnFunction_fp32`` without the reference's padded
+    [N, max_len] rebatch (TU/deformable_cross_attention.py:759-773): only visible (camera, voxel) pairs are sampled and
+    back-propagated.  value [B,S,M,Cm], dist [B,S,1|M,D], loc3 [n,M,L,P,3], attn [n,M,L,P] -> [n, M*Cm]."""
+
+    @staticmethod
+    def forward(ctx, value, value_dpt_dist, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, item_batch):
+        value = value.float().contiguous()
+        value_dpt_dist = value_dpt_dist.float().contiguous()
+        sampling_locations = sampling_locations.float().contiguous()
+        attention_weights = attention_weights.float().contiguous()
+        item_batch = item_batch.to(torch.int32).contiguous()
+        out = ext.ops().dfa3d_forward_items(value, value_dpt_dist, value_spatial_shapes, value_level_start_index,
+                                            sampling_locations, attention_weights, item_batch)
+        ctx.save_for_backward(value, value_dpt_dist, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights, item_batch)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, dist, shapes3, lsi, loc, attn, item_batch = ctx.saved_tensors
+        gv, gd, gl, ga = ext.ops().dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, item_batch,
+                                                        grad_output.float().contiguous())
+        return gv, gd, None, None, gl, ga, None
+
+
 # the DFA3D package spells them without the suffix (dfa3D/ops/multi_scale_3D_deform_attn.py:22,67,146)
 MultiScale3DDeformableAttnFunction = MultiScale3DDeformableAttnFunction_fp32
 MultiScaleDepthScoreSampleFunction = MultiScaleDepthScoreSampleFunction_fp32

@@ -332,6 +332,53 @@ class DeformCrossAttention_DFA3D(BaseModule):
         out = self.dropout(out)
         return out if zero_query else out + query
 
+    # ---- training: pair list, differentiable --------------------------------------------------
+    # The reference (and `_forward_reference_layout` below, kept as the checker) pads every camera's visible queries to
+    # max_len rows and samples / back-propagates the padding too.  Here the differentiable path runs on the visible pairs
+    # only: the fused operator and its backward take an item list (functions.PairListDeformAttnFunction), the Linears are
+    # torch ops on [n_pairs, .] rows; the inter-view nn.MultiheadAttention keeps the reference's dense [N, L, C] slots.
+    train_pair_list = True
+
+    def _forward_pairs_train(self, query, feat, dist, ref_cam, mask, spatial_shapes, level_start_index):
+        from ..functions import PairListDeformAttnFunction
+        C = self.embed_dims
+        N, Nq = mask.shape
+        cam, q = mask.nonzero(as_tuple=True)                         # camera-major, ascending query: the pair list
+        n_pairs = cam.shape[0]
+        da = self.deformable_attention
+        M, L, P = da.num_heads, da.num_levels, da.num_points
+        S = feat.shape[1]
+        shapes3 = da.get_spatial_shape_3D(spatial_shapes, dist.shape[-1])
+        ref = ref_cam[cam, q]                                          # [n_pairs, 3]
+        item = cam.to(torch.int32)
+        geo = PairListDeformAttnFunction.apply(feat.view(N, S, 1, C), dist.view(N, S, 1, -1), shapes3, level_start_index,
+                                               ref.view(n_pairs, 1, 1, 1, 3).expand(n_pairs, 1, L, 1, 3).contiguous()
+                                               if L > 1 else ref.view(n_pairs, 1, 1, 1, 3),
+                                               torch.ones((n_pairs, 1, L, 1), dtype=feat.dtype, device=feat.device), item)
+        if self.deformable_attn:
+            value = da.value_proj(feat).view(N, S, M, C // M)
+            off_uv = da.sampling_offsets(geo).view(n_pairs, M, L, P, 2)
+            off_d = da.sampling_offsets_depth(geo).view(n_pairs, M, L, P, 1)
+            attn = da.attention_weights(geo).view(n_pairs, M, L * P).softmax(-1).view(n_pairs, M, L, P)
+            normalizer = torch.stack([shapes3[..., 1], shapes3[..., 0], shapes3[..., 2]], -1).to(feat.dtype)   # (W, H, D) per level
+            loc = ref.view(n_pairs, 1, 1, 1, 3) + torch.cat([off_uv, off_d], -1) / normalizer[None, None, :, None, :]
+            per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item)
+        else:
+            per_pair = geo
+        slots = torch.zeros((N, Nq, C), dtype=feat.dtype, device=feat.device).index_put((cam, q), per_pair)
+        count = mask.sum(0)
+        valid_index = count.nonzero()[:, 0]
+        valid_slots = slots[:, valid_index]                                # [N,L,C]
+        valid_mask = mask[:, valid_index]                                  # [N,L]
+        pooled = (valid_slots * valid_mask[..., None]).sum(0) / count[valid_index][:, None]
+        pooled = self.output_proj(pooled)
+        if self.inter_view_aggregation == "attn":
+            pooled, _ = self.attention_pooling(pooled[None], valid_slots, valid_slots, ~valid_mask.t())
+            pooled = pooled[0]
+        out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
+        out = out.index_put((torch.zeros_like(valid_index), valid_index), pooled)
+        return self.dropout(out) + query
+
     # ---- training: reference data layout, differentiable -----------------------------------
     def _forward_reference_layout(self, query, feat, dist, ref_cam, mask, spatial_shapes, level_start_index,
                                   **kwargs):
@@ -387,8 +434,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
         ref_cam = reference_points_cam.reshape(N, Nq, 3)
         if torch.is_grad_enabled() and (query.requires_grad or feat.requires_grad or dist.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
-            return self._forward_reference_layout(query, feat, dist, ref_cam, bev_mask.reshape(N, Nq).bool(),
-                                                  spatial_shapes, level_start_index)
+            fn = self._forward_pairs_train if self.train_pair_list else self._forward_reference_layout
+            return fn(query, feat, dist, ref_cam, bev_mask.reshape(N, Nq).bool(), spatial_shapes, level_start_index)
         if spatial_shapes.shape[0] != 1:
             raise NotImplementedError("pair-list path supports one feature level per call (all SGCDet configs)")
         hw = kwargs.get("spatial_hw")

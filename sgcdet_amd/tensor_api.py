@@ -181,6 +181,41 @@ class TensorOps:
                    grad_dist, grad_loc3, grad_attn, B, S, M, Cm, D, dist_heads, L, Q, P)
         return grad_value, grad_dist, grad_loc3, grad_attn
 
+    def dfa3d_forward_items(self, value, dist, shapes3, lsi, loc3, attn, item_batch):
+        """Item-list form: value [B,S,M,Cm], dist [B,S,dh,D], loc3 [n,M,L,P,3], attn [n,M,L,P] | None, item_batch [n] int32
+        -> out [n, M*Cm]."""
+        self._check(value=value, value_dpt_dist=dist, value_spatial_shapes=shapes3, value_level_start_index=lsi,
+                    sampling_locations=loc3, attention_weights=attn, item_batch=item_batch)
+        self._f32(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn)
+        self._i64(value_spatial_shapes=shapes3, value_level_start_index=lsi)
+        self._i32(item_batch=item_batch)
+        B, S, M, Cm = value.shape
+        dist_heads, D = dist.shape[2], dist.shape[3]
+        n, M2, L, P, _ = loc3.shape
+        if M2 != M or item_batch.numel() != n or dist.shape[:2] != (B, S):
+            raise RuntimeError("dfa3d_forward_items: inconsistent shapes")
+        out = torch.empty((n, M * Cm), dtype=value.dtype, device=value.device)
+        if n:
+            self._call("sgc_dfa3d_forward_items", value, dist, shapes3, lsi, loc3, attn, item_batch, out, None,
+                       B, S, M, Cm, D, dist_heads, L, n, P)
+        return out
+
+    def dfa3d_backward_items(self, value, dist, shapes3, lsi, loc3, attn, item_batch, grad_out, want_grad_attn=True):
+        self._check(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn,
+                    item_batch=item_batch, grad_output=grad_out)
+        self._f32(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn, grad_output=grad_out)
+        B, S, M, Cm = value.shape
+        dist_heads, D = dist.shape[2], dist.shape[3]
+        n, _, L, P, _ = loc3.shape
+        grad_value = torch.zeros_like(value)
+        grad_dist = torch.zeros_like(dist)
+        grad_loc3 = torch.empty_like(loc3)
+        grad_attn = torch.empty((n, M, L, P), dtype=value.dtype, device=value.device) if want_grad_attn else None
+        if n:
+            self._call("sgc_dfa3d_backward_items", value, dist, shapes3, lsi, loc3, attn, item_batch, grad_out, grad_value,
+                       grad_dist, grad_loc3, grad_attn, B, S, M, Cm, D, dist_heads, L, n, P)
+        return grad_value, grad_dist, grad_loc3, grad_attn
+
     # ---- 3. projection + compaction ---------------------------------------
     def project_points(self, ref3d, origin, proj, img_w, img_h, d_near, d_far, sel=None):
         """``sel``: optional int64 [Nq] -- query q is voxel ``sel[q]`` of ``ref3d`` (the reference gathers

@@ -112,6 +112,55 @@ def test_two_rank_gloo_sharding_and_grad_allreduce(tmp_path):
     assert r0["tiny"] == [0]                                                 # 1 scene, 4 ranks: nobody is left empty
 
 
+def _syncbn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sgcdet_amd import dist as sd
+    from sgcdet_amd.plugin.neck3d import FastIndoorImVoxelNeck
+    torch.set_num_threads(1)
+    sd.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    neck = sd.convert_sync_batchnorm(FastIndoorImVoxelNeck(in_channels=8, n_blocks=[1, 1, 1], out_channels=4)).train()
+    n_bn = sum(isinstance(m, sd.SyncBatchNorm3d) for m in neck.modules())
+    x = torch.randn(1, 8, 8, 8, 4, generator=torch.Generator().manual_seed(100 + rank))
+    outs = neck(x)
+    sum(o.square().mean() for o in outs).backward()
+    sd.BucketedGradAllReduce(neck.parameters(), bucket_bytes=1 << 12)()
+    grads = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
+    stats = torch.cat([b.reshape(-1).float() for n, b in neck.named_buffers() if "running" in n])
+    torch.save(dict(grads=grads, stats=stats, n_bn=n_bn, outs=[o.detach() for o in outs]), out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sync_batchnorm_two_ranks_equal_a_single_process_batch_of_two(tmp_path):
+    """SyncBN (reference: pl.Trainer(sync_batchnorm=True), main.py:81) with ONE scene per rank == nn.BatchNorm3d on the
+    two-scene batch in one process: activations, running statistics and -- after the gradient all-reduce (mean over
+    ranks, as DDP) -- the gradients of the loss 0.5 * (L_0 + L_1)."""
+    out = str(tmp_path / "sbn")
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["n_bn"] == 15                                    # every BatchNorm3d of the neck was converted
+    from sgcdet_amd.plugin.neck3d import FastIndoorImVoxelNeck
+    torch.manual_seed(0)
+    neck = FastIndoorImVoxelNeck(in_channels=8, n_blocks=[1, 1, 1], out_channels=4).train()
+    x = torch.cat([torch.randn(1, 8, 8, 8, 4, generator=torch.Generator().manual_seed(100 + i)) for i in range(2)])
+    outs = neck(x)
+    # rank r's loss is the mean over ITS scene; the step's gradient is the mean over ranks
+    loss = 0.5 * sum(o[0].square().mean() + o[1].square().mean() for o in outs)
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in neck.parameters()])
+    stats = torch.cat([b.reshape(-1).float() for n, b in neck.named_buffers() if "running" in n])
+    for o, a, b in zip(outs, r0["outs"], r1["outs"]):
+        assert torch.allclose(o[0:1], a, rtol=1e-4, atol=1e-5) and torch.allclose(o[1:2], b, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(r0["stats"], stats, rtol=1e-5, atol=1e-6) and torch.equal(r0["stats"], r1["stats"])
+    assert torch.allclose(r0["grads"], want, rtol=2e-4, atol=1e-6)
+    assert torch.equal(r0["grads"], r1["grads"])
+
+
 def test_shard_scenes_pads_by_repetition():
     from sgcdet_amd.dist import shard_scenes
     for n, world in [(1, 4), (2, 8), (3, 8), (5, 2), (8, 8), (9, 4)]:

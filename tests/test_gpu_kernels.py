@@ -636,3 +636,26 @@ def test_bf16_storage_mode_of_the_tiled_gather(C, HW, bins, oracle_ops, gpu_ops)
     y32 = gpu_ops.linear_rows_headmajor_bf16x3(cu(x), cu(hi), cu(lo), None, N, H * W, M)
     y16 = gpu_ops.linear_rows_headmajor_bf16x3(cu(x), cu(hi), cu(lo), None, N, H * W, M, out_dtype=torch.bfloat16)
     assert torch.equal(y16, y32.to(torch.bfloat16))
+
+
+def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
+    """sgc_dfa3d_forward_items / sgc_dfa3d_backward_items (training path on pair lists) vs the oracle."""
+    B, S_hw, M, Cm, D, L, P, n = 4, (9, 11), 8, 8, 6, 1, 4, 333
+    g = torch.Generator().manual_seed(77)
+    S = S_hw[0] * S_hw[1]
+    value = torch.randn(B, S, M, Cm, generator=g)
+    dist = torch.randn(B, S, 1, D, generator=g).mul(2).softmax(-1).contiguous()
+    shapes3 = torch.tensor([[S_hw[0], S_hw[1], D]], dtype=torch.int64)
+    lsi = torch.zeros(1, dtype=torch.int64)
+    loc = (torch.rand(n, M, L, P, 3, generator=g) * 1.3 - 0.15).contiguous()
+    attn = torch.rand(n, M, L, P, generator=g)
+    item = torch.randint(0, B, (n,), generator=g, dtype=torch.int32).sort().values.contiguous()
+    go = torch.randn(n, M * Cm, generator=g)
+    out_c = oracle_ops.dfa3d_forward_items(value, dist, shapes3, lsi, loc, attn, item)
+    cu = lambda t: t.cuda()
+    out_g = gpu_ops.dfa3d_forward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(item))
+    close(out_g, out_c)
+    gc = oracle_ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, item, go)
+    gg = gpu_ops.dfa3d_backward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(item), cu(go))
+    for a, b in zip(gg, gc):
+        close(a, b, tol=2e-5)

@@ -730,3 +730,41 @@ def test_masked_decoder_tail_gives_the_dense_detections():
     assert bd.tensor.shape[0] > 0 if hasattr(bd, "tensor") else bd.shape[0] > 0
     tb = (lambda t: t.tensor if hasattr(t, "tensor") else t)
     assert torch.equal(tb(bd), tb(bs)) and torch.equal(sd, ss) and torch.equal(ld, ls)
+
+
+def test_pair_list_training_path_equals_the_padded_reference_layout():
+    """f-3: the differentiable path on the visible (camera, voxel) pairs (item-list operator + backward, no padded
+    [N, max_len] rebatch) gives the same volume and the same gradients -- parameters, feature maps, depth maps -- as the
+    reference's padded layout (`_forward_reference_layout`, pinned to the reference golden by
+    test_module_training_path_runs_and_matches_inference_path)."""
+    from sgcdet_amd.plugin.voxformer import DeformCrossAttention_DFA3D
+    d, sd = load("voxel_head")
+    results = {}
+    for mode in (True, False):
+        head = _build_voxel_head(d)
+        head.load_state_dict(sd)
+        head = head.cuda().train()
+        for m in head.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, DeformCrossAttention_DFA3D):
+                m.train_pair_list = mode
+        feats = [d[f"feat{i}"].cuda().requires_grad_() for i in range(4)]
+        dpt = d["dpt"].cuda().requires_grad_()
+        dpts = depth_pyramid(dpt)
+        volume, valid, occ = head(feats, img_meta(d), dpts)
+        g = torch.Generator().manual_seed(1)
+        w = torch.randn(volume.shape, generator=g).cuda()
+        ((volume * w).sum() + occ.square().sum()).backward()
+        results[mode] = (volume.detach(), valid, [f.grad for f in feats[:3]], dpt.grad,
+                         {n: p.grad for n, p in head.named_parameters() if p.grad is not None})
+    v1, m1, fg1, dg1, pg1 = results[True]
+    v0, m0, fg0, dg0, pg0 = results[False]
+    assert torch.equal(m1, m0) and max_err(v1, v0) < 1e-5 * max(1.0, v0.abs().max().item())
+    assert max_err(v1, d["volume"]) < 1e-3
+    for a, b in zip(fg1, fg0):
+        assert max_err(a, b) < 2e-4 * max(1.0, b.abs().max().item())
+    assert max_err(dg1, dg0) < 2e-4 * max(1.0, dg0.abs().max().item())
+    assert set(pg1) == set(pg0) and len(pg1) > 20
+    for k in pg0:
+        assert max_err(pg1[k], pg0[k]) < 2e-4 * max(1.0, pg0[k].abs().max().item()), k
