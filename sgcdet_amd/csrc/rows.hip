@@ -102,14 +102,30 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      int rem = s_remaining, d = 255;
-      for (; d > 0; --d) {                      // walk the digits from the top until the k-th element is inside one
-        if (hist[d] >= rem) break;
-        rem -= hist[d];
+    // which digit holds the k-th element: suffix sums of the histogram from the top, in parallel over 256 threads (a serial
+    // walk by one thread was ~450 dependent LDS round trips per launch -- most of the first version's 60-70 us)
+    {
+      const int rem = s_remaining;
+      int v = 0, incl = 0;
+      if (tid < 256) {
+        v = hist[255 - tid];
+        incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if ((tid & 63) >= o) incl += t;
+        }
+        if ((tid & 63) == 63) wave_sums[tid >> 6] = incl;
       }
-      s_prefix = prefix | ((uint32_t)d << shift);
-      s_remaining = rem;                        // how many elements with this prefix are still to be taken
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = 0; w < (tid >> 6); ++w) incl += wave_sums[w];
+        const int excl = incl - v;
+        if (excl < rem && rem <= incl) {          // exactly one thread: the digit whose bin contains the k-th element
+          s_prefix = prefix | ((uint32_t)(255 - tid) << shift);
+          s_remaining = rem - excl;               // how many elements with this prefix are still to be taken
+        }
+      }
     }
     __syncthreads();
   }
