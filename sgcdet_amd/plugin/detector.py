@@ -1,10 +1,10 @@
 """``SGCDet`` detector shell: the three calls of the reference that form the hot path.
 
-Reference: mmdet3d_plugin/models/detectors/SGCDet.py:61-129.  The 2D stage (ResNet + FPN,
-``DepthNet_Fusion``) is upstream of the path and is NOT
-built here: ``backbone`` / ``neck`` / ``depth_head`` configs are accepted and kept, and the
-path starts from what they produce -- FPN maps ``x[l] = [1,N,C,H_l,W_l]`` and the depth
-distribution ``[1,N,D,H_0,W_0]``:
+Reference: mmdet3d_plugin/models/detectors/SGCDet.py:61-129.  The 2D backbone (ResNet + FPN, mmdet -- not in the
+reference tree) is upstream of the path and is NOT built here: its configs are accepted and kept.  ``depth_head``
+(``DepthNet_Fusion``, row f-2 of SURVEY.md section 8) IS built when configured: ``build_volume_from_fpn`` runs it on the
+finest FPN map + the images (SGCDet.py:71-85) and hands its depth distribution to the path.  The path itself starts
+from FPN maps ``x[l] = [1,N,C,H_l,W_l]`` and the depth distribution ``[1,N,D,H_0,W_0]``:
 
     volume, valid, occ = voxel_head(x, img_metas[0], mlvl_dpt_dists)      # SGCDet.py:87
     feats = neck_3d(volume)                                               # :96
@@ -24,6 +24,8 @@ class SGCDet(nn.Module):
                  use_gt_dpt=False, depth_loss=False, occ_loss=False, lighting_augmentation=False):
         super().__init__()
         self.upstream_cfg = dict(backbone=backbone, neck=neck, depth_head=depth_head, head_2d=head_2d)
+        self.depth_head = build_head(depth_head) if depth_head is not None else None
+        self.use_gt_dpt, self.depth_loss = use_gt_dpt, depth_loss
         self.neck_3d = build_neck(neck_3d)
         bbox_head = dict(bbox_head)
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
@@ -54,6 +56,23 @@ class SGCDet(nn.Module):
         return [dpt_dist,
                 F.interpolate(dpt_dist, scale_factor=(1, 0.5, 0.5), mode="nearest"),
                 F.interpolate(dpt_dist, scale_factor=(1, 0.25, 0.25), mode="nearest")]
+
+    def depth_distribution(self, x, img, img_metas, depth_maps=None, stride=4):
+        """SGCDet.build_volume's depth branch (SGCDet.py:71-82): x = FPN maps [B,N,C,H_l,W_l], img [B,N,3,4H,4W] ->
+        dpt_dist [B,N,D,H_0,W_0] from ``depth_head`` (or from the ground-truth depth maps with ``use_gt_dpt``)."""
+        if self.depth_head is None:
+            raise RuntimeError("SGCDet was built without a depth_head config")
+        if self.use_gt_dpt:
+            b, n, _, h, w = x[0].shape
+            return self.depth_head.get_downsampled_gt_depth(depth_maps).view(b, n, h, w, -1).permute(0, 1, 4, 2, 3)
+        xs = x[0].detach() if self.depth_loss else x[0]
+        return self.depth_head(xs=xs, imgs=img, img_metas=img_metas, stride=stride)
+
+    def build_volume_from_fpn(self, x, img, img_metas, depth_maps=None):
+        """FPN maps + images -> (volume, valid, dpt_dist, occ): the reference's build_volume from the FPN output on."""
+        dpt_dist = self.depth_distribution(x, img, img_metas, depth_maps)
+        volume, valid, occ = self.build_volume_from_features(x, img_metas, dpt_dist)
+        return volume, valid, dpt_dist, occ
 
     def build_volume_from_features(self, x, img_metas, dpt_dist):
         volume, valid, occ = self.voxel_head(x, img_metas[0], self.depth_pyramid(dpt_dist))

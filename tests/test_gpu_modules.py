@@ -768,3 +768,34 @@ def test_pair_list_training_path_equals_the_padded_reference_layout():
     assert set(pg1) == set(pg0) and len(pg1) > 20
     for k in pg0:
         assert max_err(pg1[k], pg0[k]) < 2e-4 * max(1.0, pg0[k].abs().max().item()), k
+
+
+def test_depth_net_inference_uses_the_fused_plane_sweep_and_matches_the_reference():
+    """DepthNet_Fusion (row f-2) on the GPU in inference: the cost volume comes from the fused HIP plane-sweep kernel (no
+    warped [N,C,D,H,W] tensor); the depth distribution equals the reference class's output (tests/golden/depth_net.npz)
+    and, through the detector shell, feeds the view transform."""
+    import numpy as np
+    import os
+    import sgcdet_amd.plugin as P
+    from golden_util import fill_by_name
+    d, _ = load("depth_net")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth_net.npz"))
+    stride, dbound = int(z["stride"]), [float(v) for v in z["dbound"]]
+    net = P.DepthNet_Fusion(neighbor_img_num=2, downsample_factor=stride, dbound=dbound, mono_channels=d["xs"].shape[2],
+                            loss_weight=0.5, max_tol=0, init_weight="none").eval()
+    fill_by_name(net, base_seed=7, scale=0.15)
+    net = net.cuda()
+    meta = img_meta(d)
+    from sgcdet_amd import ext
+    ops = ext.ops()
+    ops.event_log, ops.event_names = [], {"sgc_plane_sweep_corr"}
+    try:
+        with torch.no_grad():
+            pred = net(d["xs"].cuda(), d["imgs"].cuda(), [meta], stride)
+        assert len(ops.event_log) == 1                            # the fused kernel ran (once for the scene)
+    finally:
+        ops.event_log = ops.event_names = None
+    assert max_err(pred, d["pred"]) < 5e-5
+    assert max_err(pred.sum(2), torch.ones_like(pred.sum(2))) < 1e-5
+    loss = net.loss(d["depth_maps"].cuda(), pred)["loss_dpt"]
+    assert abs(float(loss) - float(d["loss"])) < 1e-4
