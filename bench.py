@@ -99,6 +99,32 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
     return n_views * hw * C * s + n_views * hw * D * s + pairs * (M * P * 4 * 4) + pairs * C * s
 
 
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask capped by the cgroup CPU quota.  os.cpu_count() reports
+    the machine (256 on the GPU hosts) even when the container is limited to a few cores, and an OpenMP team of 256
+    spinning threads on such a quota is 10-1000x slower than one thread (measured in round 2)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                 # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                             # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def cpu_baseline(w, n_views, seed):
     """The CPU oracle (a port: the reference has no CPU implementation of this path) timed on the host cores on a
     bounded sample of scenes of the same workload: all cores (~12 s), then one thread (one scene), plus the per-stage
@@ -111,7 +137,7 @@ def cpu_baseline(w, n_views, seed):
     from sgcdet_amd.mmcv_lite import build_detector
     import sgcdet_amd.plugin  # noqa: F401
     oracle.build()
-    all_cores = int(os.environ.get("SGC_CPU_THREADS", os.cpu_count() or 1))
+    all_cores = int(os.environ.get("SGC_CPU_THREADS", usable_cores()))
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
@@ -160,15 +186,21 @@ def cpu_baseline(w, n_views, seed):
         stages, rp.timing = rp.timing, None
         return n, dt, {k: round(v / n * 1e3, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
 
-    n, dt, stages = run(all_cores, 12.0, 64)
-    out = dict(value=n / dt, unit="scenes/sec", cores=all_cores, kind="port",
-               sample=f"{n} scenes of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels on "
-                      f"{all_cores} threads + torch-CPU ops on {min(all_cores, torch_cap)}), {dt:.1f} s",
-               stages_ms_per_scene=stages)
+    def record(threads, n, dt, stages):
+        return dict(value=n / dt, unit="scenes/sec", cores=threads, kind="port",
+                    sample=f"{n} scene(s) of {w['name']} ({n_views} views) after 1 warm-up, CPU oracle (OpenMP C kernels "
+                           f"on {threads} thread(s) + torch-CPU ops on {min(threads, torch_cap)}), {dt:.1f} s",
+                    stages_ms_per_scene=stages)
+
+    runs = [record(all_cores, *run(all_cores, 12.0, 64))]
     if all_cores > 1 and not os.environ.get("SGC_CPU_SKIP_1T"):
-        n1, dt1, stages1 = run(1, 0.0, 1)               # one scene on one thread (tens of seconds at config 2)
-        out["one_thread"] = dict(value=n1 / dt1, unit="scenes/sec", cores=1,
-                                 sample=f"{n1} scene after 1 warm-up, {dt1:.1f} s", stages_ms_per_scene=stages1)
+        runs.append(record(1, *run(1, 0.0, 1)))         # one scene on one thread (seconds at config 2)
+    # the headline CPU figure is the FASTER configuration (more threads is not always faster for this path: the
+    # torch-CPU ops over the [views, voxels] slots scale badly); the other run is kept beside it
+    runs.sort(key=lambda r: -r["value"])
+    out = dict(runs[0], host_cpus=os.cpu_count(), usable_cores=usable_cores())
+    if len(runs) > 1:
+        out["one_thread" if runs[1]["cores"] == 1 else "all_cores"] = {k: v for k, v in runs[1].items() if k != "kind"}
     set_threads(all_cores)
     return out
 

@@ -362,7 +362,8 @@ int sgc_scatter_add_rows(const float *rows, const int64_t *idx, float *vol, int 
  *      [Cout,Cin,kx,ky,kz] permuted), or, transposed = 1, the 8 parities (px*2+py)*2+pz of
  *      nn.ConvTranspose3d(k=2, s=2) weight [Cin,Cout,2,2,2];
  *   scale/shift [Cout] or NULL: folded eval-mode BatchNorm3d (or bias); residual [OV,Cout] or NULL;
- *   ksize in {1,3} (pad = ksize/2), stride in {1,2};  y [ox*oy*oz, Cout] fully written.
+ *   ksize in {1,3} (pad = ksize/2), stride in {1,2}, or ksize 2 with stride 2 and no padding (the adjoint geometry of
+ *   nn.ConvTranspose3d(2, 2): its input gradient);  y [ox*oy*oz, Cout] fully written.
  * fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).           */
 int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,
                       const float *residual_or_null, float *y,
@@ -389,6 +390,21 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
  * the rounding of a different summation order.  The query returns 0 for layers that are not split.            */
 int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                     int transposed, int bf16x3);
+
+/* Weight gradient of the same convolutions (the neck / head layers in training; the reference gets it
+ * from cuDNN through autograd of nn.Conv3d, necks/imvoxelnet.py:36-64):
+ *   dw[tap][co][ci] = sum over output voxels o of dy[o][co] * x[nbr(o, tap)][ci]      (bf16x3 arithmetic, fp32 accumulate)
+ *   x [ix*iy*iz, Cin], dy [ox*oy*oz, Cout] channels-last rows; dw [ksize^3][Cout][Cin] = nn.Conv3d.weight.grad permuted
+ *   like the forward weights.  ksize / stride as above (ksize 2 = the ConvTranspose3d(2,2) layers with x := the fine-grid
+ *   tensor, dy := the coarse one); Cin % 4 == 0, Cout % 4 == 0.  The voxel range is split over workgroups; with a
+ *   workspace of sgc_conv3d_wgrad_workspace_floats(...) floats the partial sums are added in a fixed order (run-to-run
+ *   bit-identical); without it one workgroup walks the whole range (slower).  The INPUT gradient needs no entry point of
+ *   its own: it is sgc_conv3d_cl_bf16x3 on dy with the taps mirrored and Cin/Cout swapped (stride 1), on the
+ *   zero-interleaved dy (stride 2), or with ksize 2 / stride 2 (transposed layers) -- sgcdet_amd/functions.py.     */
+int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *dw, int ix, int iy, int iz, int Cin, int Cout,
+                            int ksize, int stride, float *workspace_or_null, int64_t workspace_floats,
+                            sgc_stream_t stream);
+int64_t sgc_conv3d_wgrad_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride);
 
 /* Output-masked form of the 3x3x3 stride-1 convolution (north star: "sparse 3D convolution over the occupancy-masked
  * voxels").  The reference's volume is dense, so its convolutions are dense (necks/imvoxelnet.py:47-64); but the

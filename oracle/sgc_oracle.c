@@ -843,7 +843,7 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
   (void)workspace_or_null; (void)workspace_floats;      /* the oracle never splits a reduction */
   (void)stream;
   if (!x || !wt || !y) return fail(SGC_EINVAL, "null pointer");
-  const int pad = ksize / 2;
+  const int pad = ksize == 2 ? 0 : ksize / 2;        /* k2 s2 p0: the adjoint geometry of ConvTranspose3d(2, 2) */
   int ox, oy, oz;
   if (transposed) { ox = 2 * ix; oy = 2 * iy; oz = 2 * iz; }
   else { ox = (ix + 2 * pad - ksize) / stride + 1; oy = (iy + 2 * pad - ksize) / stride + 1; oz = (iz + 2 * pad - ksize) / stride + 1; }
@@ -904,6 +904,41 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                                    transposed, relu, NULL, 0, stream);
   free(w);
   return rc;
+}
+
+/* weight gradient of the convolution above: dW[tap][co][ci] = sum_o dy[o][co] * x[nbr(o, tap)][ci]
+ * (what autograd returns for nn.Conv3d.weight, permuted to the kernel's [tap][Cout][Cin] layout); double accumulation */
+int64_t sgc_conv3d_wgrad_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
+  (void)ix; (void)iy; (void)iz; (void)Cin; (void)Cout; (void)ksize; (void)stride;
+  return 0;
+}
+
+int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *dw, int ix, int iy, int iz, int Cin, int Cout,
+                            int ksize, int stride, float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream) {
+  (void)workspace_or_null; (void)workspace_floats; (void)stream;
+  if (!x || !dy || !dw) return fail(SGC_EINVAL, "null pointer");
+  const int pad = ksize == 2 ? 0 : ksize / 2;
+  const int ox = (ix + 2 * pad - ksize) / stride + 1, oy = (iy + 2 * pad - ksize) / stride + 1, oz = (iz + 2 * pad - ksize) / stride + 1;
+  const int taps = ksize * ksize * ksize;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int tap = 0; tap < taps; ++tap)
+    for (int co = 0; co < Cout; ++co) {
+      const int kx = tap / (ksize * ksize), ky = (tap / ksize) % ksize, kz = tap % ksize;
+      double *acc = (double *)calloc((size_t)Cin, sizeof(double));
+      for (int a = 0; a < ox; ++a)
+        for (int b = 0; b < oy; ++b)
+          for (int c = 0; c < oz; ++c) {
+            const int xx = a * stride + kx - pad, yy = b * stride + ky - pad, zz = c * stride + kz - pad;
+            if (xx < 0 || xx >= ix || yy < 0 || yy >= iy || zz < 0 || zz >= iz) continue;
+            const float g = dy[(((int64_t)a * oy + b) * oz + c) * Cout + co];
+            const float *xi = x + (((int64_t)xx * iy + yy) * iz + zz) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc[ci] += (double)g * (double)xi[ci];
+          }
+      float *o = dw + ((int64_t)tap * Cout + co) * Cin;
+      for (int ci = 0; ci < Cin; ++ci) o[ci] = (float)acc[ci];
+      free(acc);
+    }
+  return SGC_OK;
 }
 
 /* masked form: the oracle computes every row (the mask only licenses the GPU to skip work) */

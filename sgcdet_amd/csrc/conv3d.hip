@@ -32,6 +32,7 @@ namespace sgc {
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
+int g_tune_halo_ring = 1;         // halo kernel: 1 weights by LDS-DMA into a 3-stage ring, 0 staged through registers (round-1 form)
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -537,24 +538,31 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 // of the brick holds each halo-row residue mod 16 exactly twice (checked offline for the three brick shapes:
 // 18 for BZ = 16, 12 for BZ = 8, 6 for BZ = 4) -- the precondition of the conflict-free lane assignment.
 __host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ + 2; }
-__host__ __device__ constexpr size_t halo_tab_offset(int lrows) {
-  const size_t planes = (size_t)(2 * lrows + 4 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
+constexpr int HALO_AP = 32;              // ring form: bf16 per LDS row (64 B, no padding; 16-byte chunks XOR-swizzled by the row)
+constexpr int HALO_NST = 4;              // ring form: weight stages in LDS = 2 groups of 2 taps (one barrier per group)
+constexpr int HALO_BSTAGE = 2 * 128 * HALO_AP * 2;   // bytes of one weight stage: hi|lo planes of [128][32] bf16 = 16 KB
+__host__ __device__ constexpr size_t halo_tab_offset(int lrows, bool ring) {
+  const size_t planes = ring ? (size_t)2 * lrows * HALO_AP * sizeof(uint16_t) + (size_t)HALO_NST * HALO_BSTAGE
+                             : (size_t)(2 * lrows + 4 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
   const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                    // epilogue tile [256][BNV + 8]
   return planes > stage ? planes : stage;
 }
 
-template <int BX, int BY, int BZ>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BX, int BY, int BZ, bool RING>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int BNV = 128, NT = 512;
   constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
-  constexpr int A_PLANE = LROWS * LDKH, B_PLANE = BNV * LDKH;
+  constexpr int AP = RING ? HALO_AP : LDKH;          // bf16 per LDS row of the halo image
+  constexpr int A_PLANE = LROWS * AP, B_PLANE = BNV * LDKH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
   // [8 tiles][32 lanes], behind both the staging planes and the epilogue's output tile that later overlays them
-  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS));
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, RING));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -640,58 +648,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   const int bn = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);
   const bool bn_ok = n0 + bn < p.Cout;
 
-  float4 ra[NA];
-  uint4 rbh, rbl;
-  auto load_A = [&](int cc) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int idx = i * NT + tid;
-      const int row = idx >> 3, c4 = idx & 7;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < HROWS) {
-        const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-        const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
-        if (gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz)
-          ra[i] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4);
-      }
-    }
-  };
-  auto store_A = [&]() {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int idx = i * NT + tid;
-      const int row = idx >> 3, c4 = idx & 7;
-      if (row < HROWS) {
-        const int lrow = (row / HZ) * HZP + row % HZ;
-        const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-        bf16x4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const __bf16 hb = (__bf16)v[e];
-          h[e] = hb;
-          l[e] = (__bf16)(v[e] - (float)hb);
-        }
-        *reinterpret_cast<bf16x4 *>(A_hi + lrow * LDKH + c4 * 4) = h;
-        *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
-      }
-    }
-  };
-  auto load_B = [&](int tap, int cc) {
-    if (bn_ok) {
-      const int64_t off = ((int64_t)tap * p.Cout + n0 + bn) * p.Cin + cc * BK + bc * 8;
-      rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-      rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
-    } else {
-      rbh = make_uint4(0, 0, 0, 0);
-      rbl = make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto store_B = [&](int buf) {
-    __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
-    *reinterpret_cast<uint4 *>(b) = rbh;
-    *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
-  };
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -700,76 +656,299 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
-  int g = 0;                       // global step counter -> B buffer parity
-  load_A(c_lo);
-  load_B(0, c_lo);
-  store_A();
-  store_B(0);
-  __syncthreads();
-  // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
-  // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
-  // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
-  //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
-  bf16x8 ah_n[2] = {}, al_n[2] = {};
-  auto read_A0 = [&](int tap) {
-    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+  if constexpr (RING) {
+    // ---- ring form: weights by LDS-DMA into a 3-stage ring, no registers and no ds_write on the weight path ----
+    // (The staged form below moves every weight tile global -> VGPR -> ds_write_b128 -> LDS between two barriers; with
+    //  that path removed in a timing build the 90-GF layer ran 222 instead of 294 us.)  One global_load_lds_dwordx4 writes
+    //  1 KiB = 16 rows x 64 B contiguously, so the LDS rows carry no padding; bank conflicts are avoided by XOR-ing the
+    //  16-byte chunk index with (row >> 2) & 3 -- applied on the SOURCE address of the DMA for the weights, on the
+    //  ds_write address for the halo rows, and on every fragment read.  With the lane -> voxel assignment above (halo
+    //  rows distinct mod 16 inside every 16-lane group of a ds_read_b128) both images are conflict-free.
+    //  Wave w fills rows 16 w .. 16 w + 15 of both planes of a stage: 2 DMA instructions per wave per tap, issued two
+    //  taps ahead; the step-end wait leaves the youngest tap in flight (counted vmcnt) and a raw s_barrier publishes the
+    //  stage every wave reads next.  Same accumulation order as the staged form: bit-identical results.
+    __bf16 *Bring = A_lo + A_PLANE;
+    float4 ra[NA];
+    // halo rows through BUFFER loads: rows outside the volume (and the padding slots past HROWS) get an out-of-range
+    // offset and come back as zeros, so every wave issues exactly NA load instructions -- the counted waits below rely
+    // on it (with plain loads the compiler branches around a load whose lanes are all outside the volume)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, (int)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+    auto load_A = [&](int cc) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int o = (arow[i] + toff) * LDKH + fh * 8;
-      ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-      al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-    }
-  };
-  read_A0(0);
-  for (int cc = c_lo; cc < c_hi; ++cc) {
-    for (int tap = 0; tap < 27; ++tap, ++g) {
-      const bool last_tap = tap == 26;
-      const bool more = !last_tap || cc + 1 < c_hi;
-      if (more) load_B(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
-      if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+      for (int i = 0; i < NA; ++i) {
+        const int idx = i * NT + tid;
+        const int row = idx >> 3, c4 = idx & 7;
+        const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
+        const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+        const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
+        const int off = (((gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4) * 4;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in ? off : 0x7fffffff, 0, 0);
+        ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      }
+    };
+    auto store_A = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int idx = i * NT + tid;
+        const int row = idx >> 3, c4 = idx & 7;
+        if (row < HROWS) {
+          const int lrow = (row / HZ) * HZP + row % HZ;
+          const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+          bf16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 hb = (__bf16)v[e];
+            h[e] = hb;
+            l[e] = (__bf16)(v[e] - (float)hb);
+          }
+          const int o = lrow * AP + (((c4 >> 1) ^ ((lrow >> 2) & 3)) << 3) + (c4 & 1) * 4;
+          *reinterpret_cast<bf16x4 *>(A_hi + o) = h;
+          *reinterpret_cast<bf16x4 *>(A_lo + o) = l;
+        }
+      }
+    };
+    // weight DMA: lane -> (row 16 wid + (lane >> 2), LDS chunk lane & 3) of its wave's 1-KiB block; the chunk it FETCHES is
+    // the swizzled one
+    const int brow = min(n0 + 16 * wid + (lane >> 2), p.Cout - 1);            // columns past Cout: any finite row (never stored)
+    const int64_t bsrc = (int64_t)brow * p.Cin + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+    const int64_t wtap = (int64_t)p.Cout * p.Cin;
+    const int bdst = __builtin_amdgcn_readfirstlane(wid) * 1024;              // byte offset of the wave's block in a plane
+    auto issue_B = [&](int tap, int cc, int stage) {
+      const int64_t off = tap * wtap + cc * BK + bsrc;
+      unsigned char *d = reinterpret_cast<unsigned char *>(Bring) + stage * HALO_BSTAGE + bdst;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.w_hi + off),
+                                       (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.w_lo + off),
+                                       (__attribute__((address_space(3))) void *)(d + HALO_BSTAGE / 2), 16, 0, 0);
+    };
+    const int S = (c_hi - c_lo) * 27;
+    // issue pointer: runs one GROUP (two taps, stages 2 g & 1 .. + 1) ahead of the compute pointer
+    int itap = 0, icc = c_lo, ist = 0, issued = 0;
+    auto issue_next = [&]() {
+      if (issued < S) {
+        issue_B(itap, icc, ist);
+        ++issued;
+        if (++itap == 27) { itap = 0; ++icc; }
+      }
+      ist = (ist + 1) & (HALO_NST - 1);
+    };
+    load_A(c_lo);
+    issue_next();
+    issue_next();
+    store_A();
+    wait_vmcnt<0>();
+    __syncthreads();
+    // fragment addressing: A row = arow[i] + toff(tap), chunk (2 kk + fh) ^ ((row >> 2) & 3); B row = wn*64 + j*32 + fr,
+    // whose (row >> 2) & 3 = (fr >> 2) & 3 is a lane constant
+    int bo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) bo[kk] = (wn * 64 + fr) * AP + (((2 * kk + fh) ^ ((fr >> 2) & 3)) << 3);
+    bf16x8 ah_n[2] = {}, al_n[2] = {};
+    auto read_A0 = [&](int tap) {
       const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
       const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
-      const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
-      const __bf16 *bl_ = bh_ + B_PLANE;
-      if (wave_live) {
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+      for (int i = 0; i < 2; ++i) {
+        const int row = arow[i] + toff;
+        const int o = row * AP + ((fh ^ ((row >> 2) & 3)) << 3);
+        ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+        al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+      }
+    };
+    if (wave_live) read_A0(0);
+    constexpr int TA = 18;                         // tap at which the next slice's halo loads are issued
+    int s = 0, st = 0;
+    for (int cc = c_lo; cc < c_hi; ++cc) {
+      for (int tap = 0; tap < 27; ++tap, ++s) {
+        const bool last_tap = tap == 26;
+        const bool prefetchA = tap == TA && cc + 1 < c_hi;
+        if ((s & 1) == 0) {                        // group start: weights of the NEXT group (steps s + 2, s + 3); their stages were
+          issue_next();                            // last read in the previous group, which every wave has left
+          issue_next();
+        }
+        if (prefetchA) load_A(cc + 1);             // NA loads, younger than the DMA just issued
+        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+        const __bf16 *bh_ = Bring + st * (HALO_BSTAGE / 2);
+        const __bf16 *bl_ = bh_ + HALO_BSTAGE / 4;
+        if (wave_live) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (kk == 0) {
-            ah[i] = ah_n[i]; al[i] = al_n[i];
-          } else {
-            const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
-            ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-            al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+          for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              if (kk == 0) {
+                ah[i] = ah_n[i]; al[i] = al_n[i];
+              } else {
+                const int row = arow[i] + toff;
+                const int o = row * AP + (((2 + fh) ^ ((row >> 2) & 3)) << 3);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+                al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + bo[kk] + j * 32 * AP);
+              bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + bo[kk] + j * 32 * AP);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
           }
+          if (!last_tap) read_A0(tap + 1);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
-          bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+        // group end: the weights of the next group (issued at this group's start) must have landed for THIS wave before
+        // the barrier; only halo loads issued since may stay in flight
+        const bool gend = (s & 1) || s + 1 == S;
+        if (gend) {
+          if (cc + 1 < c_hi && (tap == TA || tap == TA + 1)) wait_vmcnt<NA>(); else wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
         }
+        if (++st == HALO_NST) st = 0;
+        if (last_tap && cc + 1 < c_hi && !gend) {  // slice end in the middle of a group: every wave must be past the last tap
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
+        store_A();
+        __syncthreads();
+        if (wave_live) read_A0(0);
+      }
+    }
+  } else {
+    float4 ra[NA];
+    uint4 rbh, rbl;
+    auto load_A = [&](int cc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NA; ++i) {
+        const int idx = i * NT + tid;
+        const int row = idx >> 3, c4 = idx & 7;
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < HROWS) {
+          const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
+          const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+          if (gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz)
+            ra[i] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4);
+        }
+      }
+    };
+    auto store_A = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int idx = i * NT + tid;
+        const int row = idx >> 3, c4 = idx & 7;
+        if (row < HROWS) {
+          const int lrow = (row / HZ) * HZP + row % HZ;
+          const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+          bf16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 hb = (__bf16)v[e];
+            h[e] = hb;
+            l[e] = (__bf16)(v[e] - (float)hb);
+          }
+          *reinterpret_cast<bf16x4 *>(A_hi + lrow * LDKH + c4 * 4) = h;
+          *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
+        }
+      }
+    };
+    auto load_B = [&](int tap, int cc) {
+      if (bn_ok) {
+        const int64_t off = ((int64_t)tap * p.Cout + n0 + bn) * p.Cin + cc * BK + bc * 8;
+        rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
+        rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+      } else {
+        rbh = make_uint4(0, 0, 0, 0);
+        rbl = make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto store_B = [&](int buf) {
+      __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
+      *reinterpret_cast<uint4 *>(b) = rbh;
+      *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
+    };
+
+    int g = 0;                       // global step counter -> B buffer parity
+    load_A(c_lo);
+    load_B(0, c_lo);
+    store_A();
+    store_B(0);
+    __syncthreads();
+    // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
+    // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
+    // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
+    //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
+    bf16x8 ah_n[2] = {}, al_n[2] = {};
+    auto read_A0 = [&](int tap) {
+      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+      const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int o = (arow[i] + toff) * LDKH + fh * 8;
+        ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+        al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+      }
+    };
+    read_A0(0);
+    for (int cc = c_lo; cc < c_hi; ++cc) {
+      for (int tap = 0; tap < 27; ++tap, ++g) {
+        const bool last_tap = tap == 26;
+        const bool more = !last_tap || cc + 1 < c_hi;
+        if (more) load_B(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
+        if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+        const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
+        const __bf16 *bl_ = bh_ + B_PLANE;
+        if (wave_live) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (kk == 0) {
+              ah[i] = ah_n[i]; al[i] = al_n[i];
+            } else {
+              const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
+              ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+              al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
+            bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
           }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (!last_tap) read_A0(tap + 1);
+        }
+        if (more) store_B((g + 1) & 1);
+        __syncthreads();
       }
-      if (!last_tap) read_A0(tap + 1);
+      if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
+        store_A();
+        __syncthreads();
+        if (wave_live) read_A0(0);
       }
-      if (more) store_B((g + 1) & 1);
-      __syncthreads();
     }
-    if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
-      store_A();
-      __syncthreads();
-      if (wave_live) read_A0(0);
-    }
+
   }
 
   // Epilogue through LDS (as in the implicit-GEMM kernel): the halo / weight buffers are free, the 256 x 128 tile
@@ -884,12 +1063,12 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
-template <int BX, int BY, int BZ>
+template <int BX, int BY, int BZ, bool RING>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
-  const size_t smem = halo_tab_offset(LROWS) + 256 * sizeof(uint16_t);
+  const size_t smem = halo_tab_offset(LROWS, RING) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, 128);
   const int nchunks = p.Cin / BK;
@@ -905,7 +1084,7 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
@@ -957,9 +1136,10 @@ static int conv_setup(ConvParams &p, const char *who, const float *x, const void
     p.gx = ix; p.gy = iy; p.gz = iz; p.ksize = 1; p.stride = 1; p.pad = 0; p.taps = 1;
     ox = 2 * ix; oy = 2 * iy; oz = 2 * iz;
   } else {
-    if (!((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2)))
-      return set_error(SGC_EUNSUP, "%s: ksize in {1,3}, stride in {1,2}", who);
-    p.pad = ksize / 2; p.ksize = ksize; p.stride = stride; p.taps = ksize * ksize * ksize;
+    if (!((ksize == 3 || ksize == 1) && (stride == 1 || stride == 2)) && !(ksize == 2 && stride == 2))
+      return set_error(SGC_EUNSUP, "%s: ksize in {1,3} with stride in {1,2}, or ksize 2 with stride 2", who);
+    p.pad = ksize == 2 ? 0 : ksize / 2; p.ksize = ksize; p.stride = stride; p.taps = ksize * ksize * ksize;   // k2s2: no padding (the
+                                                                                                       // dgrad of ConvTranspose3d k2s2)
     ox = (ix + 2 * p.pad - ksize) / stride + 1; oy = (iy + 2 * p.pad - ksize) / stride + 1;
     oz = (iz + 2 * p.pad - ksize) / stride + 1;
     p.gx = ox; p.gy = oy; p.gz = oz;
@@ -1050,9 +1230,13 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
-    if (p.gz >= 16 && g_tune_halo_brick == 0) rc = launch_halo<4, 4, 16>(p, OV, st);
-    else if (p.gz >= 8 && g_tune_halo_brick != 2) rc = launch_halo<4, 8, 8>(p, OV, st);
-    else rc = launch_halo<8, 8, 4>(p, OV, st);
+    // ring form where it measured faster (the 256 -> 256 layers on the 4x4x16 brick: 293 -> 279 us; 3-7 % slower on the
+    // 512-channel / 128-column layers, whose split-K slices are short); halo_ring = 2 forces it everywhere
+    const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && p.gz >= 16 && g_tune_halo_brick == 0 && Cout >= 256 && Cin <= 256)) &&
+                      (int64_t)ix * iy * iz * Cin * 4 < 0x7fffffff;   // 32-bit buffer offsets
+    if (p.gz >= 16 && g_tune_halo_brick == 0) rc = ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);
+    else if (p.gz >= 8 && g_tune_halo_brick != 2) rc = ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
+    else rc = ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
@@ -1089,6 +1273,214 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   return conv_finish(p, OV, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions (training): dW[tap][co][ci] = sum_o dy[o][co] * x[nbr(o, tap)][ci],
+// a GEMM per tap with M = Cout, N = Cin and the OUTPUT VOXELS as the reduction dimension.  Both operands are stored
+// voxel-major (rows = k), so the staging pass transposes: a thread loads a 4-voxel x 4-channel block (four 16-byte loads
+// from four rows), splits it hi/lo and writes four 8-byte runs of 4 consecutive k into the [channel][k] LDS image the
+// forward kernel's fragment reads expect.  128 x 128 tile, K-step 32 voxels, 4 waves (2 x 2, 64 x 64 each), register
+// prefetch of step s + 1 under the MFMAs of step s, double-buffered LDS.  The voxel range is split over blockIdx.z
+// (taps x splits); partial tiles go to a workspace and are summed in split order (deterministic), or straight to dW
+// when there is one split.  ksize 1 | 3 (pad k/2, stride 1 | 2) or 2 (stride 2, no pad: the ConvTranspose3d k2s2 layers
+// with x := the fine-grid tensor and dy := the coarse one).
+// ---------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float *x, *dy;
+  float *out;               // dW [taps][Cout][Cin] (one split) or the workspace [splits][taps][Cout][Cin]
+  int Cin, Cout;
+  int ix, iy, iz, ox, oy, oz;
+  int ksize, stride, pad, taps;
+  int OV, ksteps, splits, steps_per_split;
+};
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradParams p) {
+  constexpr int BMW = 128, BNW = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  constexpr int PLANE = 128 * LDKH, BUF = 4 * PLANE;        // per buffer: A_hi, A_lo, B_hi, B_lo of [128][LDKH]
+  __bf16 *base = reinterpret_cast<__bf16 *>(smem_w);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int co0 = blockIdx.x * BMW, ci0 = blockIdx.y * BNW;
+  const int tap = blockIdx.z % p.taps, split = blockIdx.z / p.taps;
+  const int s_lo = split * p.steps_per_split, s_hi = min(p.ksteps, s_lo + p.steps_per_split);
+  int dx = 0, dy_ = 0, dz = 0;
+  if (p.ksize > 1) { dx = tap / (p.ksize * p.ksize); dy_ = (tap / p.ksize) % p.ksize; dz = tap % p.ksize; }
+
+  const int kb = tid & 7, cb = tid >> 3;                    // this thread's block: voxels 4 kb .. + 3 of the step, channels 4 cb .. + 3
+  const bool a_ok = co0 + 4 * cb < p.Cout, b_ok = ci0 + 4 * cb < p.Cin;
+  float4 ra[4], rb[4];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = s * 32 + 4 * kb + j;
+      ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[j] = ra[j];
+      if (o < p.OV) {
+        if (a_ok) ra[j] = *reinterpret_cast<const float4 *>(p.dy + (int64_t)o * p.Cout + co0 + 4 * cb);
+        const int z = o % p.oz, y = (o / p.oz) % p.oy, x = o / (p.oz * p.oy);
+        const int xx = x * p.stride + dx - p.pad, yy = y * p.stride + dy_ - p.pad, zz = z * p.stride + dz - p.pad;
+        if (b_ok && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz)
+          rb[j] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + ci0 + 4 * cb);
+      }
+    }
+  };
+  auto store_block = [&](const float4 (&r)[4], __bf16 *hi, __bf16 *lo) {
+    const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
+                           {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                           // channel 4 cb + c: its 4 consecutive k
+      bf16x4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 hb = (__bf16)v[j][c];
+        h[j] = hb;
+        l[j] = (__bf16)(v[j][c] - (float)hb);
+      }
+      const int o = (4 * cb + c) * LDKH + 4 * kb;
+      *reinterpret_cast<bf16x4 *>(hi + o) = h;
+      *reinterpret_cast<bf16x4 *>(lo + o) = l;
+    }
+  };
+  auto store_step = [&](int buf) {
+    __bf16 *a_hi = base + buf * BUF;
+    store_block(ra, a_hi, a_hi + PLANE);
+    store_block(rb, a_hi + 2 * PLANE, a_hi + 3 * PLANE);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  if (s_lo < s_hi) {
+    load_step(s_lo);
+    store_step(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int s = s_lo; s < s_hi; ++s) {
+      const int buf = (s - s_lo) & 1;
+      if (s + 1 < s_hi) load_step(s + 1);
+      const __bf16 *a_hi = base + buf * BUF + (wm * 64 + fr) * LDKH + fh * 8;
+      const __bf16 *a_lo = a_hi + PLANE;
+      const __bf16 *b_hi = base + buf * BUF + 2 * PLANE + (wn * 64 + fr) * LDKH + fh * 8;
+      const __bf16 *b_lo = b_hi + PLANE;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + i * 32 * LDKH + kk * 16);
+          al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + i * 32 * LDKH + kk * 16);
+          bh[i] = *reinterpret_cast<const bf16x8 *>(b_hi + i * 32 * LDKH + kk * 16);
+          bl[i] = *reinterpret_cast<const bf16x8 *>(b_lo + i * 32 * LDKH + kk * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      if (s + 1 < s_hi) store_step(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // a lane owns column ci = lane & 31 of a 32 x 32 tile: for a fixed register the 32 lanes of a half-wave store 128
+  // contiguous bytes of one dW row
+  float *out = p.out + ((int64_t)split * p.taps + tap) * p.Cout * p.Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
+      if (ci >= p.Cin) continue;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int co = co0 + wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout) out[(int64_t)co * p.Cin + ci] = acc[i][j][k];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4 *__restrict__ ws, float4 *__restrict__ dw, int64_t n4, int splits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ws[i];
+    for (int s = 1; s < splits; ++s) {                      // fixed order: deterministic
+      const float4 b = ws[(int64_t)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    dw[i] = a;
+  }
+}
+
+static int wgrad_geometry(WgradParams &p, int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
+  if (Cin <= 0 || Cout <= 0 || ix <= 0 || iy <= 0 || iz <= 0) return set_error(SGC_EINVAL, "sgc_conv3d_wgrad_bf16x3: bad size");
+  if ((Cin & 3) || (Cout & 3)) return set_error(SGC_EUNSUP, "sgc_conv3d_wgrad_bf16x3: Cin and Cout must be multiples of 4");
+  if (ksize == 2) {
+    if (stride != 2 || (ix & 1) || (iy & 1) || (iz & 1)) return set_error(SGC_EUNSUP, "sgc_conv3d_wgrad_bf16x3: ksize 2 needs stride 2 and an even grid");
+    p.pad = 0;
+  } else if ((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2)) {
+    p.pad = ksize / 2;
+  } else {
+    return set_error(SGC_EUNSUP, "sgc_conv3d_wgrad_bf16x3: ksize in {1,2,3}, stride in {1,2}");
+  }
+  p.Cin = Cin; p.Cout = Cout; p.ix = ix; p.iy = iy; p.iz = iz; p.ksize = ksize; p.stride = stride;
+  p.taps = ksize * ksize * ksize;
+  p.ox = (ix + 2 * p.pad - ksize) / stride + 1; p.oy = (iy + 2 * p.pad - ksize) / stride + 1; p.oz = (iz + 2 * p.pad - ksize) / stride + 1;
+  p.OV = p.ox * p.oy * p.oz;
+  p.ksteps = ceil_div(p.OV, 32);
+  const int tiles = ceil_div(Cout, 128) * ceil_div(Cin, 128) * p.taps;
+  int splits = 1;
+  while (tiles * splits < 512 && p.ksteps / (splits * 2) >= 16) splits *= 2;     // fill the chip twice over; >= 16 K-steps per split
+  p.steps_per_split = ceil_div(p.ksteps, splits);
+  p.splits = ceil_div(p.ksteps, p.steps_per_split);
+  return SGC_OK;
+}
+
+extern "C" int64_t sgc_conv3d_wgrad_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
+  WgradParams p = {};
+  if (wgrad_geometry(p, ix, iy, iz, Cin, Cout, ksize, stride)) return -1;
+  return p.splits > 1 ? (int64_t)p.splits * p.taps * Cout * Cin : 0;
+}
+
+extern "C" int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *dw, int ix, int iy, int iz, int Cin, int Cout,
+                                       int ksize, int stride, float *workspace_or_null, int64_t workspace_floats,
+                                       sgc_stream_t stream) {
+  if (!x || !dy || !dw) return set_error(SGC_EINVAL, "sgc_conv3d_wgrad_bf16x3: null pointer");
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace_or_null) & 15)
+    return set_error(SGC_EINVAL, "sgc_conv3d_wgrad_bf16x3: pointers must be 16-byte aligned");
+  WgradParams p = {};
+  int rc = wgrad_geometry(p, ix, iy, iz, Cin, Cout, ksize, stride);
+  if (rc) return rc;
+  p.x = x; p.dy = dy;
+  const int64_t n = (int64_t)p.taps * Cout * Cin;
+  if (p.splits > 1 && !(workspace_or_null && workspace_floats >= p.splits * n)) {     // no workspace: one split (slower, same result class)
+    p.splits = 1;
+    p.steps_per_split = p.ksteps;
+  }
+  p.out = p.splits > 1 ? workspace_or_null : dw;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = (size_t)2 * 4 * 128 * LDKH * sizeof(uint16_t);
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void *)conv3d_wgrad_bf16x3_kernel, (int)smem, attr_done);
+  hipLaunchKernelGGL(conv3d_wgrad_bf16x3_kernel, dim3(ceil_div(Cout, 128), ceil_div(Cin, 128), p.taps * p.splits), dim3(256), smem, st, p);
+  rc = check_launch("conv3d_wgrad_bf16x3_kernel");
+  if (rc) return rc;
+  if (p.splits > 1) {
+    const int64_t n4 = n / 4;
+    const int g = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, reinterpret_cast<const float4 *>(workspace_or_null),
+                       reinterpret_cast<float4 *>(dw), n4, p.splits);
+    rc = check_launch("wgrad_reduce_kernel");
+  }
+  return rc;
+}
 
 // Split-K workspace (floats) the convolution above would use for a deterministic reduction; 0 = the layer is not
 // split.  Mirrors the dispatch of sgc_conv3d_cl_f32 (bf16x3 = 0) / sgc_conv3d_cl_bf16x3 (bf16x3 = 1).
@@ -1171,7 +1563,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
   int ox, oy, oz, gx, gy, gz;
   if (transposed) { ox = 2 * ix; oy = 2 * iy; oz = 2 * iz; gx = ix; gy = iy; gz = iz; }
   else {
-    const int pad = ksize / 2;
+    const int pad = ksize == 2 ? 0 : ksize / 2;
     ox = (ix + 2 * pad - ksize) / stride + 1; oy = (iy + 2 * pad - ksize) / stride + 1; oz = (iz + 2 * pad - ksize) / stride + 1;
     gx = ox; gy = oy; gz = oz;
   }

@@ -485,7 +485,8 @@ class TensorOps:
         taps, Cout, Cin2 = w_hi.shape
         if V != ix * iy * iz or Cin2 != Cin or taps != (8 if transposed else ksize ** 3):
             raise RuntimeError("conv3d_cl_bf16x3: inconsistent shapes")
-        og = (2 * ix, 2 * iy, 2 * iz) if transposed else tuple((d + 2 * (ksize // 2) - ksize) // stride + 1 for d in grid)
+        pad = 0 if ksize == 2 else ksize // 2              # ksize 2 (stride 2): the adjoint geometry of ConvTranspose3d(2, 2)
+        og = (2 * ix, 2 * iy, 2 * iz) if transposed else tuple((d + 2 * pad - ksize) // stride + 1 for d in grid)
         if out is not None:
             self._check(out=out)
             if out.shape != (og[0] * og[1] * og[2], Cout) or out.dtype != torch.float32:
@@ -525,6 +526,27 @@ class TensorOps:
             self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout,
                        _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
         return y
+
+    def conv3d_wgrad_bf16x3(self, x, dy, grid, ksize, stride=1):
+        """dW [ksize^3, Cout, Cin] of the channels-last convolution: x [IV, Cin] on ``grid``, dy [OV, Cout] on the output
+        grid (``sgc_conv3d_wgrad_bf16x3``; ksize 2 = stride 2, no padding)."""
+        self._check(x=x, dy=dy)
+        self._f32(x=x, dy=dy)
+        ix, iy, iz = grid
+        pad = 0 if ksize == 2 else ksize // 2
+        og = tuple((d + 2 * pad - ksize) // stride + 1 for d in grid)
+        V, Cin = x.shape
+        OV, Cout = dy.shape
+        if V != ix * iy * iz or OV != og[0] * og[1] * og[2]:
+            raise RuntimeError("conv3d_wgrad_bf16x3: inconsistent shapes")
+        dw = torch.empty((ksize ** 3, Cout, Cin), dtype=torch.float32, device=x.device)
+        n = int(self.lib._dll.sgc_conv3d_wgrad_workspace_floats(ix, iy, iz, Cin, Cout, ksize, stride))
+        if n < 0:
+            raise RuntimeError("conv3d_wgrad_bf16x3: " + self.lib.last_error())
+        ws = torch.empty(n, dtype=torch.float32, device=x.device) if n > 0 else None
+        self._call("sgc_conv3d_wgrad_bf16x3", x, dy, dw, ix, iy, iz, Cin, Cout, ksize, stride, ws, n,
+                   _meta=dict(V=OV, Cin=Cin, Cout=Cout, taps=ksize ** 3, OV=OV))
+        return dw
 
     def _conv_workspace(self, device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, bf16x3):
         """Split-K layers get a workspace so that their partial sums are added in a fixed order (bit-identical

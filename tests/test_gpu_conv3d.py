@@ -126,3 +126,35 @@ def test_output_masked_conv_is_bit_identical_on_live_rows(grid, cin, cout, relu,
         assert torch.isfinite(got).all()
         live = m.bool()
         assert torch.equal(got[live], dense[live])
+
+
+@pytest.mark.parametrize("grid,cin,cout,relu,res", [((40, 40, 16), 256, 256, 1, True), ((12, 9, 19), 64, 160, 2, False),
+                                                     ((20, 20, 8), 128, 128, 0, False), ((10, 12, 4), 96, 28, 1, True),
+                                                     ((17, 6, 8), 512, 256, 0, False)])
+def test_halo_ring_form_is_bit_identical_to_the_staged_form(grid, cin, cout, relu, res, gpu_ops):
+    """The two weight paths of the halo kernel -- LDS-DMA into the swizzled 4-stage ring (two taps per barrier, counted
+    vmcnt) and the register-staged double buffer -- accumulate in the same order: every brick shape, ragged grids, split-K
+    slices, column counts that are not a multiple of 128, an output mask; repeated launches to catch a race on the ring."""
+    g = torch.Generator().manual_seed(sum(grid) + cin + cout)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g).cuda()
+    w = (torch.randn(27, cout, cin, generator=g) * 0.05)
+    hi, lo = gpu_ops.split_bf16(w)
+    hi, lo = hi.cuda(), lo.cuda()
+    scale, shift = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    residual = torch.randn(V, cout, generator=g).cuda() if res else None
+    mask = (torch.rand(grid, generator=g) < 0.3).reshape(-1).to(torch.uint8).cuda()
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 1)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 0)
+        staged, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+        staged_m, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=mask)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 2)
+        for _ in range(5):
+            ring, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+            assert torch.equal(ring, staged)
+        ring_m, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=mask)
+        assert torch.equal(ring_m, staged_m)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 1)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 2048)
