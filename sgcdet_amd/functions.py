@@ -133,6 +133,101 @@ class PairListDeformAttnFunction(Function):
         return gv, gd, None, None, gl, ga, None
 
 
+def _pad_cols(t, mult):
+    """[rows, C] -> [rows, ceil(C / mult) * mult] with zero columns (a view when nothing is added)."""
+    c = t.shape[-1]
+    cp = (c + mult - 1) // mult * mult
+    return t if cp == c else torch.nn.functional.pad(t, (0, cp - c))
+
+
+class ChannelsLastConv3dFunction(Function):
+    """``nn.Conv3d(k, stride, padding=k//2, bias=False)`` on channels-last rows, forward AND backward on the MFMA kernels
+    (the neck / head convolutions in training; the reference gets all three passes from cuDNN,
+    necks/imvoxelnet.py:36-64, dense_heads/imvoxel_head_v2.py:75-78).
+
+    x [X*Y*Z, Cin] rows of the volume, weight [Cout, Cin, k, k, k] (the module's parameter, untouched layout), grid =
+    (X, Y, Z), k in {1, 3}, stride in {1, 2} -> y [OX*OY*OZ, Cout].  Cin % 32 == 0.
+
+    * forward: ``sgc_conv3d_cl_bf16x3`` (no epilogue: BatchNorm in training mode needs the raw output);
+    * input gradient: the same kernel on dy with the taps mirrored and Cin / Cout swapped; for stride 2 on the
+      zero-interleaved dy (dy at the even fine-grid positions: 8x the necessary matrix work on two small layers, no new
+      kernel -- the two stride-2 layers are 6 % of the neck's FLOPs);
+    * weight gradient: ``sgc_conv3d_wgrad_bf16x3``.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, grid, ksize, stride):
+        ops = ext.ops()
+        cout, cin = weight.shape[:2]
+        wt = _pad_cols(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(ksize ** 3, cout, cin).transpose(1, 2), 4).transpose(1, 2)
+        hi, lo = ops.split_bf16(wt.contiguous())
+        x = x.float().contiguous()
+        y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, ksize, stride)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (tuple(grid), tuple(og), ksize, stride)
+        return y[:, :cout] if y.shape[1] != cout else y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ops = ext.ops()
+        x, weight = ctx.saved_tensors
+        grid, og, ksize, stride = ctx.geom
+        cout, cin = weight.shape[:2]
+        dy = dy.float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx[i] = sum_d dy[(i - d + pad) / stride] W[d]^T: a stride-1 convolution of (zero-interleaved) dy with the
+            # mirrored taps; its "input channels" are Cout, padded to the kernel's multiple of 32
+            wt = weight.detach().float().flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(ksize ** 3, cin, cout)
+            hi, lo = ops.split_bf16(_pad_cols(wt, 32).contiguous())
+            g = _pad_cols(dy, 32)
+            if stride == 2:
+                up = torch.zeros((grid[0], grid[1], grid[2], g.shape[1]), dtype=torch.float32, device=dy.device)
+                up[:2 * og[0]:2, :2 * og[1]:2, :2 * og[2]:2] = g.view(og[0], og[1], og[2], -1)
+                g = up.view(-1, g.shape[1])
+            dx, _ = ops.conv3d_cl_bf16x3(g.contiguous(), hi, lo, grid, ksize, 1)
+        if ctx.needs_input_grad[1]:
+            dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), grid, ksize, stride)        # [taps, cout_p, cin]
+            dw = dwk[:, :cout].permute(1, 2, 0).reshape(cout, cin, ksize, ksize, ksize).to(weight.dtype)
+        return dx, dw, None, None, None
+
+
+class ChannelsLastConvTranspose3dFunction(Function):
+    """``nn.ConvTranspose3d(2, 2, bias=False)`` on channels-last rows (up_block_*, necks/imvoxelnet.py:56-58): forward on the
+    parity form of the MFMA kernel, input gradient = the k2 s2 convolution of dy, weight gradient =
+    ``sgc_conv3d_wgrad_bf16x3`` with the roles of the two tensors exchanged.  x [X*Y*Z, Cin], weight [Cin, Cout, 2, 2, 2]
+    -> y [8*X*Y*Z, Cout]; Cin % 32 == 0, Cout % 32 == 0."""
+
+    @staticmethod
+    def forward(ctx, x, weight, grid):
+        ops = ext.ops()
+        cin, cout = weight.shape[:2]
+        hi, lo = ops.split_bf16(weight.detach().float().permute(2, 3, 4, 1, 0).reshape(8, cout, cin).contiguous())
+        x = x.float().contiguous()
+        y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, 2, 2, True)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (tuple(grid), tuple(og))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ops = ext.ops()
+        x, weight = ctx.saved_tensors
+        grid, og = ctx.geom
+        cin, cout = weight.shape[:2]
+        dy = dy.float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            hi, lo = ops.split_bf16(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(8, cin, cout).contiguous())
+            dx, _ = ops.conv3d_cl_bf16x3(dy, hi, lo, og, 2, 2)                  # dx[x] = sum_p dy[2x + p] W[:, :, p]^T
+        if ctx.needs_input_grad[1]:
+            dwk = ops.conv3d_wgrad_bf16x3(dy, x, og, 2, 2)                      # [8, cin, cout]
+            dw = dwk.permute(1, 2, 0).reshape(cin, cout, 2, 2, 2).to(weight.dtype)
+        return dx, dw, None
+
+
 # the DFA3D package spells them without the suffix (dfa3D/ops/multi_scale_3D_deform_attn.py:22,67,146)
 MultiScale3DDeformableAttnFunction = MultiScale3DDeformableAttnFunction_fp32
 MultiScaleDepthScoreSampleFunction = MultiScaleDepthScoreSampleFunction_fp32

@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ext
 from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
-from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
+from .conv_plan import train_conv_on_hip, ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
 from . import losses
 
 
@@ -97,9 +97,27 @@ class ImVoxelHeadV2(nn.Module):
             cls.append(full[:, 1 + n_reg:])
         return ctr, reg, cls
 
+    def _forward_autograd_hip(self, feats):
+        """Training / autograd path on the HIP kernels: the three 3x3x3 convolutions of a scale as ONE convolution with the
+        concatenated weights (autograd splits the weight gradient back), imvoxel_head_v2.py:75-78,103-110."""
+        from ..functions import ChannelsLastConv3dFunction
+        w = torch.cat([self.centerness_conv.weight, self.reg_conv.weight, self.cls_conv.weight], 0)
+        n_reg = self.reg_conv.weight.shape[0]
+        ctr, reg, cls = [], [], []
+        for x, scale in zip(feats, self.scales):
+            rows, grid = to_channels_last_rows(x)
+            y = ChannelsLastConv3dFunction.apply(rows, w, tuple(grid), 3, 1)
+            full = rows_to_ncdhw(y, grid, y.shape[1])
+            ctr.append(full[:, :1])
+            reg.append(self._reg_activation(full[:, 1:1 + n_reg], scale))
+            cls.append(full[:, 1 + n_reg:] + self.cls_conv.bias.view(1, -1, 1, 1, 1))
+        return ctr, reg, cls
+
     def forward(self, x, valid_masks=None):
         if not self.training and not torch.is_grad_enabled() and x[0].is_cuda and x[0].shape[0] == 1:
             return self._forward_hip(x, valid_masks)
+        if train_conv_on_hip(x[0], [self.cls_conv.in_channels]):
+            return self._forward_autograd_hip(x)
         return multi_apply(self.forward_single, [t.contiguous() for t in x], self.scales)   # packed NCDHW for MIOpen
 
     def _reg_activation(self, reg, scale):

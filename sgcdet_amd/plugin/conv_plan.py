@@ -6,6 +6,8 @@ channel counts are zero-padded to multiples of 32 (the K tile) -- a no-op for ev
 config (128 ... 1024 channels).  Plans are cached per module and rebuilt when a parameter or
 buffer changes (``Tensor._version``) or moves device.
 """
+import os
+
 import torch
 
 from .. import ext
@@ -63,6 +65,58 @@ class ConvSpec:
                                               self.transposed, self.scale, self.shift, residual, relu, out_mask=out_mask)
         return ext.ops().conv3d_cl(x, self.wt, grid, self.ksize, self.stride, self.transposed, self.scale,
                                    self.shift, residual, relu)
+
+
+# training / autograd path of the neck and head convolutions: "hip" = forward, input and weight gradients on the MFMA
+# kernels (functions.ChannelsLastConv3dFunction), "library" = torch's convolutions (MIOpen) as in round 1
+TRAIN_CONV = os.environ.get("SGC_TRAIN_CONV", "hip")
+
+
+def set_train_conv(mode):
+    global TRAIN_CONV
+    if mode not in ("hip", "library"):
+        raise ValueError(mode)
+    TRAIN_CONV = mode
+
+
+def train_conv_on_hip(x, channels):
+    """Can the autograd path of a conv chain run on the HIP kernels?  (one scene, CUDA, channel counts the K tile accepts)"""
+    return (TRAIN_CONV == "hip" and CONV_MODE == "bf16x3" and x.is_cuda and x.shape[0] == 1
+            and all(c % _PAD == 0 for c in channels))
+
+
+def conv_rows(conv, rows, grid):
+    """``nn.Conv3d`` module (k in {1,3}, padding k//2) applied to channels-last rows with autograd on the HIP kernels."""
+    from ..functions import ChannelsLastConv3dFunction
+    k, s = conv.kernel_size[0], conv.stride[0]
+    y = ChannelsLastConv3dFunction.apply(rows, conv.weight, tuple(grid), k, s)
+    if conv.bias is not None:
+        y = y + conv.bias
+    return y, tuple((d + 2 * (k // 2) - k) // s + 1 for d in grid)
+
+
+def conv_transpose_rows(conv, rows, grid):
+    """``nn.ConvTranspose3d(2, 2, bias=False)`` on channels-last rows."""
+    from ..functions import ChannelsLastConvTranspose3dFunction
+    return ChannelsLastConvTranspose3dFunction.apply(rows, conv.weight, tuple(grid)), tuple(2 * d for d in grid)
+
+
+def bn_rows(bn, rows, grid):
+    """A BatchNorm3d-like module on channels-last rows [V, C].  ``nn.BatchNorm3d`` over [1, C, X, Y, Z] is the statistics of
+    the V rows per channel, i.e. ``F.batch_norm`` on the [V, C] matrix (same running-statistics update); any other module
+    (SyncBatchNorm3d, GroupNorm ...) gets the 5-D channels-last view."""
+    if type(bn) is torch.nn.BatchNorm3d:
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        return torch.nn.functional.batch_norm(rows, bn.running_mean if not bn.training or bn.track_running_stats else None,
+                                              bn.running_var if not bn.training or bn.track_running_stats else None,
+                                              bn.weight, bn.bias, use_batch, momentum, bn.eps)
+    y = bn(rows_to_ncdhw(rows, grid, rows.shape[1]))
+    return y[0].permute(1, 2, 3, 0).reshape(rows.shape[0], rows.shape[1])
 
 
 def module_fingerprint(module):

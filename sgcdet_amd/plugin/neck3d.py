@@ -13,7 +13,8 @@ import torch
 from torch import nn
 
 from ..mmcv_lite import NECKS
-from .conv_plan import ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
+from .conv_plan import (ConvSpec, bn_rows, conv_rows, conv_transpose_rows, module_fingerprint, rows_to_ncdhw,
+                        to_channels_last_rows, train_conv_on_hip)
 
 
 class BasicBlock3dV2(nn.Module):
@@ -114,12 +115,50 @@ class FastIndoorImVoxelNeck(nn.Module):
             outs.append(rows_to_ncdhw(o, g, spec.cout))
         return outs[::-1]
 
+    def _forward_autograd_hip(self, x):
+        """Training / autograd path on the HIP kernels: every convolution -- forward, input gradient,
+        weight gradient -- through ``ChannelsLastConv3dFunction`` / ``ChannelsLastConvTranspose3dFunction`` on the
+        channels-last rows the voxel head hands over; BatchNorm (batch statistics), ReLU and the skip additions stay
+        torch ops on the same rows.  Same chain as imvoxelnet.py:22-34,146-173."""
+        relu = torch.relu
+        rows, grid = to_channels_last_rows(x)
+        skips = []
+        for i in range(self.n_scales):
+            for blk in getattr(self, f"down_layer_{i}"):
+                h, g1 = conv_rows(blk.conv1, rows, grid)
+                h = relu(bn_rows(blk.norm1, h, g1))
+                o, _ = conv_rows(blk.conv2, h, g1)
+                o = bn_rows(blk.norm2, o, g1)
+                if blk.stride != 1:
+                    skip, _ = conv_rows(blk.downsample[0], rows, grid)
+                    skip = bn_rows(blk.downsample[1], skip, g1)
+                else:
+                    skip = rows
+                rows, grid = relu(o + skip), g1
+            skips.append((rows, grid))
+        outs = []
+        for i in reversed(range(self.n_scales)):
+            if i < self.n_scales - 1:
+                up = getattr(self, f"up_block_{i + 1}")
+                h, g = conv_transpose_rows(up[0], rows, grid)
+                h = relu(bn_rows(up[1], h, g))
+                h, _ = conv_rows(up[3], h, g)
+                h = relu(bn_rows(up[4], h, g))
+                rows, grid = skips[i][0] + h, g
+            ob = getattr(self, f"out_block_{i}")
+            o, _ = conv_rows(ob[0], rows, grid)
+            o = relu(bn_rows(ob[1], o, grid))
+            outs.append(rows_to_ncdhw(o, grid, o.shape[1]))
+        return outs[::-1]
+
     def forward(self, x, tail_masks=None):
         """[1,C,nx,ny,nz] -> [out@1x, out@1/2, out@1/4], finest first (imvoxelnet.py:22-34)."""
         if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.shape[0] == 1:
             return self._forward_hip(x, tail_masks)
-        # library convolutions (training / autograd): the voxel head hands over a channels-last strided view, for which
-        # MIOpen has only its naive_conv_*_nonpacked kernels (2.6 s per config-2 step instead of ~0.1 s)
+        if train_conv_on_hip(x, [m.in_channels for m in self.modules() if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]):
+            return self._forward_autograd_hip(x)
+        # library convolutions: the voxel head hands over a channels-last strided view, for which MIOpen has only its
+        # naive_conv_*_nonpacked kernels (2.6 s per config-2 step instead of ~0.1 s)
         x = x.contiguous()
         skips = []
         for i in range(self.n_scales):

@@ -712,7 +712,7 @@ class TensorOps:
         if transposed:
             og = (2 * ix, 2 * iy, 2 * iz)
         else:
-            pad = ksize // 2
+            pad = 0 if ksize == 2 else ksize // 2
             og = tuple((d + 2 * pad - ksize) // stride + 1 for d in grid)
         y = torch.empty((og[0] * og[1] * og[2], Cout), dtype=torch.float32, device=x.device)
         if residual is not None and residual.shape != y.shape:

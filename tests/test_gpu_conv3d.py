@@ -158,3 +158,95 @@ def test_halo_ring_form_is_bit_identical_to_the_staged_form(grid, cin, cout, rel
     finally:
         gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 1)
         gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 2048)
+
+
+def test_k2_s2_convolution_matches_oracle(oracle_ops, gpu_ops):
+    """ksize 2 / stride 2 / no padding (the input gradient of ConvTranspose3d(2, 2)), fp32 and bf16x3 kernels."""
+    g = torch.Generator().manual_seed(5)
+    grid, Cin, Cout = (8, 6, 4), 64, 96
+    x = torch.randn(grid[0] * grid[1] * grid[2], Cin, generator=g)
+    wt = torch.randn(8, Cout, Cin, generator=g) * 0.05
+    y_c, og = oracle_ops.conv3d_cl(x, wt, grid, 2, 2, False, None, None, None, False)
+    assert og == (4, 3, 2)
+    y_g, og_g = gpu_ops.conv3d_cl(x.cuda(), wt.cuda(), grid, 2, 2, False, None, None, None, False)
+    assert og_g == og and float((y_g.cpu() - y_c).abs().max()) < 2e-5 * float(y_c.abs().max())
+    hi, lo = gpu_ops.split_bf16(wt.cuda())
+    y_b, _ = gpu_ops.conv3d_cl_bf16x3(x.cuda(), hi, lo, grid, 2, 2)
+    assert float((y_b.cpu() - y_c).abs().max()) < 1e-4 * float(y_c.abs().max())
+
+
+WGRAD_CASES = [  # Cin, Cout, grid, ksize, stride
+    (64, 128, (10, 9, 4), 3, 1),
+    (32, 28, (7, 5, 6), 3, 1),             # head-like: Cout % 128 != 0
+    (256, 256, (24, 20, 8), 3, 1),         # several tiles, voxel range split over workgroups (workspace reduce)
+    (64, 128, (8, 6, 4), 3, 2),
+    (64, 132, (6, 4, 4), 1, 2),
+    (96, 64, (8, 6, 4), 2, 2),             # ConvTranspose3d(2, 2) with the roles exchanged
+    (36, 4, (5, 5, 3), 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv3d_wgrad_matches_oracle(case, oracle_ops, gpu_ops):
+    """sgc_conv3d_wgrad_bf16x3 against the double-accumulating oracle loop: the 3-way bf16 split is fp32-faithful (bound
+    1e-4 of the tensor scale as for the forward kernel); two launches are bit-identical (ordered split reduction)."""
+    Cin, Cout, grid, k, s = case
+    g = torch.Generator().manual_seed(sum(grid) + Cin + Cout)
+    V = grid[0] * grid[1] * grid[2]
+    pad = 0 if k == 2 else k // 2
+    og = tuple((d + 2 * pad - k) // s + 1 for d in grid)
+    x = torch.randn(V, Cin, generator=g)
+    dy = torch.randn(og[0] * og[1] * og[2], Cout, generator=g)
+    ref = oracle_ops.conv3d_wgrad_bf16x3(x, dy, grid, k, s)
+    got = gpu_ops.conv3d_wgrad_bf16x3(x.cuda(), dy.cuda(), grid, k, s)
+    again = gpu_ops.conv3d_wgrad_bf16x3(x.cuda(), dy.cuda(), grid, k, s)
+    assert got.shape == ref.shape == (k ** 3, Cout, Cin)
+    assert torch.equal(got, again)
+    assert float((got.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,s", [(64, 96, (10, 8, 6), 3, 1), (32, 64, (8, 6, 4), 3, 2), (64, 128, (6, 6, 4), 1, 2),
+                                                (128, 25, (9, 7, 4), 3, 1)])
+def test_channels_last_conv_function_matches_torch_autograd(cin, cout, grid, k, s, gpu_ops):
+    """ChannelsLastConv3dFunction (forward, input gradient, weight gradient on the HIP kernels) against torch's conv3d
+    autograd in float64 on the CPU."""
+    from sgcdet_amd.functions import ChannelsLastConv3dFunction
+    g = torch.Generator().manual_seed(cin + cout)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) * 0.05
+    xr = x.double().view(*grid, cin).permute(3, 0, 1, 2).unsqueeze(0).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv3d(xr, wr, None, s, k // 2)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = ChannelsLastConv3dFunction.apply(xg, wg, grid, k, s)
+    y_ref = yr[0].permute(1, 2, 3, 0).reshape(-1, cout)
+    assert float((y.detach().cpu() - y_ref).abs().max()) < 1e-4 * float(y_ref.abs().max())
+    y.backward(gy[0].permute(1, 2, 3, 0).reshape(-1, cout).float().cuda())
+    dx_ref = xr.grad[0].permute(1, 2, 3, 0).reshape(V, cin)
+    assert float((xg.grad.cpu() - dx_ref).abs().max()) < 1e-4 * float(dx_ref.abs().max())
+    assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max())
+
+
+def test_channels_last_conv_transpose_function_matches_torch_autograd(gpu_ops):
+    from sgcdet_amd.functions import ChannelsLastConvTranspose3dFunction
+    g = torch.Generator().manual_seed(11)
+    grid, cin, cout = (5, 4, 3), 64, 32
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(cin, cout, 2, 2, 2, generator=g) * 0.05
+    xr = x.double().view(*grid, cin).permute(3, 0, 1, 2).unsqueeze(0).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv_transpose3d(xr, wr, None, 2)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = ChannelsLastConvTranspose3dFunction.apply(xg, wg, grid)
+    y_ref = yr[0].permute(1, 2, 3, 0).reshape(-1, cout)
+    assert float((y.detach().cpu() - y_ref).abs().max()) < 1e-4 * float(y_ref.abs().max())
+    y.backward(gy[0].permute(1, 2, 3, 0).reshape(-1, cout).float().cuda())
+    dx_ref = xr.grad[0].permute(1, 2, 3, 0).reshape(V, cin)
+    assert float((xg.grad.cpu() - dx_ref).abs().max()) < 1e-4 * float(dx_ref.abs().max())
+    assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max())

@@ -45,3 +45,32 @@ def test_oracle_upsample_backward_is_the_adjoint_torch_autograd_computes(oracle_
         want, = torch.autograd.grad(up, x, go)
         got = oracle_ops.upsample2x_backward(go.contiguous())
         assert got.shape == want.shape and (got - want).abs().max() < 1e-5, shape
+
+
+def test_oracle_weight_gradient_is_what_torch_autograd_returns(oracle_ops):
+    """sgc_conv3d_wgrad_bf16x3 (oracle): nn.Conv3d.weight.grad permuted to [tap][Cout][Cin], strides 1 and 2, 1x1x1, and
+    the ConvTranspose3d(2, 2) weight gradient through the k2 s2 geometry with the two tensors exchanged."""
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, grid, k, s in [(8, 12, (5, 4, 3), 3, 1), (8, 4, (6, 4, 4), 3, 2), (4, 8, (4, 4, 2), 1, 2)]:
+        V = grid[0] * grid[1] * grid[2]
+        x = torch.randn(V, cin, generator=g)
+        w = torch.randn(cout, cin, k, k, k, generator=g).double().requires_grad_(True)
+        y = F.conv3d(x.double().view(*grid, cin).permute(3, 0, 1, 2).unsqueeze(0), w, None, s, k // 2)
+        gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        y.backward(gy)
+        dw = oracle_ops.conv3d_wgrad_bf16x3(x, gy[0].permute(1, 2, 3, 0).reshape(-1, cout).float().contiguous(), grid, k, s)
+        ref = w.grad.permute(2, 3, 4, 0, 1).reshape(k ** 3, cout, cin)
+        assert (dw - ref).abs().max() < 1e-5 * ref.abs().max()
+    grid, cin, cout = (3, 4, 2), 8, 4
+    x = torch.randn(24, cin, generator=g)
+    w = torch.randn(cin, cout, 2, 2, 2, generator=g).double().requires_grad_(True)
+    xr = x.double().view(*grid, cin).permute(3, 0, 1, 2).unsqueeze(0).requires_grad_(True)
+    y = F.conv_transpose3d(xr, w, None, 2)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    dy = gy[0].permute(1, 2, 3, 0).reshape(-1, cout).float().contiguous()
+    dwk = oracle_ops.conv3d_wgrad_bf16x3(dy, x, (6, 8, 4), 2, 2)
+    assert (dwk.permute(1, 2, 0).reshape(cin, cout, 2, 2, 2) - w.grad).abs().max() < 1e-5 * w.grad.abs().max()
+    wt = w.detach().float().permute(2, 3, 4, 0, 1).reshape(8, cin, cout).contiguous()
+    dx, og = oracle_ops.conv3d_cl(dy, wt, (6, 8, 4), 2, 2, False, None, None, None, False)
+    assert og == grid and (dx - xr.grad[0].permute(1, 2, 3, 0).reshape(24, cin)).abs().max() < 1e-4

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="cfg2_scannet")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-neck", action="store_true", help="stop at the volume (view transform only)")
+ap.add_argument("--profile", action="store_true", help="print the 25 kernels with the most GPU time (torch.profiler)")
 args = ap.parse_args()
 w = workload(args.workload)
 torch.manual_seed(0)
@@ -41,5 +42,14 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(args.steps):
     l = step()
 torch.cuda.synchronize()
+if args.profile:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
+    for e in rows:
+        print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
 print(json.dumps(dict(workload=args.workload, ms_per_step=round((time.perf_counter() - t) / args.steps * 1e3, 2), loss=l,
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck)))
