@@ -417,6 +417,7 @@ extern int g_tune_tile_depth_lds;
 extern int g_tune_tile_diag;
 extern int g_tune_tile_nbuf;
 extern int g_tune_tile_hg;
+extern int g_tune_tile_xcd;
 extern int g_tune_conv_halo;    // conv3d.hip: halo-resident kernel for the 3x3x3 stride-1 layers   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
 static int pick_tp(int SPI, int LPI) {
@@ -595,6 +596,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "tile_diag")) { g_tune_tile_diag = value; return SGC_OK; }
   if (!strcmp(key, "tile_nbuf")) { g_tune_tile_nbuf = value; return SGC_OK; }
   if (!strcmp(key, "tile_hg")) { g_tune_tile_hg = value; return SGC_OK; }
+  if (!strcmp(key, "tile_xcd")) { g_tune_tile_xcd = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }
 

@@ -196,6 +196,7 @@ struct TileParams {
   int hx, hy;                 // halo on each side of the bin
   int smx, smy;               // largest |shift| over the heads
   int HG;                     // heads per workgroup (divides M)
+  int xcd_map;                // 1: all work of camera n on XCD n % 8 (see the kernel), 0: plain (camera, bin, head) order
   int diag;                   // timing experiments only (sgc_set_tuning "tile_diag"): 1 = no compute, 2 = no fill
 };
 
@@ -245,9 +246,23 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ngrp = p.M / p.HG;
-  const int hg = blockIdx.x % ngrp;
-  const int t = blockIdx.x / ngrp;              // (camera, bin)
   const int nb = p.nbx * p.nby;
+  int hg, t;
+  if (p.xcd_map) {
+    // (option, off by default -- see g_tune_tile_xcd)  Workgroups go to the 8 XCDs round-robin by blockIdx, and every XCD
+    // has its own L2.  All work of camera n runs on XCD n % 8, head-major with the bins innermost: a bin's halo rows are
+    // re-read by its neighbours a few workgroups later, and the camera's depth map (shared by the 8 heads; re-fetched by
+    // 8 different L2s when head h simply goes to XCD h) is re-read by the next head about 1 MB of traffic later.
+    const int x = blockIdx.x & 7, r = blockIdx.x >> 3, per_cam = nb * ngrp;
+    const int n = (r / per_cam) * 8 + x;
+    if (n >= p.N) return;
+    const int j = r - (r / per_cam) * per_cam;
+    hg = j / nb;
+    t = n * nb + (j - hg * nb);
+  } else {
+    hg = blockIdx.x % ngrp;
+    t = blockIdx.x / ngrp;                      // (camera, bin)
+  }
   const int i0 = p.bin_offset[t], i1 = p.bin_offset[t + 1];
   // the first head's window shift travels with the bin bounds (two dependent scalar round trips otherwise)
   int sx_first = 0, sy_first = 0;
@@ -474,6 +489,10 @@ int g_tune_tile_depth_lds = -1; // >= 0 overrides the caller's depth_in_lds
 int g_tune_tile_diag = 0;
 int g_tune_tile_nbuf = 0;       // value-window buffers; 2 = the next head's window lands while the current head is computed
                                 // (needs heads-per-workgroup > 1).  auto: 1
+int g_tune_tile_xcd = 0;        // 1: camera n's workgroups on XCD n % 8 (head-major, bins innermost); 0: (camera, bin, head) order,
+                                // i.e. head h on XCD h.  Measured in one process: 106.8 / 109.1 vs 108.8 / 125.2 us (config 2), 463 vs
+                                // 437 us (config 4, depth in LDS), 503 vs 547 us (depth from global) -- no consistent gain: the 1.30x HBM
+                                // overfetch (the depth maps through 8 L2s) is not what bounds the kernel
 int g_tune_tile_hg = 0;         // heads per workgroup.  auto: 1 (most workgroups: (camera, bin, head))
 
 }  // namespace sgc
@@ -554,7 +573,7 @@ template <int CM, int NW, bool DL, int NBUF, int VB>
 static int launch_tile(const TileParams &p, size_t smem, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
   ensure_dynamic_lds((const void *)dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>, 160 * 1024, attr_done);
-  const int64_t grid = (int64_t)p.N * p.nbx * p.nby * (p.M / p.HG);
+  const int64_t grid = (int64_t)(p.xcd_map ? (p.N + 7) / 8 * 8 : p.N) * p.nbx * p.nby * (p.M / p.HG);
   hipLaunchKernelGGL((dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
   return check_launch("dfa3d_fwd_tile_kernel");
 }
@@ -587,6 +606,7 @@ extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf1
   p.hx = halo_x; p.hy = halo_y; p.smx = smx; p.smy = smy; p.diag = g_tune_tile_diag;
   p.tw = g.tw; p.th = g.th; p.dw = g.dw; p.dh = g.dh;
   p.HG = (g_tune_tile_hg > 0 && M % g_tune_tile_hg == 0) ? g_tune_tile_hg : 1;
+  p.xcd_map = g_tune_tile_xcd;
   if (g.lds > 160 * 1024)
     return set_error(SGC_EUNSUP, "sgc_pairs_deform_gather_tiled: window %dx%d needs %zu bytes of LDS", g.tw, g.th, g.lds);
   if (((int64_t)g.tw * g.th + 1) * (Cm / 4) >= 0x10000)
