@@ -101,7 +101,7 @@ for spec in os.environ.get("SGC_TILE_CONFIGS", "").split(";"):
 max_shift = (int(head_shift[:, 0].abs().max()), int(head_shift[:, 1].abs().max())) if head_shift is not None else (0, 0)
 res = []
 for bw, bh, hx, hy, dl, nw, sh, nbuf, hg in configs:
-    for key, val in (("tile_nw", nw), ("tile_nbuf", nbuf), ("tile_hg", hg), ("tile_xcd", int(os.environ.get("SGC_TILE_XCD", "1")))):
+    for key, val in (("tile_nw", nw), ("tile_nbuf", nbuf), ("tile_hg", hg), ("tile_xcd", int(os.environ.get("SGC_TILE_XCD", "0")))):
         ops.lib.call("sgc_set_tuning", key.encode(), val)
     hs = head_shift if sh else None
     ms = max_shift if sh else (0, 0)
