@@ -125,3 +125,34 @@ def test_depth_net_matches_the_reference_class_on_cpu_paths():
     assert abs(float(loss) - float(d["loss"])) < 1e-4
     loss.backward()
     assert xs.grad is not None and torch.isfinite(xs.grad).all() and float(xs.grad.abs().sum()) > 0
+
+
+def test_bn_rows_is_batchnorm3d_on_the_channels_last_rows():
+    """conv_plan.bn_rows (the BatchNorm of the HIP training path, applied to [V, C] rows) == nn.BatchNorm3d on the
+    [1, C, X, Y, Z] volume: output, running statistics, num_batches_tracked, gradients; momentum=None (cumulative average)
+    and eval mode; a non-BatchNorm3d module goes through the 5-D view."""
+    import copy
+    import torch
+    from sgcdet_amd.plugin.conv_plan import bn_rows, rows_to_ncdhw
+    torch.manual_seed(0)
+    grid, C = (4, 3, 5), 8
+    for momentum, training in ((0.1, True), (None, True), (0.1, False)):
+        bn = torch.nn.BatchNorm3d(C, momentum=momentum)
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+        bn.train(training)
+        ref = copy.deepcopy(bn)
+        for _ in range(2):                                   # two steps: the cumulative-average momentum changes per step
+            rows = torch.randn(grid[0] * grid[1] * grid[2], C, requires_grad=True)
+            vol = rows_to_ncdhw(rows.detach(), grid, C).contiguous().requires_grad_(True)
+            y = bn_rows(bn, rows, grid)
+            y_ref = ref(vol)
+            assert torch.allclose(rows_to_ncdhw(y, grid, C), y_ref, atol=1e-6)
+            y.square().sum().backward(); y_ref.square().sum().backward()
+            assert torch.allclose(rows_to_ncdhw(rows.grad, grid, C), vol.grad, atol=1e-5)
+        assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-6) and torch.allclose(bn.running_var, ref.running_var, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+        assert torch.allclose(bn.weight.grad, ref.weight.grad, atol=1e-4) and torch.allclose(bn.bias.grad, ref.bias.grad, atol=1e-4)
+    gn = torch.nn.GroupNorm(2, C)
+    rows = torch.randn(60, C)
+    assert torch.allclose(rows_to_ncdhw(bn_rows(gn, rows, grid), grid, C), gn(rows_to_ncdhw(rows, grid, C)), atol=1e-6)
