@@ -391,6 +391,17 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
 int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                                     int transposed, int bf16x3);
 
+/* 2-D convolution over a stack of channels-last images -- the producer side of the hand-over: the output
+ * convolutions of the image FPN (mmdet `FPN.fpn_convs` / `lateral_convs` as configured in configs/SGCDet_ScanNet.py:84-88
+ * and called at detectors/SGCDet.py:67) emitting the [N, H*W, C] rows the view transformation consumes
+ * (TU/transformer.py:151-170) with no NCHW round trip.
+ *   x [N*H*W, Cin] -> y [N*H*W, Cout]; w_hi / w_lo [ksize^2][Cout][Cin] (nn.Conv2d weight [Cout,Cin,ky,kx] permuted, split as
+ *   for sgc_conv3d_cl_bf16x3); ksize in {1,3} with padding ksize/2, stride 1; scale / shift / residual / relu as above;
+ *   Cin % 32 == 0, Cout % 4 == 0.                                                                                       */
+int sgc_conv2d_nhwc_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                           const float *shift, const float *residual_or_null, float *y, int N, int H, int W,
+                           int Cin, int Cout, int ksize, int relu, sgc_stream_t stream);
+
 /* Weight gradient of the same convolutions (the neck / head layers in training; the reference gets it
  * from cuDNN through autograd of nn.Conv3d, necks/imvoxelnet.py:36-64):
  *   dw[tap][co][ci] = sum over output voxels o of dy[o][co] * x[nbr(o, tap)][ci]      (bf16x3 arithmetic, fp32 accumulate)

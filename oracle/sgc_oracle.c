@@ -906,6 +906,39 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   return rc;
 }
 
+/* nn.Conv2d(k, padding=k/2) over channels-last images + the same epilogue (mmdet FPN lateral / output convolutions) */
+int sgc_conv2d_nhwc_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                           const float *shift, const float *residual_or_null, float *y, int N, int H, int W,
+                           int Cin, int Cout, int ksize, int relu, sgc_stream_t stream) {
+  (void)stream;
+  if (!x || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  if (ksize != 1 && ksize != 3) return fail(SGC_EUNSUP, "ksize in {1,3}");
+  const int pad = ksize / 2;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w) {
+        const int64_t orow = ((int64_t)n * H + h) * W + w;
+        for (int co = 0; co < Cout; ++co) {
+          float acc = 0.f;
+          for (int ky = 0; ky < ksize; ++ky)
+            for (int kx = 0; kx < ksize; ++kx) {
+              const int hh = h + ky - pad, ww = w + kx - pad;
+              if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+              const float *xi = x + (((int64_t)n * H + hh) * W + ww) * Cin;
+              const int64_t wo = ((int64_t)(ky * ksize + kx) * Cout + co) * Cin;
+              for (int ci = 0; ci < Cin; ++ci) acc += xi[ci] * (bf16_to_f32(w_hi[wo + ci]) + bf16_to_f32(w_lo[wo + ci]));
+            }
+          float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+          if (relu == 2 && v < 0.f) v = 0.f;
+          if (residual_or_null) v += residual_or_null[orow * Cout + co];
+          if (relu == 1 && v < 0.f) v = 0.f;
+          y[orow * Cout + co] = v;
+        }
+      }
+  return SGC_OK;
+}
+
 /* weight gradient of the convolution above: dW[tap][co][ci] = sum_o dy[o][co] * x[nbr(o, tap)][ci]
  * (what autograd returns for nn.Conv3d.weight, permuted to the kernel's [tap][Cout][Cin] layout); double accumulation */
 int64_t sgc_conv3d_wgrad_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {

@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3_masked": [_p] * 8 + [_i] * 6 + [_p, C.c_int64] + [_p],
+    "sgc_conv2d_nhwc_bf16x3": [_p] * 7 + [_i] * 7 + [_p],
     "sgc_conv3d_wgrad_bf16x3": [_p] * 3 + [_i] * 7 + [_p, C.c_int64] + [_p],
     "sgc_mask_dilate3": [_p, _p, _i, _i, _i, _p],
     "sgc_valid_pyramid": [_p, _p, _i, _i, _i, _i, _p],

@@ -65,6 +65,8 @@ struct ConvParams {
                           // rows with mask 0 are not needed by the caller.  Tiles of 64 voxels (one wave) without a live row skip
                           // their MFMAs, bricks without one skip everything; what they store is the epilogue of a zero
                           // accumulator (finite, deterministic).  Live rows are bit-identical to the dense launch.
+  int two_d;              // 2-D convolution over a stack of images: grid (x, y, z) = (image, row, column), the taps only span (y, z)
+                          // (sgc_conv2d_nhwc_bf16x3: the FPN output convolutions)
   int hm_bf16;            // head-major output stored as bfloat16 (RNE of the fp32 result)
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
     int dx = 0, dy = 0, dz = 0;
     if (!p.transposed && p.ksize > 1) {
       dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
+      if (p.two_d) { dx = p.pad; dy = tap / p.ksize; dz = tap % p.ksize; }      // k x k taps in the (y, z) plane of every x slice
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     int dx = 0, dy = 0, dz = 0;
     if (!p.transposed && p.ksize > 1) {
       dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
+      if (p.two_d) { dx = p.pad; dy = tap / p.ksize; dz = tap % p.ksize; }      // k x k taps in the (y, z) plane of every x slice
     }
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
@@ -1144,6 +1148,11 @@ static int conv_setup(ConvParams &p, const char *who, const float *x, const void
     oz = (iz + 2 * p.pad - ksize) / stride + 1;
     p.gx = ox; p.gy = oy; p.gz = oz;
   }
+  if (p.two_d) {                               // images are independent: no taps, no padding, no stride along x
+    if (transposed || stride != 1) return set_error(SGC_EUNSUP, "%s: the 2-D form is stride 1, not transposed", who);
+    p.taps = ksize * ksize;
+    ox = ix; p.gx = ox;
+  }
   p.M = p.gx * p.gy * p.gz;
   return SGC_OK;
 }
@@ -1217,9 +1226,10 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                          int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
-                         const uint8_t *out_mask_or_null, sgc_stream_t stream) {
+                         const uint8_t *out_mask_or_null, sgc_stream_t stream, int two_d = 0) {
   ConvParamsB p = {};
   p.out_mask = out_mask_or_null;
+  p.two_d = two_d;
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
   if (rc) return rc;
@@ -1229,7 +1239,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
-  if (g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
+  if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
     // ring form where it measured faster (the 256 -> 256 layers on the 4x4x16 brick: 293 -> 279 us; 3-7 % slower on the
     // 512-channel / 128-column layers, whose split-K slices are short); halo_ring = 2 forces it everywhere
     const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && p.gz >= 16 && g_tune_halo_brick == 0 && Cout >= 256 && Cin <= 256)) &&
@@ -1491,6 +1501,20 @@ extern "C" int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const 
                                     sgc_stream_t stream) {
   return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu,
                        workspace_or_null, workspace_floats, nullptr, stream);
+}
+
+// 2-D convolution over a stack of channels-last images (the producer side of the hand-over -- the FPN's
+// output convolutions, mmdet FPN.fpn_convs as configured by configs/SGCDet_ScanNet.py:84-88 and called at detectors/
+// SGCDet.py:67, emitting the [N, H*W, C] rows the view transformation consumes, TU/transformer.py:151-170, without an
+// NCHW round trip).  x [N*H*W, Cin] -> y [N*H*W, Cout], ksize 1 | 3 (pad k/2), stride 1; same bf16x3 arithmetic and
+// epilogue (scale / shift / residual / relu) as the 3-D entry point, on the implicit-GEMM kernel with the taps confined to
+// the (row, column) plane.
+extern "C" int sgc_conv2d_nhwc_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                      const float *shift, const float *residual_or_null, float *y, int N, int H, int W,
+                                      int Cin, int Cout, int ksize, int relu, sgc_stream_t stream) {
+  if (ksize != 1 && ksize != 3) return set_error(SGC_EUNSUP, "sgc_conv2d_nhwc_bf16x3: ksize in {1,3}");
+  return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, N, H, W, Cin, Cout, ksize, 1, 0, relu, nullptr, 0,
+                       nullptr, stream, 1);
 }
 
 // Output-masked 3x3x3 stride-1 convolution (the decoder tail / head of the neck, where only voxels in -- or next to --

@@ -10,11 +10,12 @@ from .neck3d import FastIndoorImVoxelNeck, BasicBlock3dV2
 from .bbox_head import ImVoxelHeadV2, ScanNetImVoxelHeadV2, SunRgbdImVoxelHeadV2, get_points
 from .detector import SGCDet
 from .depth_net import DepthNet_Fusion, ResNetFPN, SimpleUnet2D, ConvBnReLU2D
+from .fpn import FPN
 
 __all__ = [
     "MSDeformableAttention3D_DFA3D", "DeformCrossAttention_DFA3D", "MyCustomBaseTransformerLayer",
     "VoxFormerLayer", "VoxFormerEncoder_DFA3D", "PerceptionTransformer_DFA3D", "compute_projection",
     "AdaptiveSparseHead", "DenseHead", "topk_wo_grad", "FastIndoorImVoxelNeck", "BasicBlock3dV2",
     "ImVoxelHeadV2", "ScanNetImVoxelHeadV2", "SunRgbdImVoxelHeadV2", "get_points", "SGCDet",
-    "DepthNet_Fusion", "ResNetFPN", "SimpleUnet2D", "ConvBnReLU2D",
+    "DepthNet_Fusion", "ResNetFPN", "SimpleUnet2D", "ConvBnReLU2D", "FPN",
 ]

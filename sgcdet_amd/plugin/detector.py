@@ -24,6 +24,8 @@ class SGCDet(nn.Module):
                  use_gt_dpt=False, depth_loss=False, occ_loss=False, lighting_augmentation=False):
         super().__init__()
         self.upstream_cfg = dict(backbone=backbone, neck=neck, depth_head=depth_head, head_2d=head_2d)
+        # the image FPN (row f-1): built when the config names the plain FPN; the backbone stays a config entry
+        self.neck = build_neck(neck) if isinstance(neck, dict) and neck.get("type") == "FPN" else None
         self.depth_head = build_head(depth_head) if depth_head is not None else None
         self.use_gt_dpt, self.depth_loss = use_gt_dpt, depth_loss
         self.neck_3d = build_neck(neck_3d)
@@ -37,6 +39,14 @@ class SGCDet(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.occ_loss = occ_loss
+
+    def image_features(self, backbone_feats):
+        """Backbone maps [[B*N, C_l, H_l, W_l], ...] -> [[B, N, C, H, W], ...] as SGCDet.py:67-69 with B = 1.  In eval mode on
+        the GPU the FPN's convolutions emit channels-last memory (plugin/fpn.py), which the view transformation reads in
+        place; the reshape keeps that memory format."""
+        if self.neck is None:
+            raise RuntimeError("SGCDet.image_features: the config has no FPN neck")
+        return [f.unsqueeze(0) for f in self.neck(backbone_feats)]
 
     @staticmethod
     def depth_pyramid(dpt_dist):

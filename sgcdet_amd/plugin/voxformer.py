@@ -767,7 +767,16 @@ class PerceptionTransformer_DFA3D(BaseModule):
             else:   # channels-last producers: no copy; otherwise one crop+transpose launch each
                 f_rows = _channels_last_rows(feat[0], h, w) if feat.dtype == torch.float32 else None
                 d_rows = _channels_last_rows(dpt[0], h, w) if dpt.dtype == torch.float32 else None
-                if f_rows is None or d_rows is None or f_rows.shape[1] != d_rows.shape[1]:
+                if f_rows is not None and (d_rows is None or f_rows.shape[1] != d_rows.shape[1]):
+                    # channels-last feature maps (the FPN of plugin/fpn.py) next to an NCHW depth map: only the small depth
+                    # map is transposed, into rows with the feature map's camera stride (the cropped rows are never read)
+                    d = ops.nchw_to_nhwc_crop(dpt[0].float(), h, w)
+                    if f_rows.shape[1] == h * w:
+                        d_rows = d
+                    else:
+                        d_rows = d.new_empty((n_cam, f_rows.shape[1], d.shape[2]))
+                        d_rows[:, :h * w] = d
+                elif f_rows is None or d_rows is None:
                     f_rows = ops.nchw_to_nhwc_crop(feat[0].float(), h, w)
                     d_rows = ops.nchw_to_nhwc_crop(dpt[0].float(), h, w)
                 feats.append(f_rows)

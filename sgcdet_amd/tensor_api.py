@@ -527,6 +527,25 @@ class TensorOps:
                        _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
         return y
 
+    def conv2d_nhwc_bf16x3(self, x, w_hi, w_lo, nhw, ksize, scale=None, shift=None, residual=None, relu=False, out=None):
+        """2-D convolution (k in {1,3}, padding k//2, stride 1) over channels-last image rows: x [N*H*W, Cin] ->
+        [N*H*W, Cout]; weights [k*k, Cout, Cin] split as ``split_bf16`` (``sgc_conv2d_nhwc_bf16x3``)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual, out=out)
+        self._f32(x=x, scale=scale, shift=shift, residual=residual, out=out)
+        if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape:
+            raise RuntimeError("conv2d_nhwc_bf16x3: w_hi / w_lo must be bfloat16 tensors of one shape")
+        N, H, W = nhw
+        rows, Cin = x.shape
+        taps, Cout, Cin2 = w_hi.shape
+        if rows != N * H * W or Cin2 != Cin or taps != ksize * ksize:
+            raise RuntimeError("conv2d_nhwc_bf16x3: inconsistent shapes")
+        y = out if out is not None else torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
+        if y.shape != (rows, Cout) or (residual is not None and residual.shape != y.shape):
+            raise RuntimeError("conv2d_nhwc_bf16x3: bad `out` / residual shape")
+        self._call("sgc_conv2d_nhwc_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, N, H, W, Cin, Cout, ksize, int(relu),
+                   _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=taps, OV=rows))
+        return y
+
     def conv3d_wgrad_bf16x3(self, x, dy, grid, ksize, stride=1):
         """dW [ksize^3, Cout, Cin] of the channels-last convolution: x [IV, Cin] on ``grid``, dy [OV, Cout] on the output
         grid (``sgc_conv3d_wgrad_bf16x3``; ksize 2 = stride 2, no padding)."""

@@ -62,10 +62,13 @@ def test_reference_configs_build_unchanged(name, params_m, depth_m):
     cfg = Config.fromfile(os.path.join(REF_CONFIGS, name + ".py"))
     det = build_detector(cfg.model)
     nd = sum(p.numel() for p in det.depth_head.parameters()) / 1e6          # DepthNet_Fusion (f-2) is built from the config too
-    n = sum(p.numel() for p in det.parameters()) / 1e6 - nd                 # voxel head + neck + head
+    nf = sum(p.numel() for p in det.neck.parameters()) / 1e6                # and the image FPN (f-1): 4 lateral 1x1 + 4 output 3x3
+    n = sum(p.numel() for p in det.parameters()) / 1e6 - nd - nf            # voxel head + neck + head
     assert abs(n - params_m) < 0.02 and abs(nd - depth_m) < 0.02, (n, nd)
+    c = cfg.model["neck"]["out_channels"]
+    assert sum(p.numel() for p in det.neck.parameters()) == sum(ci * c + c for ci in (256, 512, 1024, 2048)) + 4 * (9 * c * c + c)
     keys = det.state_dict().keys()
-    for k in ("voxel_head.base_heads.0.ref_3d",
+    for k in ("neck.lateral_convs.3.conv.weight", "neck.fpn_convs.0.conv.bias","voxel_head.base_heads.0.ref_3d",
               "voxel_head.base_heads.2.cross_transformer.encoder.layers.0.attentions.0.deformable_attention.sampling_offsets_depth.bias",
               "voxel_head.base_heads.1.cross_transformer.encoder.layers.0.attentions.0.attention_pooling.in_proj_weight",
               "voxel_head.base_heads.0.cross_transformer.encoder.layers.0.ffns.0.layers.0.0.weight",

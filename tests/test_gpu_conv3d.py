@@ -250,3 +250,26 @@ def test_channels_last_conv_transpose_function_matches_torch_autograd(gpu_ops):
     dx_ref = xr.grad[0].permute(1, 2, 3, 0).reshape(V, cin)
     assert float((xg.grad.cpu() - dx_ref).abs().max()) < 1e-4 * float(dx_ref.abs().max())
     assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,k,relu,res", [(3, 15, 20, 64, 96, 3, 1, True), (2, 8, 10, 256, 32, 1, 0, False),
+                                                        (4, 30, 40, 32, 256, 3, 0, False), (1, 7, 5, 96, 28, 3, 2, True)])
+def test_conv2d_nhwc_matches_oracle_and_torch(N, H, W, cin, cout, k, relu, res, oracle_ops, gpu_ops):
+    """sgc_conv2d_nhwc_bf16x3 (row f-1: the FPN's convolutions on channels-last image rows): against the oracle loop and
+    against F.conv2d on the NCHW view; images must not leak into each other (the taps are confined to one image)."""
+    g = torch.Generator().manual_seed(N * H + cin + cout)
+    x = torch.randn(N * H * W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    wt = w.permute(2, 3, 0, 1).reshape(k * k, cout, cin).contiguous()
+    hi, lo = gpu_ops.split_bf16(wt)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    r = torch.randn(N * H * W, cout, generator=g) if res else None
+    ref = oracle_ops.conv2d_nhwc_bf16x3(x, hi, lo, (N, H, W), k, sc, sh, r, relu)
+    got = gpu_ops.conv2d_nhwc_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), (N, H, W), k, sc.cuda(), sh.cuda(),
+                                     r.cuda() if res else None, relu).cpu()
+    assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    if relu == 0 and not res:
+        y = torch.nn.functional.conv2d(x.view(N, H, W, cin).permute(0, 3, 1, 2), (hi.float() + lo.float()).view(k, k, cout, cin).permute(2, 3, 0, 1),
+                                       None, 1, k // 2)
+        y = y.permute(0, 2, 3, 1).reshape(-1, cout) * sc + sh
+        assert float((got - y).abs().max()) < 1e-4 * max(1.0, float(y.abs().max()))

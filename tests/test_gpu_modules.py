@@ -880,3 +880,47 @@ def test_neck_and_head_autograd_on_hip_kernels_matches_library_convolutions():
         assert float((ga - gb).abs().max()) < 5e-2 * max(1e-12, float(gb.abs().max())), n
         if gb.numel() > 1:
             assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.9999, n
+
+
+def test_fpn_on_hip_emits_channels_last_maps_the_path_reads_in_place():
+    """Row f-1, producer side: plugin.fpn.FPN in eval mode on the GPU == its torch formulation (1e-4 of the scale), its
+    outputs are channels-last in memory, and feeding them to the view transformation launches NO NCHW -> NHWC pass of the
+    feature maps while giving the results of the NCHW hand-over (same values, so bit-identical volume / valid / occ)."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd import ext
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    w = workload("cfg2_scannet")
+    torch.manual_seed(5)
+    cfg = model_config(w)
+    cfg["neck"] = dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=w["embed_dims"], num_outs=4)
+    det = build_detector(cfg).eval().cuda()
+    det.neck.init_weights()
+    N = 6
+    gen = torch.Generator().manual_seed(9)
+    backbone = [torch.randn(N, c, h, wd, generator=gen).cuda() * 0.5
+                for c, (h, wd) in zip([256, 512, 1024, 2048], [(64, 80), (32, 40), (16, 20), (8, 10)])]   # 239x320 padded to 256x320
+    backbone[1] = backbone[1].contiguous(memory_format=torch.channels_last)      # one level already channels-last: read in place
+    with torch.no_grad():
+        maps = det.image_features(backbone)
+        want = [f.unsqueeze(0) for f in det.neck._forward_torch(backbone)]
+    for a, b in zip(maps, want):
+        assert a.shape == b.shape and max_err(a, b) < 1e-4 * float(b.abs().max())
+        assert a[0].is_contiguous(memory_format=torch.channels_last)
+    _, dpt, meta = make_scene(N, w["embed_dims"], kind=w["kind"], seed=33, device="cuda", img_hw=(239, 320))
+    ops = ext.ops()
+    calls = []
+    orig = ops.nchw_to_nhwc_crop
+    ops.nchw_to_nhwc_crop = lambda src, *a, **k: (calls.append(src.shape[1]), orig(src, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            got = det.forward_features(maps[:3], [meta], dpt)
+            got = {k: got[k].clone() for k in ("volume", "valid", "occ")}
+            n_cl = sum(1 for c in calls if c == w["embed_dims"])
+            ref = det.forward_features([m.contiguous() for m in maps[:3]], [meta], dpt)
+            torch.cuda.synchronize()
+    finally:
+        ops.nchw_to_nhwc_crop = orig
+    assert n_cl == 0 and sum(1 for c in calls if c == w["embed_dims"]) > 0      # only the NCHW hand-over transposed feature maps
+    for k in got:
+        assert torch.equal(got[k], ref[k]), k

@@ -156,3 +156,29 @@ def test_bn_rows_is_batchnorm3d_on_the_channels_last_rows():
     gn = torch.nn.GroupNorm(2, C)
     rows = torch.randn(60, C)
     assert torch.allclose(rows_to_ncdhw(bn_rows(gn, rows, grid), grid, C), gn(rows_to_ncdhw(rows, grid, C)), atol=1e-6)
+
+
+def test_fpn_restates_the_published_module():
+    """plugin.fpn.FPN (torch formulation) against the module's definition written out with plain functional calls: lateral
+    1x1 + bias, top-down nearest to the finer size (odd sizes: 8 -> 15), 3x3 + bias; state-dict keys as mmdet's."""
+    import torch
+    import torch.nn.functional as F
+    from sgcdet_amd.plugin.fpn import FPN, _nearest_index
+    torch.manual_seed(0)
+    fpn = FPN([32, 64, 96, 128], 32, 4).eval()
+    fpn.init_weights()
+    for p in fpn.parameters():
+        p.data.add_(torch.randn_like(p) * 0.05)
+    feats = [torch.randn(2, c, h, w) for c, (h, w) in zip([32, 64, 96, 128], [(60, 80), (30, 40), (15, 20), (8, 10)])]
+    sd = fpn.state_dict()
+    assert set(sd) == {f"{g}.{i}.conv.{t}" for g in ("lateral_convs", "fpn_convs") for i in range(4) for t in ("weight", "bias")}
+    lat = [F.conv2d(f, sd[f"lateral_convs.{i}.conv.weight"], sd[f"lateral_convs.{i}.conv.bias"]) for i, f in enumerate(feats)]
+    for i in (3, 2, 1):
+        lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+    want = [F.conv2d(l, sd[f"fpn_convs.{i}.conv.weight"], sd[f"fpn_convs.{i}.conv.bias"], padding=1) for i, l in enumerate(lat)]
+    got = fpn(feats)
+    assert len(got) == 4 and all(torch.allclose(g, w, atol=1e-5) for g, w in zip(got, want))
+    # the index rule the kernel path uses for the top-down step == F.interpolate(mode="nearest")
+    x = torch.arange(8 * 10, dtype=torch.float32).view(1, 1, 8, 10)
+    up = F.interpolate(x, size=(15, 20), mode="nearest")
+    assert torch.equal(up[0, 0], x[0, 0][_nearest_index(15, 8, "cpu")][:, _nearest_index(20, 10, "cpu")])
