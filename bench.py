@@ -290,7 +290,10 @@ def main():
     eager_events = not det.scene_graph      # kernels inside a replayed scene graph cannot carry host-side events
     if eager_events:
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
+        # the neck / head convolutions live in the tail hipGraph when there is one (a capture cannot carry host-side events)
+        gather_names = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled"}
+        ops.event_names = (gather_names if det.use_graph else None if args.breakdown
+                           else gather_names | {"sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"})
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)

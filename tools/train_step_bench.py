@@ -42,6 +42,7 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(args.steps):
     l = step()
 torch.cuda.synchronize()
+ms_step = round((time.perf_counter() - t) / args.steps * 1e3, 2)
 if args.profile:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -51,5 +52,5 @@ if args.profile:
     rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
     for e in rows:
         print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
-print(json.dumps(dict(workload=args.workload, ms_per_step=round((time.perf_counter() - t) / args.steps * 1e3, 2), loss=l,
+print(json.dumps(dict(workload=args.workload, ms_per_step=ms_step, loss=l,
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck)))
