@@ -258,10 +258,7 @@ def main():
             feats, dpt = [cl(f) for f in feats], cl(dpt)
         scenes.append((feats, dpt, [meta]))
 
-    ops = ext.ops()
-    for kv in filter(None, os.environ.get("SGC_TUNE", "").split(",")):      # development knobs: SGC_TUNE="tile_nw=8,tile_hg=2"
-        key, val = kv.split("=")
-        ops.lib.call("sgc_set_tuning", key.encode(), int(val))
+    ops = ext.ops()                 # honours the development knobs of SGC_TUNE="tile_nw=8,tile_hg=2" (variant selection only)
 
     streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
 

@@ -14,6 +14,8 @@ Inputs must be contiguous CUDA(HIP) tensors on one device -- anything else raise
 ``RuntimeError`` (reference: AT_ASSERTM, wms_deform_attn_cuda.cu:220-238).  There is no
 CPU path.
 """
+import os
+
 import torch
 
 from ._lib import library
@@ -27,6 +29,10 @@ def ops():
     global _OPS
     if _OPS is None:
         _OPS = TensorOps(library(), "cuda")
+        # development knobs of the kernels (variant selection only -- results never depend on them): SGC_TUNE="key=value,..."
+        for kv in filter(None, os.environ.get("SGC_TUNE", "").split(",")):
+            key, val = kv.split("=")
+            _OPS.lib.call("sgc_set_tuning", key.strip().encode(), int(val))
     return _OPS
 
 
