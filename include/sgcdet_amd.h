@@ -464,6 +464,13 @@ int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const
  * counts as the largest value, as in torch).  One launch, one workgroup, deterministic.                          */
 int sgc_topk_select(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
                     sgc_stream_t stream);
+/* The same selection over many workgroups (candidate sets of the 80x80x32 / 96x96x32 configurations: one workgroup needs
+ * ~0.5 ms for 204 800 scores): four histogram launches, a counting launch and an ordered compaction, identical outputs.
+ * workspace: sgc_topk_select_workspace_bytes(n) bytes, contents irrelevant; NULL / too small / a small n: the one-workgroup
+ * form above.                                                                                                          */
+int sgc_topk_select_ws(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
+                       void *workspace_or_null, int64_t workspace_bytes, sgc_stream_t stream);
+int64_t sgc_topk_select_workspace_bytes(int n);
 
 /* nn.LayerNorm(C) over the first min(rows_cap, *rows_dev_or_null) rows of x [rows_cap, C] (the two norms of
  * VoxFormerLayer, TU/encoder.py:311-338): y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance,

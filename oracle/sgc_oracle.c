@@ -1101,6 +1101,14 @@ int sgc_topk_select(const float *score, int n, int k, int64_t *idx_out, int64_t 
   return SGC_OK;
 }
 
+/* many-workgroup entry point of the product: the oracle has one implementation */
+int64_t sgc_topk_select_workspace_bytes(int n) { (void)n; return 0; }
+int sgc_topk_select_ws(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
+                       void *workspace_or_null, int64_t workspace_bytes, sgc_stream_t stream) {
+  (void)workspace_or_null; (void)workspace_bytes;
+  return sgc_topk_select(score, n, k, idx_out, valid_or_null, mask_or_null, stream);
+}
+
 int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
                         const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream) {
   (void)stream;

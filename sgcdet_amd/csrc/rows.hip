@@ -173,6 +173,179 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
   }
 }
 
+// ---- many-workgroup form for large candidate sets (config 4 / 5: 204 800 voxels; one workgroup took ~500 us there) ----
+// Same selection, same tie rule, same outputs.  Four histogram launches (one per key byte, most significant first), one
+// counting launch and one ordered-compaction launch; workgroup w owns the 4096 consecutive candidates [4096 w, 4096 w + 4096).
+// The digit picked after pass q is a pure function of hist[0..q], which is complete when the next launch starts, so every
+// workgroup re-derives (prefix, remaining) itself: no single-workgroup "pick" launches and no device-side state hand-over.
+// workspace: int hist[4][256], then int cnt[G][2] = (elements above the cut, elements equal to it) per workgroup.
+constexpr int TK_T = 256, TK_ITEMS = 16, TK_CHUNK = TK_T * TK_ITEMS;
+
+__global__ void topk_init_kernel(int *__restrict__ ws, int n_ints) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ints; i += gridDim.x * blockDim.x) ws[i] = 0;
+}
+
+// (prefix, remaining) after the first `passes` bytes; all TK_T threads call it, hist_g is complete for those passes
+__device__ __forceinline__ void topk_resolve(const int *__restrict__ hist_g, int passes, int k, uint32_t &prefix_out, int &rem_out,
+                                             int *s_wave, uint32_t *s_pref, int *s_rem) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0;
+  int rem = k;
+  for (int q = 0; q < passes; ++q) {
+    const int shift = 24 - 8 * q;
+    const int v = hist_g[q * 256 + 255 - tid];
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); ++w) incl += s_wave[w];
+    const int excl = incl - v;
+    if (excl < rem && rem <= incl) {            // exactly one thread
+      *s_pref = prefix | ((uint32_t)(255 - tid) << shift);
+      *s_rem = rem - excl;
+    }
+    __syncthreads();
+    prefix = *s_pref;
+    rem = *s_rem;
+    __syncthreads();
+  }
+  prefix_out = prefix;
+  rem_out = rem;
+}
+
+__global__ __launch_bounds__(TK_T) void topk_hist_kernel(const float *__restrict__ score, int n, int k, int pass, int *__restrict__ ws) {
+  __shared__ int hist[256];
+  __shared__ int s_wave[4];
+  __shared__ uint32_t s_pref;
+  __shared__ int s_rem;
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  uint32_t prefix;
+  int rem;
+  topk_resolve(ws, pass, k, prefix, rem, s_wave, &s_pref, &s_rem);
+  (void)rem;
+  __syncthreads();                                 // the zeroed histogram (pass 0 resolves nothing and has no barrier)
+  const int shift = 24 - 8 * pass;
+  const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+  const int base = blockIdx.x * TK_CHUNK;
+  uint32_t keys[TK_ITEMS];
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    const int i = base + j * TK_T + tid;
+    keys[j] = i < n ? float_key(score[i]) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    const int i = base + j * TK_T + tid;
+    const uint32_t key = keys[j];
+    bool act = i < n && (key & hi_mask) == prefix;
+    const unsigned digit = (key >> shift) & 255u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {               // a wave's most common digits are counted by ballot (see the one-workgroup form)
+      const unsigned long long remb = __ballot(act);
+      if (!remb) break;
+      const int l = __ffsll((long long)remb) - 1;
+      const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)digit, l);
+      const unsigned long long same = __ballot(act && digit == d0);
+      if ((int)(tid & 63) == l) atomicAdd(&hist[d0], __popcll(same));
+      if (digit == d0) act = false;
+    }
+    if (act) atomicAdd(&hist[digit], 1);
+  }
+  __syncthreads();
+  const int c = hist[tid];
+  if (c) atomicAdd(&ws[pass * 256 + tid], c);
+}
+
+__global__ __launch_bounds__(TK_T) void topk_count_kernel(const float *__restrict__ score, int n, int k, int *__restrict__ ws) {
+  __shared__ int s_wave[4];
+  __shared__ uint32_t s_pref;
+  __shared__ int s_rem;
+  __shared__ int s_cnt[2];
+  const int tid = threadIdx.x;
+  if (tid < 2) s_cnt[tid] = 0;
+  uint32_t thr;
+  int need_eq;
+  topk_resolve(ws, 4, k, thr, need_eq, s_wave, &s_pref, &s_rem);
+  (void)need_eq;
+  const int base = blockIdx.x * TK_CHUNK;
+  int gt = 0, eq = 0;
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    const int i = base + j * TK_T + tid;
+    if (i < n) {
+      const uint32_t key = float_key(score[i]);
+      gt += key > thr;
+      eq += key == thr;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { gt += __shfl_xor(gt, o); eq += __shfl_xor(eq, o); }
+  if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], gt); atomicAdd(&s_cnt[1], eq); }
+  __syncthreads();
+  if (tid < 2) ws[4 * 256 + blockIdx.x * 2 + tid] = s_cnt[tid];
+}
+
+__global__ __launch_bounds__(TK_T) void topk_compact_kernel(const float *__restrict__ score, int n, int k, const int *__restrict__ ws,
+                                                            int64_t *__restrict__ idx_out, int64_t *__restrict__ valid_out,
+                                                            float *__restrict__ mask_out) {
+  __shared__ int s_wave[4];
+  __shared__ uint32_t s_pref;
+  __shared__ int s_rem;
+  __shared__ int s_before[2];
+  __shared__ int wave_cnt[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid < 2) s_before[tid] = 0;
+  uint32_t thr;
+  int need_eq;
+  topk_resolve(ws, 4, k, thr, need_eq, s_wave, &s_pref, &s_rem);
+  // candidates above / equal to the cut in the workgroups before this one
+  int gtb = 0, eqb = 0;
+  for (int w = tid; w < (int)blockIdx.x; w += TK_T) { gtb += ws[4 * 256 + 2 * w]; eqb += ws[4 * 256 + 2 * w + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { gtb += __shfl_xor(gtb, o); eqb += __shfl_xor(eqb, o); }
+  if (lane == 0) { atomicAdd(&s_before[0], gtb); atomicAdd(&s_before[1], eqb); }
+  __syncthreads();
+  int eq_base = s_before[1];
+  int out_base = s_before[0] + min(eq_base, need_eq);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int base = blockIdx.x * TK_CHUNK;
+  int parity = 0;
+#pragma unroll 1
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    if (base + j * TK_T >= n) break;                          // block-uniform
+    const int i = base + j * TK_T + tid;
+    const uint32_t key = i < n ? float_key(score[i]) : 0u;
+    const bool is_gt = i < n && key > thr, is_eq = i < n && key == thr;
+    const unsigned long long bg = __ballot(is_gt), be = __ballot(is_eq);
+    if (lane == 0) wave_cnt[parity][wid] = (__popcll(bg) << 16) | __popcll(be);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = wave_cnt[parity][w];
+      if (w < wid) before += c;
+      total += c;
+    }
+    parity ^= 1;
+    const int gt_before = (before >> 16) + __popcll(bg & lt);
+    const int eq_rank = eq_base + (before & 0xffff) + __popcll(be & lt);
+    const bool sel = is_gt || (is_eq && eq_rank < need_eq);
+    if (sel) idx_out[out_base + gt_before + min(eq_rank, need_eq) - min(eq_base, need_eq)] = i;
+    if (i < n) {
+      if (valid_out) valid_out[i] = sel;
+      if (mask_out) mask_out[i] = sel ? 1.f : 0.f;
+    }
+    const int eq_tot = total & 0xffff;
+    out_base += (total >> 16) + min(eq_base + eq_tot, need_eq) - min(eq_base, need_eq);
+    eq_base += eq_tot;
+  }
+}
+
 template <int VPL>     // C = 64 * VPL channels, VPL floats per lane
 __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float eps, float *__restrict__ y,
@@ -250,6 +423,28 @@ __global__ __launch_bounds__(256) void layer_norm_rows_generic_kernel(const floa
 }  // namespace sgc
 
 using namespace sgc;
+
+namespace sgc { int g_tune_topk_multi_min = 16384; }   // candidate sets of at least this size use the many-workgroup form when a workspace is given
+
+extern "C" int64_t sgc_topk_select_workspace_bytes(int n) {
+  return n > 0 ? (int64_t)(4 * 256 + 2 * ceil_div(n, TK_CHUNK)) * (int64_t)sizeof(int) : 0;
+}
+
+extern "C" int sgc_topk_select_ws(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null, float *mask_or_null,
+                                  void *workspace_or_null, int64_t workspace_bytes, sgc_stream_t stream) {
+  if (!score || !idx_out) return set_error(SGC_EINVAL, "sgc_topk_select: null pointer");
+  if (n <= 0 || k <= 0 || k > n) return set_error(SGC_EINVAL, "sgc_topk_select: need 0 < k <= n (k = %d, n = %d)", k, n);
+  if (!workspace_or_null || workspace_bytes < sgc_topk_select_workspace_bytes(n) || n < g_tune_topk_multi_min)
+    return sgc_topk_select(score, n, k, idx_out, valid_or_null, mask_or_null, stream);
+  hipStream_t st = (hipStream_t)stream;
+  int *ws = reinterpret_cast<int *>(workspace_or_null);
+  const int G = ceil_div(n, TK_CHUNK);
+  hipLaunchKernelGGL(topk_init_kernel, dim3(4), dim3(256), 0, st, ws, 4 * 256 + 2 * G);
+  for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(topk_hist_kernel, dim3(G), dim3(TK_T), 0, st, score, n, k, pass, ws);
+  hipLaunchKernelGGL(topk_count_kernel, dim3(G), dim3(TK_T), 0, st, score, n, k, ws);
+  hipLaunchKernelGGL(topk_compact_kernel, dim3(G), dim3(TK_T), 0, st, score, n, k, ws, idx_out, valid_or_null, mask_or_null);
+  return check_launch("topk_compact_kernel");
+}
 
 extern "C" int sgc_topk_select(const float *score, int n, int k, int64_t *idx_out, int64_t *valid_or_null,
                                float *mask_or_null, sgc_stream_t stream) {

@@ -589,7 +589,9 @@ class TensorOps:
         idx = torch.empty(k, dtype=torch.int64, device=dev)
         valid = torch.empty(n, dtype=torch.int64, device=dev) if want_valid else None
         mask = torch.empty(n, dtype=torch.float32, device=dev) if want_mask else None
-        self._call("sgc_topk_select", flat, n, int(k), idx, valid, mask)
+        wsb = int(self.lib._dll.sgc_topk_select_workspace_bytes(n))
+        ws = torch.empty(max(wsb, 4) // 4, dtype=torch.int32, device=dev) if wsb > 0 else None   # many-workgroup form for large n
+        self._call("sgc_topk_select_ws", flat, n, int(k), idx, valid, mask, ws, wsb)
         return idx, valid, mask
 
     def layer_norm_rows(self, x, gamma, beta, eps=1e-5, count=None, out=None):

@@ -659,3 +659,28 @@ def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
     gg = gpu_ops.dfa3d_backward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(item), cu(go))
     for a, b in zip(gg, gc):
         close(a, b, tol=2e-5)
+
+
+@pytest.mark.parametrize("n,k", [(204800, 51200), (294912, 73728), (25600, 6400), (16385, 1), (20000, 20000), (40961, 40960)])
+def test_topk_many_workgroup_form_equals_the_one_workgroup_form(n, k, gpu_ops):
+    """sgc_topk_select_ws (histogram / count / compaction launches over 4096-candidate chunks) against the one-workgroup
+    kernel: indices, valid and mask bit-exact -- random scores, heavy exact ties at the cut, all-equal scores, NaNs and
+    infinities, chunk-boundary sizes; repeated to catch an ordering problem between the launches."""
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.sigmoid(torch.randn(n, generator=g))
+    tied = s.clone()
+    tied[torch.randperm(n, generator=g)[: int(0.4 * n)]] = float(s.sort(descending=True).values[min(k, n - 1)])
+    special = torch.randn(n, generator=g)
+    special[::97] = float("nan"); special[5::131] = float("inf"); special[7::113] = float("-inf"); special[3::89] = 0.0; special[4::89] = -0.0
+    for scores in (s, tied, torch.full((n,), 0.25), special):
+        x = scores.cuda()
+        try:
+            gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 1 << 30)         # one workgroup
+            ref = gpu_ops.topk_select(x, k, want_valid=True, want_mask=True)
+            gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 1)               # many workgroups
+            for _ in range(3):
+                got = gpu_ops.topk_select(x, k, want_valid=True, want_mask=True)
+                for a, b in zip(got, ref):
+                    assert torch.equal(a, b)
+        finally:
+            gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 16384)
