@@ -228,6 +228,56 @@ class ChannelsLastConvTranspose3dFunction(Function):
         return dx, dw, None
 
 
+class LinearRowsFunction(Function):
+    """``nn.Linear`` over a row list with all three passes on the MFMA kernels (training path of the view transform:
+    value_proj / sampling_offsets / attention_weights / output_proj, TU/deformable_cross_attention.py:417-436,826): forward
+    and input gradient on ``sgc_linear_rows_bf16x3`` (the latter with W^T), weight gradient on ``sgc_conv3d_wgrad_bf16x3``
+    with ksize 1 (the rows are its "voxels").  x [rows, Cin] (Cin % 32 == 0), weight [Cout, Cin], bias [Cout] | None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ops = ext.ops()
+        cout, cin = weight.shape
+        x = x.float().contiguous()
+        wp = _pad_cols(weight.detach().float().t(), 4).t().contiguous()                 # Cout padded to a multiple of 4
+        hi, lo = ops.split_bf16(wp.view(1, wp.shape[0], cin))
+        shift = None if bias is None else _pad_cols(bias.detach().float().view(1, -1), 4).view(-1).contiguous()
+        y = ops.linear_rows_bf16x3(x, hi, lo, shift)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y if y.shape[1] == cout else y[:, :cout]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ops = ext.ops()
+        x, weight = ctx.saved_tensors
+        cout, cin = weight.shape
+        dy = dy.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = _pad_cols(weight.detach().float().t().contiguous(), 32)               # [Cin, Cout -> mult of 32]: dx = dy @ W
+            hi, lo = ops.split_bf16(wt.view(1, cin, wt.shape[1]).contiguous())
+            dx = ops.linear_rows_bf16x3(_pad_cols(dy, 32).contiguous(), hi, lo, None)
+        if ctx.needs_input_grad[1]:
+            dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), (x.shape[0], 1, 1), 1, 1)     # [1, cout_p, cin]
+            dw = dwk[0, :cout].to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def linear_rows(module, x):
+    """``module(x)`` for an ``nn.Linear`` with the passes on the HIP kernels when the shapes allow (CUDA fp32, in_features %
+    32 == 0, at least a tile of rows); any leading shape."""
+    from .plugin.conv_plan import TRAIN_CONV
+    if (TRAIN_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or module.in_features % 32
+            or x.numel() // max(1, module.in_features) < 128):
+        return module(x)
+    y = LinearRowsFunction.apply(x.reshape(-1, module.in_features), module.weight, module.bias)
+    return y.reshape(*x.shape[:-1], module.out_features)
+
+
 # the DFA3D package spells them without the suffix (dfa3D/ops/multi_scale_3D_deform_attn.py:22,67,146)
 MultiScale3DDeformableAttnFunction = MultiScale3DDeformableAttnFunction_fp32
 MultiScaleDepthScoreSampleFunction = MultiScaleDepthScoreSampleFunction_fp32

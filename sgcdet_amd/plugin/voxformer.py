@@ -356,10 +356,11 @@ class DeformCrossAttention_DFA3D(BaseModule):
                                                if L > 1 else ref.view(n_pairs, 1, 1, 1, 3),
                                                torch.ones((n_pairs, 1, L, 1), dtype=feat.dtype, device=feat.device), item)
         if self.deformable_attn:
-            value = da.value_proj(feat).view(N, S, M, C // M)
-            off_uv = da.sampling_offsets(geo).view(n_pairs, M, L, P, 2)
-            off_d = da.sampling_offsets_depth(geo).view(n_pairs, M, L, P, 1)
-            attn = da.attention_weights(geo).view(n_pairs, M, L * P).softmax(-1).view(n_pairs, M, L, P)
+            from ..functions import linear_rows                    # the Linears' three passes on the MFMA kernels
+            value = linear_rows(da.value_proj, feat).view(N, S, M, C // M)
+            off_uv = linear_rows(da.sampling_offsets, geo).view(n_pairs, M, L, P, 2)
+            off_d = linear_rows(da.sampling_offsets_depth, geo).view(n_pairs, M, L, P, 1)
+            attn = linear_rows(da.attention_weights, geo).view(n_pairs, M, L * P).softmax(-1).view(n_pairs, M, L, P)
             normalizer = torch.stack([shapes3[..., 1], shapes3[..., 0], shapes3[..., 2]], -1).to(feat.dtype)   # (W, H, D) per level
             loc = ref.view(n_pairs, 1, 1, 1, 3) + torch.cat([off_uv, off_d], -1) / normalizer[None, None, :, None, :]
             per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item)

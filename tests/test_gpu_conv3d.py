@@ -273,3 +273,29 @@ def test_conv2d_nhwc_matches_oracle_and_torch(N, H, W, cin, cout, k, relu, res, 
                                        None, 1, k // 2)
         y = y.permute(0, 2, 3, 1).reshape(-1, cout) * sc + sh
         assert float((got - y).abs().max()) < 1e-4 * max(1.0, float(y.abs().max()))
+
+
+@pytest.mark.parametrize("rows,cin,cout,bias", [(5000, 256, 256, True), (1237, 128, 96, True), (777, 64, 33, False)])
+def test_linear_rows_function_matches_torch_autograd(rows, cin, cout, bias, gpu_ops):
+    """LinearRowsFunction (forward / input gradient on sgc_linear_rows_bf16x3, weight gradient on the ksize-1 wgrad kernel)
+    against float64 autograd of F.linear; output widths that need padding to 4 / 32 columns included."""
+    from sgcdet_amd.functions import LinearRowsFunction
+    g = torch.Generator().manual_seed(rows + cout)
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.05
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(gy)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    y = LinearRowsFunction.apply(xg, wg, bg)
+    assert y.shape == (rows, cout)
+    assert float((y.detach().cpu() - yr.detach()).abs().max()) < 1e-4 * float(yr.abs().max())
+    y.backward(gy.float().cuda())
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-4 * float(xr.grad.abs().max())
+    assert float((wg.grad.cpu() - wr.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max())
+    if bias:
+        assert float((bg.grad.cpu() - br.grad).abs().max()) < 1e-4 * float(br.grad.abs().max())
