@@ -8,7 +8,8 @@
 //                     that order implementation-defined; voxels no camera sees carry bit-identical scores, so ties are
 //                     real) -- the same rule as the oracle, so both sides select the same voxels whenever their scores
 //                     agree bit for bit.  Replaces gatherTopK + 2 radix sorts + merges + scatter + 3 elementwise
-//                     kernels (~150 us per scene at config 2) by one launch.
+//                     kernels (~150 us per scene at config 2) by one launch; candidate sets of 16 384 scores or more go
+//                     through the many-workgroup form further down (same outputs).
 //   sgc_layer_norm_rows  nn.LayerNorm(C) over rows (the two norms of VoxFormerLayer, TU/encoder.py:311-338 via
 //                     build_norm_layer(dict(type='LN')), TU/custom_base_transformer_layer.py:153-156): one wave per
 //                     row, two-pass mean / biased variance in registers, rsqrt(var + eps), affine.
@@ -21,29 +22,6 @@ __device__ __forceinline__ uint32_t float_key(float f) {
   if (f != f) return 0xffffffffu;           // NaN: treated as the largest value (torch.topk does the same)
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-// exclusive block scan of one int per thread (1024 threads); returns (exclusive prefix, block total)
-__device__ __forceinline__ int block_scan_1024(int v, int *total, int *wave_sums) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) wave_sums[wid] = incl;
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    const int s = wave_sums[w];
-    if (w < wid) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + incl - v;
 }
 
 // KPT > 0: the workgroup keeps all keys in registers (n <= 1024 * KPT): ONE pass over global memory with every load of a
