@@ -309,6 +309,12 @@ int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
                     const int32_t *valid_index, float *ctx,
                     int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
                     sgc_stream_t stream);
+/* Its backward over the same pair list (training; the reference back-propagates through nn.MultiheadAttention on the
+ * dense [N, L, C] slots, :829-833): grad_ctx [n_valid,C] -> grad_q [n_valid,C] (w.r.t. the un-scaled q), grad_kv
+ * [n_pairs,2C] (k | v gradients per visible pair; every pair row is written exactly once).                          */
+int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slot, const int32_t *valid_index,
+                             const float *ctx, const float *grad_ctx, float *grad_q, float *grad_kv,
+                             int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 6. Volume glue

@@ -806,6 +806,58 @@ int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
   return SGC_OK;
 }
 
+/* backward of the view softmax above (double accumulation): see the header */
+int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slot, const int32_t *valid_index,
+                             const float *ctx, const float *grad_ctx, float *grad_q, float *grad_kv,
+                             int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+  (void)stream; (void)ctx;
+  if (!q || !kv || !slot || !valid_index || !grad_ctx || !grad_q || !grad_kv) return fail(SGC_EINVAL, "null pointer");
+  if (C % heads) return fail(SGC_EINVAL, "C % heads != 0");
+  const int hd = C / heads;
+  const double scale = sqrt(1.0 / (double)hd);
+#pragma omp parallel for schedule(dynamic)
+  for (int i = 0; i < n_valid; ++i) {
+    const int vq = valid_index[i];
+    for (int h = 0; h < heads; ++h) {
+      const float *qh = q + (int64_t)i * C + h * hd, *dc = grad_ctx + (int64_t)i * C + h * hd;
+      double d[256], a[256], mx = -INFINITY, sum = 0.0;
+      int ps[256], cnt = 0;
+      for (int n = 0; n < N && cnt < 256; ++n) {
+        const int32_t p = slot[(int64_t)n * Nq + vq];
+        if (p < 0) continue;
+        const float *k = kv + (int64_t)p * 2 * C + h * hd;
+        double s = 0.0;
+        for (int c = 0; c < hd; ++c) s += (double)qh[c] * scale * (double)k[c];
+        d[cnt] = s; ps[cnt++] = p;
+        if (s > mx) mx = s;
+      }
+      for (int t = 0; t < cnt; ++t) { a[t] = exp(d[t] - mx); sum += a[t]; }
+      double S = 0.0;
+      for (int t = 0; t < cnt; ++t) {
+        a[t] /= sum;
+        const float *v = kv + (int64_t)ps[t] * 2 * C + C + h * hd;
+        double da = 0.0;
+        for (int c = 0; c < hd; ++c) da += (double)dc[c] * (double)v[c];
+        d[t] = da;                                   /* reuse: d[] now holds da_n */
+        S += a[t] * da;
+      }
+      float *gq = grad_q + (int64_t)i * C + h * hd;
+      for (int c = 0; c < hd; ++c) gq[c] = 0.f;
+      for (int t = 0; t < cnt; ++t) {
+        const double ds = a[t] * (d[t] - S);
+        const float *k = kv + (int64_t)ps[t] * 2 * C + h * hd;
+        float *gk = grad_kv + (int64_t)ps[t] * 2 * C + h * hd;
+        for (int c = 0; c < hd; ++c) {
+          gq[c] += (float)(ds * (double)k[c] * scale);
+          gk[c] = (float)(ds * (double)qh[c] * scale);
+          gk[C + c] = (float)(a[t] * (double)dc[c]);
+        }
+      }
+    }
+  }
+  return SGC_OK;
+}
+
 /* ---- 6. volume glue ------------------------------------------------------------ */
 int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,
                      float *vol, const int32_t *n_dev_or_null, int n, int C, sgc_stream_t stream) {

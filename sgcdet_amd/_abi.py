@@ -32,6 +32,7 @@ SIGNATURES = {
     "sgc_tile_window": [_i] * 12 + [C.POINTER(C.c_int)] * 5,
     "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
+    "sgc_view_attend_backward": [_p] * 8 + [_i] * 5 + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 7 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],

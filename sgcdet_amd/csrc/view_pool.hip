@@ -119,6 +119,83 @@ __global__ __launch_bounds__(256) void view_attend_kernel(const float *__restric
   }
 }
 
+// Backward of view_attend_kernel (training over the pair list: no dense [N, L, C] slots, no full-size K/V projections --
+// the reference back-propagates through nn.MultiheadAttention on the padded slots, TU/deformable_cross_attention.py:829-833).
+// Same lane grouping as the forward: G lanes per (voxel, head).  With a_n the softmax weights, ctx = sum_n a_n v_n:
+//   S = <d_ctx, ctx>;  da_n = <d_ctx, v_n>;  ds_n = a_n (da_n - S);
+//   d_q = scale * sum_n ds_n k_n;  d_k_n = ds_n * scale * q;  d_v_n = a_n * d_ctx.
+// Every pair belongs to exactly one voxel, so grad_kv rows are written once, without atomics.
+template <int VEC>
+__global__ __launch_bounds__(256) void view_attend_backward_kernel(const float *__restrict__ q, const float *__restrict__ kv,
+                                                                   const int32_t *__restrict__ slot,
+                                                                   const int32_t *__restrict__ valid_index,
+                                                                   const float *__restrict__ ctx, const float *__restrict__ gctx,
+                                                                   float *__restrict__ gq, float *__restrict__ gkv, int N, int Nq,
+                                                                   int C, int heads, int n_valid, int G, float scale) {
+  const int hd = C / heads;
+  const int64_t total = (int64_t)n_valid * heads * G;
+  const int64_t span = (((int64_t)total + 63) / 64) * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < span; idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = idx < total;
+    const int64_t id = live ? idx : total - 1;
+    const int g = (int)(id % G);
+    const int h = (int)((id / G) % heads);
+    const int i = (int)(id / ((int64_t)G * heads));
+    const int vq = valid_index[i];
+    const int c0 = h * hd + g * VEC;
+    float qv[VEC], dc[VEC], dq[VEC];
+    float S = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      qv[v] = q[(int64_t)i * C + c0 + v] * scale;
+      dc[v] = gctx[(int64_t)i * C + c0 + v];
+      S += dc[v] * ctx[(int64_t)i * C + c0 + v];
+      dq[v] = 0.f;
+    }
+    for (int o = 1; o < G; o <<= 1) S += __shfl_xor(S, o);
+    float mx = -INFINITY, sum = 0.f;
+    for (int n = 0; n < N; ++n) {                      // pass 1: the softmax normalisation (as the forward computes it)
+      const int p = slot[(int64_t)n * Nq + vq];
+      if (p < 0) continue;
+      const float *kp = kv + (int64_t)p * 2 * C + c0;
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d += qv[v] * kp[v];
+      for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+      const float nm = fmaxf(mx, d);
+      sum = sum * expf(mx - nm) + expf(d - nm);
+      mx = nm;
+    }
+    for (int n = 0; n < N; ++n) {                      // pass 2: gradients
+      const int p = slot[(int64_t)n * Nq + vq];
+      if (p < 0) continue;
+      const float *kp = kv + (int64_t)p * 2 * C + c0;
+      float kx[VEC], vx[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { kx[v] = kp[v]; vx[v] = kp[C + v]; }
+      float d = 0.f, da = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { d += qv[v] * kx[v]; da += dc[v] * vx[v]; }
+      for (int o = 1; o < G; o <<= 1) { d += __shfl_xor(d, o); da += __shfl_xor(da, o); }
+      const float a = expf(d - mx) / sum;
+      const float ds = a * (da - S);
+      if (live) {
+        float *gp = gkv + (int64_t)p * 2 * C + c0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          dq[v] += ds * kx[v];
+          gp[v] = ds * qv[v];
+          gp[C + v] = a * dc[v];
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) gq[(int64_t)i * C + c0 + v] = dq[v] * scale;
+    }
+  }
+}
+
 __global__ void scatter_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ idx,
                                     const int32_t *__restrict__ idx2, float *__restrict__ vol, int n, int C, int VEC,
                                     const int32_t *__restrict__ n_dev) {
@@ -283,6 +360,28 @@ extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *s
     hipLaunchKernelGGL(view_attend_kernel<1>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
                        slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale, n_dev);
   return check_launch("view_attend_kernel");
+}
+
+extern "C" int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slot, const int32_t *valid_index,
+                                        const float *ctx, const float *grad_ctx, float *grad_q, float *grad_kv,
+                                        int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream) {
+  if (!q || !kv || !slot || !valid_index || !ctx || !grad_ctx || !grad_q || !grad_kv)
+    return set_error(SGC_EINVAL, "sgc_view_attend_backward: null pointer");
+  if (heads <= 0 || C % heads) return set_error(SGC_EINVAL, "sgc_view_attend_backward: C %% heads != 0");
+  if (n_valid <= 0) return SGC_OK;
+  const int hd = C / heads;
+  const float scale = sqrtf(1.0f / (float)hd);
+  int vec = 4, G = hd / 4;
+  if (hd % 4 || (G & (G - 1)) || G > 64) { vec = 1; G = hd; }
+  if ((G & (G - 1)) || G > 64) return set_error(SGC_EUNSUP, "sgc_view_attend_backward: head_dim %d not supported", hd);
+  const int64_t work = (int64_t)n_valid * heads * G;
+  if (vec == 4)
+    hipLaunchKernelGGL(view_attend_backward_kernel<4>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv, slot,
+                       valid_index, ctx, grad_ctx, grad_q, grad_kv, N, Nq, C, heads, n_valid, G, scale);
+  else
+    hipLaunchKernelGGL(view_attend_backward_kernel<1>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv, slot,
+                       valid_index, ctx, grad_ctx, grad_q, grad_kv, N, Nq, C, heads, n_valid, G, scale);
+  return check_launch("view_attend_backward_kernel");
 }
 
 extern "C" int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_or_null,

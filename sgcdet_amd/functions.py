@@ -278,6 +278,29 @@ def linear_rows(module, x):
     return y.reshape(*x.shape[:-1], module.out_features)
 
 
+class ViewAttendFunction(Function):
+    """Softmax over the views that see a voxel (``nn.MultiheadAttention`` with query length 1 and a key-padding mask,
+    TU/deformable_cross_attention.py:829-833) on the PAIR LIST, forward and backward: q [n_valid, C] (in-projected query of
+    every visible voxel), kv [n_pairs, 2C] (k | v in-projected per visible pair), slot [N, Nq] int32 (pair index or -1),
+    valid_index [n_valid] int32 -> ctx [n_valid, C] (before out_proj)."""
+
+    @staticmethod
+    def forward(ctx_, q, kv, slot, valid_index, heads):
+        ops = ext.ops()
+        q, kv = q.float().contiguous(), kv.float().contiguous()
+        out = ops.view_attend(q, kv, slot, valid_index, heads)
+        ctx_.save_for_backward(q, kv, slot, valid_index, out)
+        ctx_.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx_, grad_out):
+        q, kv, slot, valid_index, out = ctx_.saved_tensors
+        gq, gkv = ext.ops().view_attend_backward(q, kv, slot, valid_index, ctx_.heads, out, grad_out.float().contiguous())
+        return gq, gkv, None, None, None
+
+
 # the DFA3D package spells them without the suffix (dfa3D/ops/multi_scale_3D_deform_attn.py:22,67,146)
 MultiScale3DDeformableAttnFunction = MultiScale3DDeformableAttnFunction_fp32
 MultiScaleDepthScoreSampleFunction = MultiScaleDepthScoreSampleFunction_fp32

@@ -366,16 +366,36 @@ class DeformCrossAttention_DFA3D(BaseModule):
             per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item)
         else:
             per_pair = geo
-        slots = torch.zeros((N, Nq, C), dtype=feat.dtype, device=feat.device).index_put((cam, q), per_pair)
         count = mask.sum(0)
         valid_index = count.nonzero()[:, 0]
-        valid_slots = slots[:, valid_index]                                # [N,L,C]
-        valid_mask = mask[:, valid_index]                                  # [N,L]
-        pooled = (valid_slots * valid_mask[..., None]).sum(0) / count[valid_index][:, None]
-        pooled = self.output_proj(pooled)
-        if self.inter_view_aggregation == "attn":
-            pooled, _ = self.attention_pooling(pooled[None], valid_slots, valid_slots, ~valid_mask.t())
-            pooled = pooled[0]
+        from .conv_plan import TRAIN_CONV
+        if TRAIN_CONV == "hip" and C % 32 == 0:
+            # inter-view aggregation on the pair list as well: no dense [N, L, C] slots (262 MB at config 2), K/V in-projected
+            # for visible pairs only, the softmax over views and its backward on sgc_view_attend(_backward)
+            from ..functions import LinearRowsFunction, ViewAttendFunction, linear_rows
+            n_valid = valid_index.shape[0]
+            slot = torch.full((N, Nq), -1, dtype=torch.int32, device=feat.device)
+            slot[cam, q] = torch.arange(n_pairs, dtype=torch.int32, device=feat.device)
+            row_of = torch.full((Nq,), -1, dtype=torch.int64, device=feat.device)
+            row_of[valid_index] = torch.arange(n_valid, device=feat.device)
+            mean = torch.zeros((n_valid, C), dtype=per_pair.dtype, device=feat.device).index_add(0, row_of[q], per_pair)
+            pooled = linear_rows(self.output_proj, mean / count[valid_index][:, None])
+            if self.inter_view_aggregation == "attn":
+                mha = self.attention_pooling
+                w, b = mha.in_proj_weight, mha.in_proj_bias
+                qv = LinearRowsFunction.apply(pooled, w[:C], b[:C])
+                kv = LinearRowsFunction.apply(per_pair, w[C:], b[C:])                  # [n_pairs, 2C] = k | v
+                ctx = ViewAttendFunction.apply(qv, kv, slot, valid_index.to(torch.int32), mha.num_heads)
+                pooled = LinearRowsFunction.apply(ctx, mha.out_proj.weight, mha.out_proj.bias)
+        else:
+            slots = torch.zeros((N, Nq, C), dtype=feat.dtype, device=feat.device).index_put((cam, q), per_pair)
+            valid_slots = slots[:, valid_index]                                # [N,L,C]
+            valid_mask = mask[:, valid_index]                                  # [N,L]
+            pooled = (valid_slots * valid_mask[..., None]).sum(0) / count[valid_index][:, None]
+            pooled = self.output_proj(pooled)
+            if self.inter_view_aggregation == "attn":
+                pooled, _ = self.attention_pooling(pooled[None], valid_slots, valid_slots, ~valid_mask.t())
+                pooled = pooled[0]
         out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
         out = out.index_put((torch.zeros_like(valid_index), valid_index), pooled)
         return self.dropout(out) + query

@@ -410,6 +410,19 @@ class TensorOps:
         self._call("sgc_view_mean", feat, slot, valid_index, mean, N, Nq, Cc, count, n_valid)
         return mean
 
+    def view_attend_backward(self, q, kv, slot, valid_index, heads, ctx, grad_ctx):
+        """(grad_q [n_valid, C], grad_kv [n_pairs, 2C]) of ``view_attend`` (``sgc_view_attend_backward``)."""
+        self._check(q=q, kv=kv, slot=slot, valid_index=valid_index, ctx=ctx, grad_ctx=grad_ctx)
+        self._f32(q=q, kv=kv, ctx=ctx, grad_ctx=grad_ctx)
+        self._i32(slot=slot, valid_index=valid_index)
+        N, Nq = slot.shape
+        n_valid, Cc = q.shape
+        gq = torch.zeros_like(q)
+        gkv = torch.zeros_like(kv)
+        if n_valid:
+            self._call("sgc_view_attend_backward", q, kv, slot, valid_index, ctx, grad_ctx, gq, gkv, N, Nq, Cc, heads, n_valid)
+        return gq, gkv
+
     def view_attend(self, q, kv, slot, valid_index, heads, count=None):
         self._check(q=q, kv=kv, slot=slot, valid_index=valid_index, count=count)
         self._f32(q=q, kv=kv)

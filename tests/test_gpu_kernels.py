@@ -35,6 +35,10 @@ def make_inputs(shape, seed, dev="cpu"):
     return {k: v.to(dev) for k, v in t.items()}
 
 
+def max_abs(t):
+    return float(t.detach().abs().max())
+
+
 def close(a, b, tol=1e-5):
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
@@ -684,3 +688,45 @@ def test_topk_many_workgroup_form_equals_the_one_workgroup_form(n, k, gpu_ops):
                     assert torch.equal(a, b)
         finally:
             gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 16384)
+
+
+def test_view_attend_backward_matches_oracle_and_multihead_attention(oracle_ops, gpu_ops):
+    """sgc_view_attend_backward / ViewAttendFunction: against the double-accumulating oracle, and against autograd through
+    nn.MultiheadAttention on the dense [N, L, C] slots with the key-padding mask (the reference's formulation,
+    TU/deformable_cross_attention.py:829-833) including the in-/out-projection weights."""
+    from sgcdet_amd.functions import ViewAttendFunction
+    g = torch.Generator().manual_seed(3)
+    N, Nq, C, heads = 6, 50, 64, 8
+    mask = torch.rand(N, Nq, generator=g) < 0.45
+    mask[:, 7] = False                                                     # a voxel no camera sees
+    mask[2, 9] = True
+    cam, qi = mask.nonzero(as_tuple=True)
+    n_pairs = cam.shape[0]
+    slot = torch.full((N, Nq), -1, dtype=torch.int32)
+    slot[cam, qi] = torch.arange(n_pairs, dtype=torch.int32)
+    valid_index = mask.sum(0).nonzero()[:, 0]
+    n_valid = valid_index.shape[0]
+    q = torch.randn(n_valid, C, generator=g)
+    kv = torch.randn(n_pairs, 2 * C, generator=g)
+    gout = torch.randn(n_valid, C, generator=g)
+    ctx_c = oracle_ops.view_attend(q, kv, slot, valid_index.int(), heads)
+    gq_c, gkv_c = oracle_ops.view_attend_backward(q, kv, slot, valid_index.int(), heads, ctx_c, gout)
+    qg, kvg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    ctx_g = ViewAttendFunction.apply(qg, kvg, slot.cuda(), valid_index.int().cuda(), heads)
+    ctx_g.backward(gout.cuda())
+    assert max_abs(ctx_g.detach().cpu() - ctx_c) < 1e-5
+    assert max_abs(qg.grad.cpu() - gq_c) < 2e-5 * max(1.0, float(gq_c.abs().max()))
+    assert max_abs(kvg.grad.cpu() - gkv_c) < 2e-5 * max(1.0, float(gkv_c.abs().max()))
+    # the reference's formulation: MHA over dense slots, identity projections folded out by feeding projected tensors
+    mha = torch.nn.MultiheadAttention(C, heads).double()
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.eye(C).repeat(3, 1)); mha.in_proj_bias.zero_()
+        mha.out_proj.weight.copy_(torch.eye(C)); mha.out_proj.bias.zero_()
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    k_slots = torch.zeros(N, Nq, C, dtype=torch.float64).index_put((cam, qi), kvd[:, :C])[:, valid_index]
+    v_slots = torch.zeros(N, Nq, C, dtype=torch.float64).index_put((cam, qi), kvd[:, C:])[:, valid_index]
+    out, _ = mha(qd[None], k_slots, v_slots, key_padding_mask=~mask[:, valid_index].t())
+    out[0].backward(gout.double())
+    assert max_abs(ctx_g.detach().cpu().double() - out[0].detach()) < 1e-5
+    assert max_abs(qg.grad.cpu().double() - qd.grad) < 2e-5 * max(1.0, float(qd.grad.abs().max()))
+    assert max_abs(kvg.grad.cpu().double() - kvd.grad) < 2e-5 * max(1.0, float(kvd.grad.abs().max()))

@@ -110,3 +110,37 @@ def test_tiled_gather_restatement_equals_the_plain_pair_list_form(oracle_ops):
         got = oracle_ops.pairs_deform_gather_tiled(value_to_headmajor(value), dist, binned["pair_ref"], binned["bin_offset"],
                                                    raw_to_headmajor(raw_new, M, P), H, W, P, bw, bh, 2, 2)
         assert torch.equal(got[:n_pairs], want[old])
+
+
+def test_oracle_view_attend_backward_is_multihead_attention_autograd():
+    """oracle sgc_view_attend / sgc_view_attend_backward over the pair list == nn.MultiheadAttention (query length 1, dense
+    [N, L, C] key / value slots, key_padding_mask for the cameras that do not see the voxel) and its autograd in float64."""
+    import torch
+    import oracle
+    oracle.build()
+    ops = oracle.ops()
+    g = torch.Generator().manual_seed(3)
+    N, Nq, C, heads = 6, 50, 64, 8
+    mask = torch.rand(N, Nq, generator=g) < 0.45
+    mask[:, 7] = False
+    cam, qi = mask.nonzero(as_tuple=True)
+    n_pairs = cam.shape[0]
+    slot = torch.full((N, Nq), -1, dtype=torch.int32)
+    slot[cam, qi] = torch.arange(n_pairs, dtype=torch.int32)
+    valid_index = mask.sum(0).nonzero()[:, 0]
+    q = torch.randn(valid_index.shape[0], C, generator=g)
+    kv = torch.randn(n_pairs, 2 * C, generator=g)
+    gout = torch.randn(valid_index.shape[0], C, generator=g)
+    ctx = ops.view_attend(q, kv, slot, valid_index.int(), heads)
+    gq, gkv = ops.view_attend_backward(q, kv, slot, valid_index.int(), heads, ctx, gout)
+    mha = torch.nn.MultiheadAttention(C, heads).double()
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.eye(C).repeat(3, 1)); mha.in_proj_bias.zero_()
+        mha.out_proj.weight.copy_(torch.eye(C)); mha.out_proj.bias.zero_()
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    ks = torch.zeros(N, Nq, C, dtype=torch.float64).index_put((cam, qi), kvd[:, :C])[:, valid_index]
+    vs = torch.zeros(N, Nq, C, dtype=torch.float64).index_put((cam, qi), kvd[:, C:])[:, valid_index]
+    out, _ = mha(qd[None], ks, vs, key_padding_mask=~mask[:, valid_index].t())
+    out[0].backward(gout.double())
+    assert (ctx.double() - out[0].detach()).abs().max() < 2e-6
+    assert (gq.double() - qd.grad).abs().max() < 2e-6 and (gkv.double() - kvd.grad).abs().max() < 2e-6
