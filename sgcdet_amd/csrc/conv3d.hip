@@ -32,6 +32,7 @@ namespace sgc {
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
+int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
 int g_tune_halo_ring = 1;         // halo kernel: 1 weights by LDS-DMA into a 3-stage ring, 0 staged through registers (round-1 form)
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
@@ -1304,7 +1305,12 @@ struct WgradParams {
   int OV, ksteps, splits, steps_per_split;
 };
 
-__global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradParams p) {
+// WM = 2: 4 waves (2 x 2, 64 x 64 each), every thread stages one block of BOTH operands; WM = 4: 8 waves (4 x 2, 32 x 64 each),
+// threads 0-255 stage the dy tile and 256-511 the x tile (half the loads, conversions and registers per thread, twice the
+// waves to hide them).
+template <int WM>
+__global__ __launch_bounds__(WM * 128) void conv3d_wgrad_bf16x3_kernel(const WgradParams p) {
+  constexpr int TMW = 4 / WM * 1;                           // 32-row tiles per wave along M: 2 (WM = 2) or 1 (WM = 4)
   constexpr int BMW = 128, BNW = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
   constexpr int PLANE = 128 * LDKH, BUF = 4 * PLANE;        // per buffer: A_hi, A_lo, B_hi, B_lo of [128][LDKH]
@@ -1317,8 +1323,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradPar
   int dx = 0, dy_ = 0, dz = 0;
   if (p.ksize > 1) { dx = tap / (p.ksize * p.ksize); dy_ = (tap / p.ksize) % p.ksize; dz = tap % p.ksize; }
 
-  const int kb = tid & 7, cb = tid >> 3;                    // this thread's block: voxels 4 kb .. + 3 of the step, channels 4 cb .. + 3
-  const bool a_ok = co0 + 4 * cb < p.Cout, b_ok = ci0 + 4 * cb < p.Cin;
+  const int role = WM == 4 ? (tid >> 8) : 2;                // 0: stages dy, 1: stages x, 2: both
+  const int kb = tid & 7, cb = (tid & 255) >> 3;            // this thread's block: voxels 4 kb .. + 3 of the step, channels 4 cb .. + 3
+  const bool a_ok = role != 1 && co0 + 4 * cb < p.Cout, b_ok = role != 0 && ci0 + 4 * cb < p.Cin;
   float4 ra[4], rb[4];
   auto load_step = [&](int s) {
 #pragma unroll
@@ -1354,13 +1361,13 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradPar
   };
   auto store_step = [&](int buf) {
     __bf16 *a_hi = base + buf * BUF;
-    store_block(ra, a_hi, a_hi + PLANE);
-    store_block(rb, a_hi + 2 * PLANE, a_hi + 3 * PLANE);
+    if (role != 1) store_block(ra, a_hi, a_hi + PLANE);
+    if (role != 0) store_block(rb, a_hi + 2 * PLANE, a_hi + 3 * PLANE);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TMW][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1374,22 +1381,25 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradPar
     for (int s = s_lo; s < s_hi; ++s) {
       const int buf = (s - s_lo) & 1;
       if (s + 1 < s_hi) load_step(s + 1);
-      const __bf16 *a_hi = base + buf * BUF + (wm * 64 + fr) * LDKH + fh * 8;
+      const __bf16 *a_hi = base + buf * BUF + (wm * (32 * TMW) + fr) * LDKH + fh * 8;
       const __bf16 *a_lo = a_hi + PLANE;
       const __bf16 *b_hi = base + buf * BUF + 2 * PLANE + (wn * 64 + fr) * LDKH + fh * 8;
       const __bf16 *b_lo = b_hi + PLANE;
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TMW; ++i) {
           ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + i * 32 * LDKH + kk * 16);
           al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + i * 32 * LDKH + kk * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
           bh[i] = *reinterpret_cast<const bf16x8 *>(b_hi + i * 32 * LDKH + kk * 16);
           bl[i] = *reinterpret_cast<const bf16x8 *>(b_lo + i * 32 * LDKH + kk * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
@@ -1405,14 +1415,14 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_bf16x3_kernel(const WgradPar
   // contiguous bytes of one dW row
   float *out = p.out + ((int64_t)split * p.taps + tap) * p.Cout * p.Cin;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ci = ci0 + wn * 64 + j * 32 + (lane & 31);
       if (ci >= p.Cin) continue;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int co = co0 + wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wm * (32 * TMW) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
         if (co < p.Cout) out[(int64_t)co * p.Cin + ci] = acc[i][j][k];
       }
     }
@@ -1478,8 +1488,12 @@ extern "C" int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *d
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = (size_t)2 * 4 * 128 * LDKH * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_wgrad_bf16x3_kernel, (int)smem, attr_done);
-  hipLaunchKernelGGL(conv3d_wgrad_bf16x3_kernel, dim3(ceil_div(Cout, 128), ceil_div(Cin, 128), p.taps * p.splits), dim3(256), smem, st, p);
+  static std::atomic<uint64_t> attr_done8{0};
+  ensure_dynamic_lds((const void *)conv3d_wgrad_bf16x3_kernel<2>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_wgrad_bf16x3_kernel<4>, (int)smem, attr_done8);
+  const dim3 wgrid(ceil_div(Cout, 128), ceil_div(Cin, 128), p.taps * p.splits);
+  if (g_tune_wgrad_waves == 8) hipLaunchKernelGGL(conv3d_wgrad_bf16x3_kernel<4>, wgrid, dim3(512), smem, st, p);
+  else hipLaunchKernelGGL(conv3d_wgrad_bf16x3_kernel<2>, wgrid, dim3(256), smem, st, p);
   rc = check_launch("conv3d_wgrad_bf16x3_kernel");
   if (rc) return rc;
   if (p.splits > 1) {
