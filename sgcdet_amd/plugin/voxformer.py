@@ -623,6 +623,18 @@ def _ffn_forward(ffn, x, identity=None):
             and lin1 is not None and isinstance(ffn.layers[0][1], nn.ReLU) and x.dtype == torch.float32
             and ffn.embed_dims % 32 == 0 and ffn.feedforward_channels % 32 == 0)
     if not fast:
+        from .conv_plan import TRAIN_CONV
+        if (torch.is_grad_enabled() and TRAIN_CONV == "hip" and x.is_cuda and x.dtype == torch.float32 and lin1 is not None
+                and ffn.num_fcs == 2 and ffn.embed_dims % 32 == 0 and ffn.feedforward_channels % 32 == 0):
+            # training: the two Linears (forward, input and weight gradients) on the MFMA kernels, the rest as the module does
+            from ..functions import linear_rows
+            out = linear_rows(lin1, x)
+            for m in list(ffn.layers[0])[1:]:
+                out = m(out)                              # activation, dropout
+            out = ffn.layers[2](linear_rows(ffn.layers[1], out))
+            if not ffn.add_identity:
+                return ffn.dropout_layer(out)
+            return (x if identity is None else identity) + ffn.dropout_layer(out)
         return ffn(x, identity)
     fp = module_fingerprint(ffn)
     plan = ffn.__dict__.get("_sgc_plan")
