@@ -58,13 +58,34 @@ def iou3d_pairwise(a, b):
     return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-8)
 
 
-def average_precision(recalls, precisions):
-    """area under the monotone envelope of the precision-recall curve (indoor_eval.py:8-53, mode 'area')"""
-    mrec = np.concatenate(([0.0], recalls, [1.0]))
-    mpre = np.concatenate(([0.0], precisions, [0.0]))
-    mpre = np.maximum.accumulate(mpre[::-1])[::-1]
-    step = np.where(mrec[1:] != mrec[:-1])[0]
-    return np.float32(np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1]))
+def average_precision(recalls, precisions, mode="area"):
+    """indoor_eval.py:8-53.  1-D inputs, mode 'area' (what ``indoor_eval`` uses): area under the monotone envelope of the
+    precision-recall curve, returned as a float32 scalar.  2-D inputs [num_scales, num_dets] give one value per scale as in
+    the reference; mode '11points' is restated with the reference's arithmetic, including its ``ap /= 11`` INSIDE the loop
+    over scales (scale i is divided num_scales - i times) -- the value its own known-answer test pins
+    (tests/test_metrics/test_indoor_eval.py:184-189: 8 / 121 for the first of two scales)."""
+    recalls, precisions = np.asarray(recalls), np.asarray(precisions)
+    one_d = recalls.ndim == 1
+    if one_d:
+        recalls, precisions = recalls[None], precisions[None]
+    assert recalls.shape == precisions.shape and recalls.ndim == 2
+    ap = np.zeros(recalls.shape[0], dtype=np.float32)
+    if mode == "area":
+        for i in range(recalls.shape[0]):
+            mrec = np.concatenate(([0.0], recalls[i], [1.0]))
+            mpre = np.concatenate(([0.0], precisions[i], [0.0]))
+            mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+            step = np.where(mrec[1:] != mrec[:-1])[0]
+            ap[i] = np.sum((mrec[step + 1] - mrec[step]) * mpre[step + 1])
+    elif mode == "11points":
+        for i in range(recalls.shape[0]):
+            for thr in np.arange(0, 1 + 1e-3, 0.1):
+                precs = precisions[i, recalls[i] >= thr]
+                ap[i] += precs.max() if precs.size > 0 else 0
+            ap /= 11
+    else:
+        raise ValueError('Unrecognized mode, only "area" and "11points" are supported')
+    return np.float32(ap[0]) if one_d else ap
 
 
 def eval_class(dets, gts, iou_thrs):
