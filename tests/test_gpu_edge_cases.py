@@ -121,3 +121,41 @@ def test_kernel_level_empty_and_outside(gpu_ops, oracle_ops):
     empty = gpu_ops.dfa3d_forward(feat.view(N, H * W, M, C // M), dist.view(N, H * W, 1, D), shapes3, lsi,
                                   torch.zeros(N, 0, M, 1, P, 3).cuda(), torch.zeros(N, 0, M, 1, P).cuda())[0]
     assert empty.shape == (N, 0, C)
+
+
+def test_round2_entry_points_on_degenerate_shapes(oracle_ops, gpu_ops):
+    """wgrad with fewer output voxels than one K-step, minimal channel counts and an odd stride-2 grid; the 2-D convolution on
+    1 x 1 images; the many-workgroup top-k at exact chunk multiples; the view-softmax backward with a single camera."""
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, grid, k, s in [(4, 4, (2, 3, 2), 3, 1), (32, 8, (7, 5, 3), 3, 2), (8, 12, (3, 1, 1), 1, 1), (16, 4, (2, 2, 2), 2, 2)]:
+        pad = 0 if k == 2 else k // 2
+        og = tuple((d + 2 * pad - k) // s + 1 for d in grid)
+        x = torch.randn(grid[0] * grid[1] * grid[2], cin, generator=g)
+        dy = torch.randn(og[0] * og[1] * og[2], cout, generator=g)
+        ref = oracle_ops.conv3d_wgrad_bf16x3(x, dy, grid, k, s)
+        got = gpu_ops.conv3d_wgrad_bf16x3(x.cuda(), dy.cuda(), grid, k, s).cpu()
+        assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), (cin, cout, grid, k, s)
+    x = torch.randn(5, 32, generator=g)                               # five 1 x 1 images
+    w = torch.randn(9, 4, 32, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    ref = oracle_ops.conv2d_nhwc_bf16x3(x, hi, lo, (5, 1, 1), 3)
+    got = gpu_ops.conv2d_nhwc_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), (5, 1, 1), 3).cpu()
+    assert float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 1)
+        for n, k in [(4096, 1), (8192, 8192), (12288, 4097), (1, 1)]:
+            s = torch.rand(n, generator=g)
+            s[: n // 2] = 0.5
+            a = gpu_ops.topk_select(s.cuda(), k, want_valid=True, want_mask=True)
+            b = oracle_ops.topk_select(s, k, want_valid=True, want_mask=True)
+            assert all(torch.equal(u.cpu(), v) for u, v in zip(a, b)), (n, k)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 16384)
+    N, Nq, C, heads = 1, 9, 32, 8                                     # one camera: softmax over one view, d_score = 0
+    slot = torch.arange(Nq, dtype=torch.int32).view(1, Nq)
+    vi = torch.arange(Nq, dtype=torch.int32)
+    q, kv, go = torch.randn(Nq, C, generator=g), torch.randn(Nq, 2 * C, generator=g), torch.randn(Nq, C, generator=g)
+    ctx = gpu_ops.view_attend(q.cuda(), kv.cuda(), slot.cuda(), vi.cuda(), heads)
+    gq, gkv = gpu_ops.view_attend_backward(q.cuda(), kv.cuda(), slot.cuda(), vi.cuda(), heads, ctx, go.cuda())
+    assert float(gq.abs().max()) < 1e-6 and float(gkv[:, :C].abs().max()) < 1e-6        # softmax of one score is constant
+    assert torch.allclose(gkv[:, C:].cpu(), go, atol=1e-6) and torch.allclose(ctx.cpu(), kv[:, C:], atol=1e-6)
