@@ -33,7 +33,10 @@ int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 t
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
-int g_tune_halo_ring = 1;         // halo kernel: 1 weights by LDS-DMA into a 3-stage ring, 0 staged through registers (round-1 form)
+int g_tune_halo_ring = 0;         // halo kernel: 0 weights staged through registers (default), 1 LDS-DMA ring on the 256 -> 256 layers,
+                                  // 2 ring everywhere.  Interleaved A/B, 8 rounds x 40 launches of the 90-GF layer on two boxes:
+                                  // staged 229.7 / 231.3 us, ring 237.2 / 238.1 us once the clocks have settled (the ring only wins the
+                                  // first, cold round: 264 vs 278 us) -- bit-identical, not faster under sustained load
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -1241,8 +1244,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   hipStream_t st = (hipStream_t)stream;
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
-    // ring form where it measured faster (the 256 -> 256 layers on the 4x4x16 brick: 293 -> 279 us; 3-7 % slower on the
-    // 512-channel / 128-column layers, whose split-K slices are short); halo_ring = 2 forces it everywhere
+    // ring form: an option (see g_tune_halo_ring); 1 = the 256 -> 256 layers on the 4x4x16 brick, 2 = everywhere
     const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && p.gz >= 16 && g_tune_halo_brick == 0 && Cout >= 256 && Cin <= 256)) &&
                       (int64_t)ix * iy * iz * Cin * 4 < 0x7fffffff;   // 32-bit buffer offsets
     if (p.gz >= 16 && g_tune_halo_brick == 0) rc = ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);

@@ -156,7 +156,7 @@ def test_halo_ring_form_is_bit_identical_to_the_staged_form(grid, cin, cout, rel
         ring_m, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=mask)
         assert torch.equal(ring_m, staged_m)
     finally:
-        gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 1)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_ring", 0)
         gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 2048)
 
 
