@@ -490,8 +490,8 @@ int g_tune_tile_diag = 0;
 int g_tune_tile_nbuf = 0;       // value-window buffers; 2 = the next head's window lands while the current head is computed
                                 // (needs heads-per-workgroup > 1).  auto: 1
 int g_tune_tile_xcd = 0;        // 1: camera n's workgroups on XCD n % 8 (head-major, bins innermost); 0: (camera, bin, head) order,
-                                // i.e. head h on XCD h.  Measured in one process: 106.8 / 109.1 vs 108.8 / 125.2 us (config 2), 463 vs
-                                // 437 us (config 4, depth in LDS), 503 vs 547 us (depth from global) -- no consistent gain: the 1.30x HBM
+                                // i.e. head h on XCD h.  Interleaved A/B in one process (5 / 4 alternations): config 2 102.3 vs 102.6 us
+                                // (no difference), config 4 with the depth window in LDS 385 vs 420 us (8 % SLOWER) -- the 1.30x HBM
                                 // overfetch (the depth maps through 8 L2s) is not what bounds the kernel
 int g_tune_tile_hg = 0;         // heads per workgroup.  auto: 1 (most workgroups: (camera, bin, head))
 
