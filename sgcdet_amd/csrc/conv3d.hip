@@ -33,6 +33,8 @@ int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 t
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
+int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
+                                  // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_ring = 0;         // halo kernel: 0 weights staged through registers (default), 1 LDS-DMA ring on the 256 -> 256 layers,
                                   // 2 ring everywhere.  Interleaved A/B, 8 rounds x 40 launches of the 90-GF layer on two boxes:
                                   // staged 229.7 / 231.3 us, ring 237.2 / 238.1 us once the clocks have settled (the ring only wins the
@@ -1198,7 +1200,7 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   const bool narrow = Cout <= 32;
   const int bn = narrow ? 32 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
-  p.splitk = pick_splitk(p, mb, nb, 512);   // >= 2 workgroups per CU
+  p.splitk = pick_splitk(p, mb, nb, g_tune_split_target);   // >= 2 workgroups per CU
   hipStream_t st = (hipStream_t)stream;
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
@@ -1256,7 +1258,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
-  p.splitk = pick_splitk(p, mb, nb, 512);
+  p.splitk = pick_splitk(p, mb, nb, g_tune_split_target);
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
     if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
@@ -1616,7 +1618,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     ConvParams p = {};
     p.transposed = transposed; p.taps = transposed ? 8 : ksize * ksize * ksize;
     const int bn = bf16x3 ? (Cout <= 64 ? 64 : 128) : (Cout <= 32 ? 32 : 128);
-    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), 512);
+    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target);
   }
   return splitk > 1 ? (int64_t)splitk * OV * Cout : 0;
 }
