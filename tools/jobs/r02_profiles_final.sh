@@ -7,7 +7,7 @@ cd $R
 timeout 900 python bench.py > gpurun_out/r02_bench_cfg2.json 2> gpurun_out/r02_bench_cfg2.err; echo bench rc $?
 timeout 600 python bench.py --workload cfg4_scannet200_large --no-cpu-baseline > gpurun_out/r02_bench_cfg4.json 2> gpurun_out/r02_bench_cfg4.err; echo bench4 rc $?
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r02 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-strict-fp32 --sustain 0 > $R/gpurun_out/r02_bench_cfg2_under_rocprof.json 2> $R/gpurun_out/r02_bench_under_rocprof.err; echo rocprof rc $?
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r02 -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-strict-fp32 --sustain 0 > $R/gpurun_out/r02_bench_cfg2_under_rocprof.json 2> $R/gpurun_out/r02_bench_under_rocprof.err; echo rocprof rc $?
 f=$(find /tmp/prof_r02 -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/r02_bench_cfg2_kernel_stats.csv
 t=$(find /tmp/prof_r02 -name "*kernel_trace.csv" | head -1)
 python3 - "$t" > $R/gpurun_out/r02_kernels_from_trace.json <<'PY'
