@@ -336,7 +336,7 @@ def main():
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with the other scenes in flight and runs 0-3 % longer, see "
-                         "profiles/r01_kernels_from_trace_v12.json)")
+                         "profiles/r02_kernels_from_trace.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
     self_check = None
