@@ -35,6 +35,7 @@ int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
+int g_tune_halo_narrow = 1;       // halo kernel: 64-column tiles for layers with <= 64 output channels
 int g_tune_halo_ring = 0;         // halo kernel: 0 weights staged through registers (default), 1 LDS-DMA ring on the 256 -> 256 layers,
                                   // 2 ring everywhere.  Interleaved A/B, 8 rounds x 40 launches of the 90-GF layer on two boxes:
                                   // staged 229.7 / 231.3 us, ring 237.2 / 238.1 us once the clocks have settled (the ring only wins the
@@ -560,11 +561,15 @@ __host__ __device__ constexpr size_t halo_tab_offset(int lrows, bool ring) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BX, int BY, int BZ, bool RING>
+// BNV: output columns per workgroup, 128 (wave tile 64 x 64) or 64 (wave tile 64 x 32: the head's 28 / 32-column layers, which
+// otherwise spend three quarters of their matrix work on padding columns).
+template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
+  static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
+  constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
-  constexpr int BNV = 128, NT = 512;
+  constexpr int NT = 512;
   constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
   constexpr int AP = RING ? HALO_AP : LDKH;          // bf16 per LDS row of the halo image
   constexpr int A_PLANE = LROWS * AP, B_PLANE = BNV * LDKH;
@@ -656,13 +661,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // {r, r+4, r+8, r+12} (16 banks apart at the 20-dword pitch) instead of 4 consecutive rows that overlap by 12 banks
   const int bc = tid & 3, rs16 = (tid >> 2) & 15;
   const int bn = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);
-  const bool bn_ok = n0 + bn < p.Cout;
+  const bool bn_ok = tid < BNV * 4 && n0 + bn < p.Cout;     // BNV * 4 sixteen-byte chunks per plane and tap
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
@@ -882,6 +887,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       }
     };
     auto store_B = [&](int buf) {
+      if (tid >= BNV * 4) return;
       __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
       *reinterpret_cast<uint4 *>(b) = rbh;
       *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
@@ -917,12 +923,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
-        const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * 64 + fr) * LDKH + fh * 8;
+        const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
         const __bf16 *bl_ = bh_ + B_PLANE;
         if (wave_live) {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 ah[2], al[2], bh[2], bl[2];
+          bf16x8 ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             if (kk == 0) {
@@ -934,14 +940,14 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             }
           }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < TN; ++j) {
             bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
             bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -969,10 +975,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          cs[(wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][k];
+          cs[(wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * WCOL + j * 32 + (lane & 31)] = acc[i][j][k];
     __syncthreads();
     constexpr int C4 = BNV / 4;
     for (int e = tid; e < 256 * C4; e += NT) {
@@ -1010,8 +1016,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WCOL + j * 32 + (lane & 31);
       if (col >= p.Cout) continue;
       const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
@@ -1073,14 +1079,14 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
-template <int BX, int BY, int BZ, bool RING>
+template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
   const size_t smem = halo_tab_offset(LROWS, RING) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
-  const int nb = ceil_div(p.Cout, 128);
+  const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
   const int splitk = halo_splitk(bricks, nb, nchunks);
   p.splitk = splitk;
@@ -1094,7 +1100,7 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
@@ -1249,9 +1255,13 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     // ring form: an option (see g_tune_halo_ring); 1 = the 256 -> 256 layers on the 4x4x16 brick, 2 = everywhere
     const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && p.gz >= 16 && g_tune_halo_brick == 0 && Cout >= 256 && Cin <= 256)) &&
                       (int64_t)ix * iy * iz * Cin * 4 < 0x7fffffff;   // 32-bit buffer offsets
-    if (p.gz >= 16 && g_tune_halo_brick == 0) rc = ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);
-    else if (p.gz >= 8 && g_tune_halo_brick != 2) rc = ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
-    else rc = ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
+    const bool narrow_n = g_tune_halo_narrow && Cout <= 64;          // 64-column tiles for the head's 28 / 32-column layers
+    if (p.gz >= 16 && g_tune_halo_brick == 0)
+      rc = narrow_n ? launch_halo<4, 4, 16, false, 64>(p, OV, st) : ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);
+    else if (p.gz >= 8 && g_tune_halo_brick != 2)
+      rc = narrow_n ? launch_halo<4, 8, 8, false, 64>(p, OV, st) : ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
+    else
+      rc = narrow_n ? launch_halo<8, 8, 4, false, 64>(p, OV, st) : ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
@@ -1613,7 +1623,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
   int splitk = 1;
   if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && M >= g_tune_halo_min_m) {
     const int bx = gz >= 16 ? 4 : (gz >= 8 ? 4 : 8), by = gz >= 16 ? 4 : 8, bz = gz >= 16 ? 16 : (gz >= 8 ? 8 : 4);
-    splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, 128), Cin / BK);
+    splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, (g_tune_halo_narrow && Cout <= 64) ? 64 : 128), Cin / BK);
   } else {
     ConvParams p = {};
     p.transposed = transposed; p.taps = transposed ? 8 : ksize * ksize * ksize;
