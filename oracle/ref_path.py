@@ -18,7 +18,6 @@ Restated (paths under /root/reference/mmdet3d_plugin/models/):
 Pinned by tests/golden/*.npz produced by running the reference's own Python for these
 modules in the build container (tests/golden/make_golden.py).
 """
-import math
 
 import torch
 import torch.nn.functional as F

@@ -16,7 +16,7 @@ CPU path.
 """
 import os
 
-import torch
+import torch  # noqa: F401  (torch first: one HIP runtime per process)
 
 from ._lib import library
 from .tensor_api import TensorOps

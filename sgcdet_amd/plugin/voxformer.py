@@ -40,7 +40,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..mmcv_lite import (ATTENTION, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE,
-                         BaseModule, ConfigDict, ModuleList, TransformerLayerSequence,
+                         BaseModule, ModuleList, TransformerLayerSequence,
                          build_attention, build_feedforward_network, build_norm_layer,
                          build_transformer_layer_sequence, constant_init, xavier_init)
 from ..functions import MultiScale3DDeformableAttnFunction_fp32
