@@ -15,7 +15,7 @@ ranks shard scenes with NO data-path collective; scaling is weak (one scene per 
 step).  Rank 0 prints ONE JSON line; ``roofline`` is for the deformable-gather kernel at the
 finest level, timed with HIP events on its launch stream (with the default whole-scene hipGraph
 replay the events bracket the same kernel in an eager pass over the same scenes right after the
-timed region -- ``roofline.measured`` says which), ``roofline_mfma`` for the 90-GFLOP convolution,
+timed region -- ``roofline.measured`` says which), ``roofline_mfma`` for the 90-GFLOP convolution, ``path_roofline`` for the whole path against its composite floor,
 ``cpu_baseline`` is the CPU oracle (a port: the reference has no CPU implementation of this path)
 on a bounded sample on the host cores, ``self_check`` re-runs the scenes-in-flight configuration
 against serial eager launches bit for bit.
@@ -97,6 +97,12 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
     """compulsory traffic of the deformable gather with perfect on-chip
     reuse = projected value map + depth map + per-pair raw offsets/logits + per-pair output."""
     return n_views * hw * C * s + n_views * hw * D * s + pairs * (M * P * 4 * 4) + pairs * C * s
+
+
+# entry points whose launches the eager pass brackets with events: the gathers (HBM roofline) and every GEMM-shaped launch
+# (MFMA roofline); together they are the work the whole-path floor of `path_roofline` is made of
+PATH_KERNELS = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_pairs_geometry_sample", "sgc_conv3d_cl_bf16x3",
+                "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3", "sgc_linear_rows_headmajor_bf16x3"}
 
 
 def usable_cores():
@@ -325,7 +331,7 @@ def main():
         det.scene_graph = False
         tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
-        ops.event_names = None if args.breakdown else {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"}
+        ops.event_names = None if args.breakdown else PATH_KERNELS
         with torch.no_grad():
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
@@ -435,6 +441,31 @@ def main():
                              note=("achieved = MFMA work actually issued (three bf16 products per fp32 multiply-add: lo*hi + "
                                    "hi*lo + hi*hi); fp32_equivalent_tflops = algorithmic FLOPs of the fp32 convolution / time")
                              if bf else "exact fp32 products on v_mfma_f32_32x32x2_f32")
+    # ---- the whole path against its own roofline (north star: "as a fraction of the HBM roofline"): compulsory gather bytes at
+    #      8 TB/s + the matrix work actually issued at the dense MFMA peak, per scene, over the measured time per scene ----
+    path_roofline = None
+    if not eager_events and per_kernel:
+        n_e = max(6, min(args.steps, 20))
+        gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"])
+                   for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
+        gbytes = 0.0
+        for name, items in per_kernel.items():
+            for _, m in items:
+                if name in ("sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled"):
+                    gbytes += algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"]) \
+                        - (4 - m.get("value_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["C"]
+                elif name == "sgc_pairs_geometry_sample":     # raw map + depth map + (u, v, z) per pair + output (B_gs)
+                    gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * (12 + m["C"] * 4)
+        gbytes /= n_e
+        bf = args.conv_mode == "bf16x3"
+        issued = gemm * (3 if bf else 1)
+        floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
+        path_roofline = dict(gather_mb_algorithmic=round(gbytes / 1e6, 1), gemm_gflop_algorithmic=round(gemm / 1e9, 1),
+                             gemm_gflop_issued=round(issued / 1e9, 1), floor_ms_per_scene=round(floor_ms, 3),
+                             frac=round(floor_ms / (elapsed / args.steps * 1e3) * world, 4),
+                             note="floor = compulsory bytes of the geometry-sample + deformable gathers at 8 TB/s + the MFMA work "
+                                  "issued by every convolution / Linear (3 bf16 products per fp32 multiply-add) at the dense MFMA "
+                                  "peak, per scene; frac = floor / measured time per scene (timed region)")
     if args.breakdown and rank == 0:
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
             tot = sum(t for t, _ in items)
@@ -506,6 +537,7 @@ def main():
                        "sharding": "scenes across ranks, no collective"},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
+            "path_roofline": path_roofline,
             "strict_fp32": strict,
             "sustained": sustained,
             "self_check": self_check,
