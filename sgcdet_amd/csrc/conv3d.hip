@@ -47,6 +47,12 @@ int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo ke
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// rows_gemm.hip: persistent weight-stationary form of the K <= 256 row GEMMs (every Linear of a level, the 1x1x1 layers)
+bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_t ldx);
+int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                     const float *shift, const float *residual, void *y, const int32_t *m_dev, int M, int K, int N, int relu,
+                     int hm_S, int hm_cm, int hm_bf16, hipStream_t st);
+
 struct ConvParams {
   const float *x;         // [IV, Cin] channels-last input volume
   const float *w;         // [taps][Cout][Cin]
@@ -74,6 +80,7 @@ struct ConvParams {
                           // accumulator (finite, deterministic).  Live rows are bit-identical to the dense launch.
   int two_d;              // 2-D convolution over a stack of images: grid (x, y, z) = (image, row, column), the taps only span (y, z)
                           // (sgc_conv2d_nhwc_bf16x3: the FPN output convolutions)
+  unsigned long long *stamps;  // diagnostic builds only (SGC_HALO_STAMPS)
   int hm_bf16;            // head-major output stored as bfloat16 (RNE of the fp32 result)
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
@@ -563,6 +570,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // BNV: output columns per workgroup, 128 (wave tile 64 x 64) or 64 (wave tile 64 x 32: the head's 28 / 32-column layers, which
 // otherwise spend three quarters of their matrix work on padding columns).
+// Diagnostic builds only (tools/diag_build.sh halostamps conv3d.hip -DSGC_HALO_STAMPS): shader-clock and real-time stamps
+// around the tap loop of every workgroup -> the clock the chip holds while this kernel runs (MI355X_MICROARCH.md, DVFS
+// give-back item 6).  The stamps go to a buffer of their own; no output value depends on them.
+#if defined(SGC_HALO_STAMPS)
+unsigned long long *g_halo_stamp_buf = nullptr;
+#endif
+
 template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
@@ -670,6 +684,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+#if defined(SGC_HALO_STAMPS)
+  unsigned long long *stamp = p.stamps ? p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4) : nullptr;
+  if (stamp && tid == 0) { stamp[0] = __builtin_readcyclecounter(); stamp[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
   if constexpr (RING) {
     // ---- ring form: weights by LDS-DMA into a 3-stage ring, no registers and no ds_write on the weight path ----
@@ -967,6 +985,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
 
   }
 
+#if defined(SGC_HALO_STAMPS)
+  if (stamp && tid == 0) { stamp[2] = __builtin_readcyclecounter(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   // Epilogue through LDS (as in the implicit-GEMM kernel): the halo / weight buffers are free, the 256 x 128 tile
   // leaves as 16-byte row-contiguous stores instead of 64 four-byte stores per lane.
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
@@ -1081,6 +1102,9 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
 
 template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
+#if defined(SGC_HALO_STAMPS)
+  p.stamps = g_halo_stamp_buf;
+#endif
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
   const size_t smem = halo_tab_offset(LROWS, RING) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
@@ -1250,6 +1274,9 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   p.ws = workspace_or_null; p.ws_floats = workspace_or_null ? workspace_floats : 0;
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
+  // 1x1x1 stride-1 layers are row GEMMs (the FFN of a level, TU/encoder.py:311-338): persistent weight-stationary kernel
+  if (!transposed && ksize == 1 && stride == 1 && !p.two_d && rows_gemm_supported(Cin, Cout, 0, 0, OV, Cin))
+    return rows_gemm_launch(x, Cin, w_hi, w_lo, scale, shift, residual_or_null, y, nullptr, (int)OV, Cin, Cout, relu, 0, 0, 0, st);
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
     // ring form: an option (see g_tune_halo_ring); 1 = the 256 -> 256 layers on the 4x4x16 brick, 2 = everywhere
@@ -1646,6 +1673,11 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
   //  reduction, weights streamed through LDS in 32-column tiles -- was built, bit-identical, and measured:
   //  159 vs 175 us on 188,800 rows but 57 vs 41 us on 77,000 x 128 and 41 vs 18 us on 6,400 rows: its 10 us
   //  load-and-split prologue per workgroup is not amortised.  Not adopted.)
+  if (((uintptr_t)x | (uintptr_t)w_hi | (uintptr_t)w_lo | (uintptr_t)y) & 15)
+    return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: pointers must be 16-byte aligned");
+  if (rows_gemm_supported(Cin, Cout, hm_cm, hm_S, rows_cap, Cin))
+    return rows_gemm_launch(x, Cin, w_hi, w_lo, nullptr, shift, nullptr, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, hm_S, hm_cm,
+                            hm_bf16, (hipStream_t)stream);
   ConvParamsB p = {};
   p.x = x; p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.y = y; p.shift = shift;
@@ -1691,3 +1723,7 @@ extern "C" int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *
     return set_error(SGC_EUNSUP, "sgc_linear_rows_headmajor_bf16x3: Cm must divide the 128-column tile (got %d)", Cm);
   return linear_rows(x, w_hi, w_lo, shift, reinterpret_cast<float *>(y), nullptr, N * S, Cin, M * Cm, S, Cm, y_bf16 ? 1 : 0, stream);
 }
+
+#if defined(SGC_HALO_STAMPS)
+extern "C" void sgc_diag_halo_stamp_buffer(unsigned long long *buf) { sgc::g_halo_stamp_buf = buf; }
+#endif

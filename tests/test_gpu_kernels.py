@@ -730,3 +730,67 @@ def test_view_attend_backward_matches_oracle_and_multihead_attention(oracle_ops,
     assert max_abs(ctx_g.detach().cpu().double() - out[0].detach()) < 1e-5
     assert max_abs(qg.grad.cpu().double() - qd.grad) < 2e-5 * max(1.0, float(qd.grad.abs().max()))
     assert max_abs(kvg.grad.cpu().double() - kvd.grad) < 2e-5 * max(1.0, float(kvd.grad.abs().max()))
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(1, 256, 256), (33, 256, 128), (3200, 256, 512), (6401, 256, 256), (77, 128, 128),
+                                           (5000, 128, 256), (20001, 256, 128)])
+def test_persistent_row_gemm_against_oracle_and_the_tile_kernel(rows, cin, cout, oracle_ops, gpu_ops):
+    """csrc/rows_gemm.hip (persistent, weights in registers) takes every K in {128, 256}, N % 128 == 0 row GEMM:
+    fp32 oracle within the bf16x3 bound (1e-4 of the scale), bit-identical to the tile-per-workgroup kernel it replaces
+    (same k order, same product order), a row's bits independent of the row count (host count == device count ==
+    a prefix of a longer call), rows past the device count untouched.  Reference work: every nn.Linear of a level,
+    TU/deformable_cross_attention.py:417-436,826-833."""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    hi, lo = gpu_ops.split_bf16(w.view(1, cout, cin))
+    xc, hc, lc, bc = x.cuda(), hi.cuda(), lo.cuda(), b.cuda()
+    y = gpu_ops.linear_rows_bf16x3(xc, hc, lc, bc)
+    close(y, oracle_ops.linear_rows_bf16x3(x, hi, lo, b), tol=1e-4)
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"rows_gemm", 0)
+        y_tile = gpu_ops.linear_rows_bf16x3(xc, hc, lc, bc)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"rows_gemm", 1)
+    assert torch.equal(y, y_tile)
+    for form in (0, 2, 1):                    # staggered / two tiles ahead / the default: variants of one arithmetic
+        gpu_ops.lib.call("sgc_set_tuning", b"rows_depth", form)
+        assert torch.equal(gpu_ops.linear_rows_bf16x3(xc, hc, lc, bc), y), form
+    cnt = max(1, (rows * 2) // 3)
+    out = torch.full((rows, cout), 7.0, device="cuda")
+    gpu_ops.linear_rows_bf16x3(xc, hc, lc, bc, count=torch.tensor([cnt], dtype=torch.int32, device="cuda"), out=out)
+    assert torch.equal(out[:cnt], y[:cnt]) and bool((out[cnt:] == 7.0).all())
+    assert torch.equal(gpu_ops.linear_rows_bf16x3(xc[:cnt].contiguous(), hc, lc, bc), y[:cnt])
+
+
+@pytest.mark.parametrize("N,S,cin,M", [(3, 47, 256, 8), (5, 333, 128, 8), (2, 32, 256, 8), (4, 1280, 256, 8)])
+def test_persistent_row_gemm_head_major_and_epilogues(N, S, cin, M, oracle_ops, gpu_ops):
+    """Head-major store of the persistent kernel (tiles that straddle camera borders, fp32 and bf16 storage) and its
+    scale / shift / relu / residual epilogues (the FFN's two launches, mmcv FFN as used by TU/encoder.py:311-338)
+    against the oracle and, bit for bit, against the tile kernel."""
+    g = torch.Generator().manual_seed(S)
+    cout = cin
+    x = torch.randn(N * S, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    hi, lo = gpu_ops.split_bf16(w.view(1, cout, cin))
+    xc, hc, lc, bc = x.cuda(), hi.cuda(), lo.cuda(), b.cuda()
+    rows = gpu_ops.linear_rows_bf16x3(xc, hc, lc, bc)
+    for dt in (torch.float32, torch.bfloat16):
+        y = gpu_ops.linear_rows_headmajor_bf16x3(xc, hc, lc, bc, N, S, M, out_dtype=dt)
+        assert torch.equal(y, rows.view(N, S, M, cout // M).permute(0, 2, 1, 3).contiguous().to(dt))
+    close(gpu_ops.linear_rows_headmajor_bf16x3(xc, hc, lc, bc, N, S, M), oracle_ops.linear_rows_headmajor_bf16x3(x, hi, lo, b, N, S, M), tol=1e-4)
+    sc = torch.rand(cout, generator=g) + 0.5
+    res = torch.randn(N * S, cout, generator=g)
+    for relu, r in ((2, None), (0, res), (1, res), (2, res)):
+        rc = None if r is None else r.cuda()
+        y, _ = gpu_ops.conv3d_cl_bf16x3(xc, hc, lc, (N * S, 1, 1), 1, 1, False, sc.cuda(), bc, rc, relu)
+        y_o, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, (N * S, 1, 1), 1, 1, False, sc, b, r, relu)
+        close(y, y_o, tol=1e-4)
+        try:
+            gpu_ops.lib.call("sgc_set_tuning", b"rows_gemm", 0)
+            y_tile, _ = gpu_ops.conv3d_cl_bf16x3(xc, hc, lc, (N * S, 1, 1), 1, 1, False, sc.cuda(), bc, rc, relu)
+        finally:
+            gpu_ops.lib.call("sgc_set_tuning", b"rows_gemm", 1)
+        assert torch.equal(y, y_tile), (relu, r is not None)
