@@ -211,8 +211,37 @@ def cpu_baseline(w, n_views, seed):
     return out
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks (one per GPU) as CHILD processes through
+    ``torch.distributed.run`` and exit with their code.  Runs before anything in this process has touched the GPU
+    (``torch.cuda.device_count()`` does not initialise it on this image; a process that has initialised HIP must never
+    exec or fork GPU work).  Mirrors the reference's launch, DDP over all visible GPUs (main.py:64-70)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible -- refusing to report "
+                 f"a {args.gpus}-GPU number from fewer ranks")
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                          # never returns
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} rank(s); "
+                 "the line would misreport n_gpus")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
     from sgcdet_amd import dist as sgc_dist
@@ -223,6 +252,9 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        world = dist.get_world_size()              # the ranks RCCL actually joined: what `n_gpus` reports
+    if world != args.gpus:
+        sys.exit(f"bench.py: {world} rank(s) joined the process group, --gpus says {args.gpus}")
 
     from sgcdet_amd.scene import make_scene, workload
     from sgcdet_amd import ext

@@ -48,7 +48,10 @@ extern "C" {
 #define SGC_ELAUNCH (-2)  /* HIP launch / runtime error                          */
 #define SGC_EUNSUP (-3)   /* shape not supported by this build                    */
 
-#define SGC_ABI_VERSION 1
+/* Bumped whenever the argument list of an EXISTING entry point changes (a stale prebuilt .so is then rejected at load
+ * instead of being called with shifted arguments).  1 -> 2: sgc_project_points gained `sel`, sgc_nchw_to_nhwc_crop gained
+ * `step` (round 2).  New entry points do not bump it: a missing symbol already fails the load. */
+#define SGC_ABI_VERSION 2
 
 typedef void *sgc_stream_t; /* hipStream_t */
 

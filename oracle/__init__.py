@@ -19,8 +19,9 @@ _CACHE = {}
 def build(force=False):
     """Compile the C restatement with gcc (seconds)."""
     targets = [os.path.join(_HERE, n) for n in ("libsgc_oracle.so", "libsgc_oracle_omp.so")]
-    src = os.path.join(_HERE, "sgc_oracle.c")
-    stale = force or any((not os.path.exists(t)) or os.path.getmtime(t) < os.path.getmtime(src) for t in targets)
+    deps = [os.path.join(_HERE, "sgc_oracle.c"), os.path.join(_HERE, "..", "include", "sgcdet_amd.h")]
+    newest = max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+    stale = force or any((not os.path.exists(t)) or os.path.getmtime(t) < newest for t in targets)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
     return targets

@@ -1719,8 +1719,11 @@ extern "C" int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *
                                                 sgc_stream_t stream) {
   if (N <= 0 || S <= 0 || M <= 0 || Cm <= 0 || Cm % 4 || (int64_t)N * S >= (1ll << 31))
     return set_error(SGC_EINVAL, "sgc_linear_rows_headmajor_bf16x3: bad size (Cm %% 4 == 0 required)");
-  if (128 % Cm && Cm % 128)
-    return set_error(SGC_EUNSUP, "sgc_linear_rows_headmajor_bf16x3: Cm must divide the 128-column tile (got %d)", Cm);
+  // the head-major epilogues keep a head inside one column tile (128 columns on the tile kernel -- 64 when M * Cm <= 64 --,
+  // 32 per wave on the persistent kernel, which also takes whole-wave multiples up to 128)
+  const int tile_cols = M * Cm <= 64 ? 64 : 128;
+  if (tile_cols % Cm)
+    return set_error(SGC_EUNSUP, "sgc_linear_rows_headmajor_bf16x3: Cm must divide the %d-column tile (got %d)", tile_cols, Cm);
   return linear_rows(x, w_hi, w_lo, shift, reinterpret_cast<float *>(y), nullptr, N * S, Cin, M * Cm, S, Cm, y_bf16 ? 1 : 0, stream);
 }
 

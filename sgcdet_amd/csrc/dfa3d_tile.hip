@@ -27,6 +27,8 @@
 // + 4 packed 16-bit LDS row offsets.  Phase 2 stays in the unit's own quad: lane c reads the 16-byte chunks c (and
 // c + 4 for Cm = 32) of every corner row, so the descriptors of the unit's 4 samples arrive by DPP quad broadcasts on
 // the VALU (no LDS-crossbar shuffles), one sample's 4 rows in flight at a time (ds_read_b128), FMA, 16-byte stores.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace sgc {
@@ -486,7 +488,12 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
 int g_tune_tile_nw = 0;         // waves per workgroup (8 or 16).  auto: 8 when two workgroups fit a CU's LDS (<= 80 KB
                                 // each: one computes while the other stages its window), else 16
 int g_tune_tile_depth_lds = -1; // >= 0 overrides the caller's depth_in_lds
-int g_tune_tile_diag = 0;
+int g_tune_tile_diag = 0;       // TIMING EXPERIMENTS ONLY (1 = no compute, 2 = no fill: the outputs are garbage); inert unless
+                                // SGC_DIAG=1 is in the environment, so a stray SGC_TUNE cannot corrupt a production run
+static bool diag_allowed() {
+  static const bool ok = getenv("SGC_DIAG") && atoi(getenv("SGC_DIAG")) == 1;
+  return ok;
+}
 int g_tune_tile_nbuf = 0;       // value-window buffers; 2 = the next head's window lands while the current head is computed
                                 // (needs heads-per-workgroup > 1).  auto: 1
 int g_tune_tile_xcd = 0;        // 1: camera n's workgroups on XCD n % 8 (head-major, bins innermost); 0: (camera, bin, head) order,
@@ -603,7 +610,7 @@ extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf1
   p.raw = reinterpret_cast<const float4 *>(raw_hm); p.out = out; p.head_shift = head_shift_or_null;
   p.N = N; p.S = cam_stride_or_0 > 0 ? cam_stride_or_0 : H * W; p.H = H; p.W = W; p.D = D; p.M = M;
   p.bw = bin_w; p.bh = bin_h; p.nbx = ceil_div(W, bin_w); p.nby = ceil_div(H, bin_h);
-  p.hx = halo_x; p.hy = halo_y; p.smx = smx; p.smy = smy; p.diag = g_tune_tile_diag;
+  p.hx = halo_x; p.hy = halo_y; p.smx = smx; p.smy = smy; p.diag = diag_allowed() ? g_tune_tile_diag : 0;
   p.tw = g.tw; p.th = g.th; p.dw = g.dw; p.dh = g.dh;
   p.HG = (g_tune_tile_hg > 0 && M % g_tune_tile_hg == 0) ? g_tune_tile_hg : 1;
   p.xcd_map = g_tune_tile_xcd;

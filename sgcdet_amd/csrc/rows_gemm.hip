@@ -234,7 +234,9 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
       }
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        float v = fmaf(acc[k], sc, sh);                      // one rounding, as the epilogue of conv3d.hip compiles (fma contraction)
+        float v = acc[k] * sc;                              // two roundings (product, then sum) like the staged epilogue of
+        asm volatile("" : "+v"(v));                          // conv3d.hip and the oracle's plain C: the empty asm keeps the
+        v += sh;                                             // compiler from contracting them into one fma
         if constexpr (EPI == 2) {
           v = relu2 ? fmaxf(v, 0.f) : v;
           v += res[k];
@@ -388,7 +390,7 @@ bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_
   if (K != 128 && K != 256) return false;
   if (N <= 0 || N % 128) return false;
   if (rows <= 0 || (rows + 64) * ldx * 4 >= (int64_t)RG_OOB || (rows + 64) * N * 4 >= (int64_t)RG_OOB) return false;
-  if (hm_cm > 0 && ((32 % hm_cm && hm_cm % 32) || hm_S < RG_ROWS)) return false;
+  if (hm_cm > 0 && (128 % hm_cm || hm_S < RG_ROWS)) return false;      // per-lane head / offset arithmetic: any hm_cm | 128
   return true;
 }
 

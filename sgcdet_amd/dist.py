@@ -226,8 +226,13 @@ class _SyncBatchNormFn(torch.autograd.Function):
                 running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
         shape = [1, C] + [1] * (x.dim() - 2)
         xhat = (xf - mean.view(shape)) * invstd.view(shape)
-        y = xhat * weight.float().view(shape) + bias.float().view(shape)
-        ctx.save_for_backward(xhat, weight, invstd, n_tot)
+        y = xhat
+        if weight is not None:                                  # affine=False: no scale / shift, no parameter gradients
+            y = y * weight.float().view(shape)
+        if bias is not None:
+            y = y + bias.float().view(shape)
+        ctx.affine = (weight is not None, bias is not None)
+        ctx.save_for_backward(xhat, weight if weight is not None else invstd.new_ones(C), invstd, n_tot)
         ctx.group = group
         return y.to(x.dtype)
 
@@ -247,7 +252,9 @@ class _SyncBatchNormFn(torch.autograd.Function):
         w = weight.float()
         gx = (gyf - (g_sum / n_tot).view(shape) - xhat * (g_dot / n_tot).view(shape)) * (invstd * w).view(shape)
         # weight / bias gradients are LOCAL sums: the gradient all-reduce of the step averages them like every other parameter
-        return gx.to(gy.dtype), sum_dy_xhat.to(weight.dtype), sum_dy.to(weight.dtype), None, None, None, None, None
+        has_w, has_b = ctx.affine
+        return (gx.to(gy.dtype), sum_dy_xhat.to(weight.dtype) if has_w else None, sum_dy.to(weight.dtype) if has_b else None,
+                None, None, None, None, None)
 
 
 def _dist_on():
@@ -261,7 +268,7 @@ class SyncBatchNorm3d(torch.nn.BatchNorm3d):
     process_group = None
 
     def forward(self, x):
-        if not self.training or not self.track_running_stats and not self.training:
+        if not self.training:
             return super().forward(x)
         if self.momentum is None:
             raise NotImplementedError("SyncBatchNorm3d: cumulative moving average (momentum=None) is not used by SGCDet")

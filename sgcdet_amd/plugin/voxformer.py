@@ -756,13 +756,18 @@ class PerceptionTransformer_DFA3D(BaseModule):
         return cache[key]
 
     def _coords_are_flat(self, vox_coords):
-        """vox_coords[:, 3] == arange (true for DenseHead's own buffer; checked once per buffer on the host)."""
-        cache = self.__dict__.setdefault("_flat_cache", {})
-        key = (vox_coords.data_ptr(), vox_coords._version, vox_coords.shape[0])
-        if key not in cache:
-            cache.clear()
-            cache[key] = bool(torch.equal(vox_coords[:, 3].cpu(), torch.arange(vox_coords.shape[0])))
-        return cache[key]
+        """vox_coords[:, 3] == arange: declared by the producer (DenseHead tags the buffer it builds, ``_sgc_flat``); an
+        untagged tensor is checked on the host ONCE PER TENSOR OBJECT (the verdict is stored on the tensor itself, so a
+        different tensor that later reuses the address can never inherit it) -- and never during a graph capture, where
+        the read-back would be illegal."""
+        flat = getattr(vox_coords, "_sgc_flat", None)
+        if flat is not None and flat[0] == vox_coords._version:
+            return flat[1]
+        if vox_coords.is_cuda and torch.cuda.is_current_stream_capturing():
+            return False                                   # the general (gather) path is always correct
+        ok = bool(torch.equal(vox_coords[:, 3].cpu(), torch.arange(vox_coords.shape[0])))
+        vox_coords._sgc_flat = (vox_coords._version, ok)
+        return ok
 
     def get_vox_features(self, mlvl_feats, bev_queries, ref_3d, vox_coords, unmasked_idx, bev_pos=None,
                          prev_bev=None, img_meta=None, mlvl_dpt_dists=None, **kwargs):

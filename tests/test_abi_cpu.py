@@ -21,6 +21,16 @@ def test_header_symbols_match_binding_table():
     assert _declared_symbols() == sorted(list(SIGNATURES) + list(INTROSPECTION))
 
 
+def test_abi_version_of_header_binding_and_libraries_agree(oracle_ops):
+    """A changed argument list must bump SGC_ABI_VERSION in the header AND the binding table; both libraries are rebuilt
+    from the header, so a stale .so (old version number) is rejected by Library()."""
+    from sgcdet_amd import _abi
+    text = open(os.path.join(ROOT, "include", "sgcdet_amd.h")).read()
+    header = int(re.search(r"#define\s+SGC_ABI_VERSION\s+(\d+)", text).group(1))
+    assert header == _abi.ABI_VERSION >= 2
+    assert oracle_ops.lib._dll.sgc_abi_version() == header
+
+
 def test_hip_library_loads_and_exports_every_symbol():
     from sgcdet_amd import build
     from sgcdet_amd._abi import Library

@@ -182,3 +182,18 @@ def test_fpn_restates_the_published_module():
     x = torch.arange(8 * 10, dtype=torch.float32).view(1, 1, 8, 10)
     up = F.interpolate(x, size=(15, 20), mode="nearest")
     assert torch.equal(up[0, 0], x[0, 0][_nearest_index(15, 8, "cpu")][:, _nearest_index(20, 10, "cpu")])
+
+
+def test_bench_refuses_to_mislabel_the_gpu_count():
+    """bench.py --gpus N: without a launcher it starts N ranks itself and needs N visible GPUs (here: none -> non-zero
+    exit, before anything touches a GPU); under a launcher WORLD_SIZE must equal N."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 requested but only" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
