@@ -187,7 +187,9 @@ int sgc_project_points(const float *ref3d, const int64_t *sel_or_null, const flo
  *   vox_count [Nq] int32 OUT: #cameras seeing q, valid_index [Nq] int32 OUT: ascending
  *   q with count>0 (reference `valid_index`, TU/deformable_cross_attention.py:822),
  *   totals [4] int32 OUT: {n_pairs, n_valid, max_len, 0}.
- * workspace: >= (N*Nq + Nq + 2*N + 64) int32.                                      */
+ * workspace: >= (N*Nq + Nq + 2*N + 64) int32 (may be null); on return its first Nq entries hold
+ *   row_of [Nq]: the inverse of valid_index (row of q in the compact list of seen voxels, -1 if
+ *   no camera sees q) -- the gather index of sgc_level_tail.                                      */
 int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
                       int32_t *cam_count, int32_t *cam_offset,
                       int32_t *pair_cam, int32_t *pair_q, int32_t *slot,
@@ -486,6 +488,26 @@ int64_t sgc_topk_select_workspace_bytes(int n);
  * fp32 two-pass statistics.  y may alias x.                                                                    */
 int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
                         const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream);
+
+/* The tail of a VoxFormer level in one launch: for every voxel q of the level
+ *     x0 = out_proj(ctx[row_of[q]]) if row_of[q] >= 0 else 0      (nn.MultiheadAttention.out_proj + the slot scatter,
+ *                                                                  TU/deformable_cross_attention.py:826-837)
+ *     x1 = LayerNorm(x0; ln1)                                      (VoxFormerLayer "norm", TU/encoder.py:311-338)
+ *     x2 = W2 relu(W1 x1 + b1) + b2 + x1                           (mmcv FFN, "ffn")
+ *     out[q] = LayerNorm(x2; ln2)                                  ("norm")
+ * i.e. sgc_linear_rows_bf16x3 + sgc_scatter_rows + sgc_layer_norm_rows + 2 x sgc_conv3d_cl_bf16x3 (1x1x1) +
+ * sgc_layer_norm_rows with the intermediates kept on chip; same arithmetic, BIT-IDENTICAL results (bf16x3 products).
+ *   ctx [rows, C] fp32 compact rows (view_attend's output), row_of [Nq] int32 (sgc_compact_pairs), weights split as
+ *   bf16 hi / lo: wo [C][C], w1 [F][C], w2 [C][F], each FRAGMENT-PACKED: a row-major [N][K] matrix W is passed as
+ *   P[N/32][K/16][64][8] with P[b][kk][l][j] = W[32 b + (l & 31)][16 kk + 8 (l >> 5) + j] (the 16 bytes lane l feeds to the
+ *   32x32x16 MFMA of k-step kk: one coalesced 1 KiB access per wave instead of 32 row pieces; TensorOps.pack_b_fragments);
+ *   biases / LayerNorm parameters fp32; out [Nq, C].
+ *   Supported: C in {128, 256} and F == 2 C (sgc_level_tail_supported); SGC_EUNSUP otherwise.                   */
+int sgc_level_tail_supported(int C, int F);
+int sgc_level_tail(const float *ctx, const int32_t *row_of, const uint16_t *wo_hi, const uint16_t *wo_lo, const float *bo,
+                   const float *ln1_gamma, const float *ln1_beta, float eps1, const uint16_t *w1_hi, const uint16_t *w1_lo,
+                   const float *b1, const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const float *ln2_gamma,
+                   const float *ln2_beta, float eps2, float *out, int Nq, int C, int F, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 8. Post-processing

@@ -495,7 +495,7 @@ int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
                       int32_t *pair_cam, int32_t *pair_q, int32_t *slot,
                       int32_t *vox_count, int32_t *valid_index, int32_t *totals,
                       int32_t *workspace, sgc_stream_t stream) {
-  (void)stream; (void)workspace;
+  (void)stream;
   if (!mask || !cam_count || !cam_offset || !pair_cam || !pair_q || !slot || !vox_count || !valid_index || !totals)
     return fail(SGC_EINVAL, "null pointer");
   int32_t np = 0, max_len = 0;
@@ -516,8 +516,10 @@ int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
   }
   cam_offset[N] = np;
   int32_t nv = 0; /* valid_index = count.nonzero(), :822 */
-  for (int q = 0; q < Nq; ++q)
+  for (int q = 0; q < Nq; ++q) {
+    if (workspace) workspace[q] = vox_count[q] > 0 ? nv : -1;      /* row_of: inverse of valid_index */
     if (vox_count[q] > 0) valid_index[nv++] = q;
+  }
   totals[0] = np; totals[1] = nv; totals[2] = max_len; totals[3] = 0;
   return SGC_OK;
 }
@@ -1177,6 +1179,55 @@ int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, f
     for (int c = 0; c < C; ++c) y[(int64_t)r * C + c] = (float)((xr[c] - mean) * rstd * gamma[c] + beta[c]);
   }
   return SGC_OK;
+}
+
+/* The tail of a VoxFormer level, restated as the composition it replaces (fp32 truth of sgc_level_tail):
+ * out_proj on the seen voxels + zero rows elsewhere (TU/deformable_cross_attention.py:826-837), LayerNorm, mmcv FFN with
+ * its identity, LayerNorm (TU/encoder.py:311-338). */
+int sgc_level_tail_supported(int C, int F) { return C > 0 && F > 0; }
+
+int sgc_level_tail(const float *ctx, const int32_t *row_of, const uint16_t *wo_hi, const uint16_t *wo_lo, const float *bo,
+                   const float *ln1_gamma, const float *ln1_beta, float eps1, const uint16_t *w1_hi, const uint16_t *w1_lo,
+                   const float *b1, const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const float *ln2_gamma,
+                   const float *ln2_beta, float eps2, float *out, int Nq, int C, int F, sgc_stream_t stream) {
+  if (!ctx || !row_of || !wo_hi || !wo_lo || !bo || !ln1_gamma || !ln1_beta || !w1_hi || !w1_lo || !b1 || !w2_hi || !w2_lo ||
+      !b2 || !ln2_gamma || !ln2_beta || !out)
+    return fail(SGC_EINVAL, "null pointer");
+  if (Nq <= 0) return SGC_OK;
+  if (C % 32 || F % 32) return fail(SGC_EUNSUP, "fragment-packed weights need C, F multiples of 32");
+  /* weights arrive fragment-packed P[N/32][K/16][64][8] (include/sgcdet_amd.h): back to row-major [N][K] */
+  uint16_t *wm[6];
+  const uint16_t *src[6] = {wo_hi, wo_lo, w1_hi, w1_lo, w2_hi, w2_lo};
+  const int nn[6] = {C, C, F, F, C, C}, kk_[6] = {C, C, C, C, F, F};
+  int rc = SGC_OK;
+  for (int m = 0; m < 6; ++m) {
+    wm[m] = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)nn[m] * kk_[m]);
+    if (!wm[m]) { rc = fail(SGC_EINVAL, "out of memory"); continue; }
+    const int N_ = nn[m], K_ = kk_[m];
+    for (int b = 0; b < N_ / 32; ++b)
+      for (int ks = 0; ks < K_ / 16; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j)
+            wm[m][(size_t)(32 * b + (l & 31)) * K_ + 16 * ks + 8 * (l >> 5) + j] = src[m][(((size_t)b * (K_ / 16) + ks) * 64 + l) * 8 + j];
+  }
+  float *x0 = (float *)calloc((size_t)Nq * C, sizeof(float));
+  float *x1 = (float *)malloc(sizeof(float) * (size_t)Nq * C);
+  float *h = (float *)malloc(sizeof(float) * (size_t)Nq * F);
+  float *x2 = (float *)malloc(sizeof(float) * (size_t)Nq * C);
+  float *row = (float *)malloc(sizeof(float) * (size_t)C);
+  if (rc == SGC_OK && !(x0 && x1 && h && x2 && row)) rc = fail(SGC_EINVAL, "out of memory");
+  for (int q = 0; rc == SGC_OK && q < Nq; ++q) {
+    if (row_of[q] < 0) continue;                                   /* the slot scatter leaves unseen voxels at zero */
+    rc = sgc_conv3d_cl_bf16x3(ctx + (int64_t)row_of[q] * C, wm[0], wm[1], NULL, bo, NULL, row, 1, 1, 1, C, C, 1, 1, 0, 0, NULL, 0, stream);
+    memcpy(x0 + (int64_t)q * C, row, sizeof(float) * (size_t)C);
+  }
+  if (rc == SGC_OK) rc = sgc_layer_norm_rows(x0, ln1_gamma, ln1_beta, eps1, x1, NULL, Nq, C, stream);
+  if (rc == SGC_OK) rc = sgc_conv3d_cl_bf16x3(x1, wm[2], wm[3], NULL, b1, NULL, h, Nq, 1, 1, C, F, 1, 1, 0, 2, NULL, 0, stream);
+  if (rc == SGC_OK) rc = sgc_conv3d_cl_bf16x3(h, wm[4], wm[5], NULL, b2, x1, x2, Nq, 1, 1, F, C, 1, 1, 0, 0, NULL, 0, stream);
+  if (rc == SGC_OK) rc = sgc_layer_norm_rows(x2, ln2_gamma, ln2_beta, eps2, out, NULL, Nq, C, stream);
+  for (int m = 0; m < 6; ++m) free(wm[m]);
+  free(x0); free(x1); free(h); free(x2); free(row);
+  return rc;
 }
 
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sgc_mask_dilate3": [_p, _p, _i, _i, _i, _p],
     "sgc_valid_pyramid": [_p, _p, _i, _i, _i, _i, _p],
     "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
+    "sgc_level_tail": [_p] * 7 + [_f] + [_p] * 8 + [_f] + [_p] + [_i] * 3 + [_p],
     "sgc_topk_select": [_p, _i, _i, _p, _p, _p, _p],
     "sgc_topk_select_ws": [_p, _i, _i, _p, _p, _p, _p, C.c_int64, _p],
     "sgc_layer_norm_rows": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
@@ -64,6 +65,7 @@ INTROSPECTION = {
     "sgc_conv3d_workspace_floats": (C.c_int64, [_i] * 9),
     "sgc_conv3d_wgrad_workspace_floats": (C.c_int64, [_i] * 7),
     "sgc_topk_select_workspace_bytes": (C.c_int64, [_i]),
+    "sgc_level_tail_supported": (C.c_int, [_i] * 2),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
 }
 

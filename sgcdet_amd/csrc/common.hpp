@@ -189,4 +189,53 @@ __device__ __forceinline__ void make_sample_dp(Sample &sm, const float *__restri
   sm.w[3] = sm.in2 ? sm.lh * sm.lw * sc[3] * aw : 0.f;
 }
 
+// ---- LayerNorm over one row of C = 64 * VPL channels held by ONE wave (rows.hip: layer_norm_rows_kernel; level_tail.hip uses the
+// same functions on rows that live in LDS, so the fused level tail reproduces the stand-alone kernel bit for bit).  Lane l holds
+// channels 4 l .. 4 l + 3 (VPL % 4 == 0: one 16-byte access) or l + 64 j. ----
+template <int VPL>
+__device__ __forceinline__ int ln_channel(int lane, int j) {
+  return VPL % 4 == 0 ? ((j / 4) * 64 + lane) * 4 + (j & 3) : j * 64 + lane;
+}
+template <int VPL>
+__device__ __forceinline__ void ln_row_load(const float *xr, int lane, float (&v)[VPL]) {
+  if constexpr (VPL % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < VPL / 4; ++j) {
+      const float4 t = *reinterpret_cast<const float4 *>(xr + (j * 64 + lane) * 4);
+      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) v[j] = xr[j * 64 + lane];
+  }
+}
+template <int VPL>
+__device__ __forceinline__ void ln_row_store(float *yr, int lane, const float (&y)[VPL]) {
+  if constexpr (VPL % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < VPL / 4; ++j)
+      *reinterpret_cast<float4 *>(yr + (j * 64 + lane) * 4) = make_float4(y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) yr[j * 64 + lane] = y[j];
+  }
+}
+template <int VPL>
+__device__ __forceinline__ void ln_row_stats(const float (&v)[VPL], float eps, float &mean, float &rstd) {
+  constexpr int C = 64 * VPL;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) s += v[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  mean = s * (1.0f / (float)C);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) { const float d = v[j] - mean; q += d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  rstd = rsqrtf(q * (1.0f / (float)C) + eps);
+}
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g, float b) { return (v - mean) * rstd * g + b; }
+
 }  // namespace sgc

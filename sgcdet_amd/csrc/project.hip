@@ -124,7 +124,7 @@ __global__ void vox_count_kernel(const uint8_t *__restrict__ mask, int N, int Nq
 // single block: ascending list of queries seen by at least one camera
 __global__ __launch_bounds__(1024) void valid_index_kernel(const int32_t *__restrict__ vox_count, int Nq,
                                                            int32_t *__restrict__ valid_index,
-                                                           int32_t *__restrict__ totals) {
+                                                           int32_t *__restrict__ totals, int32_t *__restrict__ row_of) {
   __shared__ int wave_sums[16];
   int running = 0;
   for (int q0 = 0; q0 < Nq; q0 += blockDim.x) {
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(1024) void valid_index_kernel(const int32_t *__rest
     int tot;
     const int r = block_scan_flags(f, &tot, wave_sums);
     if (f) valid_index[running + r] = q;
+    if (q < Nq && row_of) row_of[q] = f ? running + r : -1;      // inverse of valid_index (sgc_level_tail gathers by it)
     running += tot;
   }
   if (threadIdx.x == 0) totals[1] = running;
@@ -160,7 +161,6 @@ extern "C" int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
                                  int32_t *pair_cam, int32_t *pair_q, int32_t *slot,
                                  int32_t *vox_count, int32_t *valid_index, int32_t *totals,
                                  int32_t *workspace, sgc_stream_t stream) {
-  (void)workspace;
   if (!mask || !cam_count || !cam_offset || !pair_cam || !pair_q || !slot || !vox_count || !valid_index || !totals)
     return set_error(SGC_EINVAL, "sgc_compact_pairs: null pointer");
   if (N <= 0 || Nq <= 0 || N > 65535) return set_error(SGC_EINVAL, "sgc_compact_pairs: bad N/Nq");
@@ -170,6 +170,6 @@ extern "C" int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
   hipLaunchKernelGGL(fill_pairs_kernel, dim3(ceil_div(Nq, 256), N), dim3(256), 0, st, cam_offset, N, Nq, slot,
                      pair_cam, pair_q);
   hipLaunchKernelGGL(vox_count_kernel, dim3(ceil_div(Nq, 256)), dim3(256), 0, st, mask, N, Nq, vox_count);
-  hipLaunchKernelGGL(valid_index_kernel, dim3(1), dim3(1024), 0, st, vox_count, Nq, valid_index, totals);
+  hipLaunchKernelGGL(valid_index_kernel, dim3(1), dim3(1024), 0, st, vox_count, Nq, valid_index, totals, workspace);
   return check_launch("sgc_compact_pairs");
 }

@@ -333,48 +333,17 @@ __global__ __launch_bounds__(256) void layer_norm_rows_kernel(const float *__res
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float *xr = x + (int64_t)row * C;
   float v[VPL];
-  if (VPL % 4 == 0) {
+  ln_row_load<VPL>(x + (int64_t)row * C, lane, v);
+  float mean, rstd;
+  ln_row_stats<VPL>(v, eps, mean, rstd);
+  float o[VPL];
 #pragma unroll
-    for (int j = 0; j < VPL / 4; ++j) {
-      const float4 t = *reinterpret_cast<const float4 *>(xr + (j * 64 + lane) * 4);
-      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) v[j] = xr[j * 64 + lane];
+  for (int j = 0; j < VPL; ++j) {
+    const int c = ln_channel<VPL>(lane, j);
+    o[j] = ln_apply(v[j], mean, rstd, gamma[c], beta[c]);
   }
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) s += v[j];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / (float)C);
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) { const float d = v[j] - mean; q += d * d; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = rsqrtf(q * (1.0f / (float)C) + eps);
-  float *yr = y + (int64_t)row * C;
-  if (VPL % 4 == 0) {
-#pragma unroll
-    for (int j = 0; j < VPL / 4; ++j) {
-      const int c = (j * 64 + lane) * 4;
-      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
-      float4 o;
-      o.x = (v[4 * j] - mean) * rstd * g.x + b.x; o.y = (v[4 * j + 1] - mean) * rstd * g.y + b.y;
-      o.z = (v[4 * j + 2] - mean) * rstd * g.z + b.z; o.w = (v[4 * j + 3] - mean) * rstd * g.w + b.w;
-      *reinterpret_cast<float4 *>(yr + c) = o;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const int c = j * 64 + lane;
-      yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
-    }
-  }
+  ln_row_store<VPL>(y + (int64_t)row * C, lane, o);
 }
 
 // generic width (any C): one wave per row, strided loops

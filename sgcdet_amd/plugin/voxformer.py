@@ -247,8 +247,12 @@ class DeformCrossAttention_DFA3D(BaseModule):
         return plan
 
     # ---- inference: pair-list pipeline --------------------------------------------------
-    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False, static_counts=False):
+    def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False, static_counts=False, want_ctx=False):
         """query [1,Nq,C]; feat [N,S,C]; dist [N,S,D]; ref_cam [N,Nq,3]; mask_u8 [N,Nq].
+
+        ``want_ctx`` (zero queries, attention aggregation on the MFMA path): stop in front of the attention's out
+        projection and return ``(ctx [rows, C], row_of [Nq])`` -- VoxFormerLayer hands them to ``sgc_level_tail``, which
+        runs out_proj, the slot scatter, both LayerNorms and the FFN in one launch.
 
         ``static_counts``: nothing is read back to the host.  The pair / visible-voxel counts stay in the
         ``totals`` tensor of ``compact_pairs``; buffers are sized for the worst case (N*Nq pairs, Nq voxels), every
@@ -268,8 +272,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
         else:
             n_pairs, n_valid, _, _ = pc["totals"].tolist()       # the one host sync of this level
             totals = pairs_cnt = valid_cnt = None
-        out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
         if n_pairs == 0:
+            if want_ctx:                                 # no camera sees any voxel: every row_of entry is -1
+                return torch.zeros((1, C), dtype=feat.dtype, device=feat.device), pc["row_of"]
+            out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
             return out if zero_query else self.dropout(out) + query
         pair_cam, pair_q = pc["pair_cam"], pc["pair_q"]
         gemm = self._gemm_plan() if use_mfma else None
@@ -327,7 +333,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 q = F.linear(pooled, w[:C], b[:C])
                 kv = F.linear(per_pair, w[C:], b[C:])
             ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads, count=valid_cnt)
+            if want_ctx and use_mfma:
+                return ctx, pc["row_of"]
             pooled = gemm["o"](ctx, count=valid_cnt) if use_mfma else F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
+        out = torch.zeros((1, Nq, C), dtype=feat.dtype, device=feat.device)
         ops.scatter_rows(pooled, valid_index, out.view(Nq, C), count=valid_cnt)
         out = self.dropout(out)
         return out if zero_query else out + query
@@ -466,7 +475,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         mask_u8 = mask_u8 if mask_u8.dtype == torch.uint8 else mask_u8.to(torch.uint8)
         return self._forward_pairs(query, feat.contiguous(), dist.contiguous(), ref_cam.contiguous(),
                                    mask_u8.contiguous(), hw[0], hw[1], zero_query=bool(kwargs.get("zero_query")),
-                                   static_counts=bool(kwargs.get("static_counts")))
+                                   static_counts=bool(kwargs.get("static_counts")), want_ctx=bool(kwargs.get("want_ctx")))
 
 
 # ----------------------------------------------------------------------------------------
@@ -534,11 +543,60 @@ class VoxFormerLayer(MyCustomBaseTransformerLayer):
         super().__init__(attn_cfgs=attn_cfgs, operation_order=operation_order, norm_cfg=norm_cfg, **kwargs)
         self.fp16_enabled = False
 
+    # inference: ("cross_attn", "norm", "ffn", "norm") -- every SGCDet config -- with the attention's out projection, the
+    # slot scatter, both LayerNorms and the FFN in ONE launch (sgc_level_tail; bit-identical to the six launches it replaces)
+    fuse_tail = True
+
+    def _fused_tail(self, query, key, value, query_pos, key_pos, ref_3d, reference_points_cam, mask, key_padding_mask,
+                    spatial_shapes, level_start_index, kwargs):
+        from .conv_plan import CONV_MODE
+        if (not self.fuse_tail or torch.is_grad_enabled() or self.operation_order != ("cross_attn", "norm", "ffn", "norm")
+                or self.pre_norm or not kwargs.get("zero_query") or CONV_MODE != "bf16x3" or not query.is_cuda
+                or query_pos is not None):
+            return None
+        att, ffn, n1, n2 = self.attentions[0], self.ffns[0], self.norms[0], self.norms[1]
+        C = self.embed_dims
+        if not (isinstance(att, DeformCrossAttention_DFA3D) and att.deformable_attn and att.inter_view_aggregation == "attn"
+                and C % 32 == 0 and isinstance(n1, nn.LayerNorm) and isinstance(n2, nn.LayerNorm)
+                and n1.elementwise_affine and n2.elementwise_affine and tuple(n1.normalized_shape) == (C,)
+                and tuple(n2.normalized_shape) == (C,) and ffn.num_fcs == 2 and ffn.add_identity and len(ffn.layers) == 3
+                and isinstance(ffn.layers[0][1], nn.ReLU) and ffn.embed_dims == C
+                and _ops().level_tail_supported(C, ffn.feedforward_channels)):
+            return None
+        got = att(query, key, value, None, query_pos=None, key_pos=key_pos, reference_points=ref_3d,
+                  reference_points_cam=reference_points_cam, mask=mask, key_padding_mask=key_padding_mask,
+                  spatial_shapes=spatial_shapes, level_start_index=level_start_index, want_ctx=True, **kwargs)
+        if not isinstance(got, tuple):                  # the attention took a path without the shortcut: finish unfused
+            x = _layer_norm(n1, got)
+            return _layer_norm(n2, _ffn_forward(ffn, x, None))
+        ctx, row_of = got
+        ops = _ops()
+        fp = (module_fingerprint(att), module_fingerprint(ffn))
+        plan = self.__dict__.get("_tail_plan")
+        if plan is None or plan[0] != fp:                       # weights split to bf16 hi / lo and fragment-packed once
+            def packed(weight):
+                hi, lo = ops.split_bf16(weight.detach().float())
+                return ops.pack_b_fragments(hi), ops.pack_b_fragments(lo)
+            mha = att.attention_pooling
+            lin1, lin2 = ffn.layers[0][0], ffn.layers[1]
+            zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=ctx.device)      # noqa: E731
+            bias = lambda lin, n: lin.bias.detach().float().contiguous() if lin.bias is not None else zeros(n)   # noqa: E731
+            plan = (fp, packed(mha.out_proj.weight), bias(mha.out_proj, C), packed(lin1.weight), bias(lin1, lin1.out_features),
+                    packed(lin2.weight), bias(lin2, C))
+            self.__dict__["_tail_plan"] = plan
+        _, wo, bo, w1, b1, w2, b2 = plan
+        y = ops.level_tail(ctx, row_of, wo, bo, (n1.weight, n1.bias, n1.eps), w1, b1, w2, b2, (n2.weight, n2.bias, n2.eps))
+        return y.view(1, -1, C)
+
     def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None, attn_masks=None,
                 query_key_padding_mask=None, key_padding_mask=None, ref_2d=None, ref_3d=None,
                 reference_points_cam=None, mask=None, spatial_shapes=None, level_start_index=None,
                 prev_bev=None, **kwargs):
         """encoder.py:262-340: walk ``operation_order``; post-norm layers pass no residual."""
+        fused = self._fused_tail(query, key, value, query_pos, key_pos, ref_3d, reference_points_cam, mask, key_padding_mask,
+                                 spatial_shapes, level_start_index, kwargs)
+        if fused is not None:
+            return fused
         norm_i = attn_i = ffn_i = 0
         identity = query
         for op in self.operation_order:

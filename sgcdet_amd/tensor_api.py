@@ -252,6 +252,7 @@ class TensorOps:
         self._call("sgc_compact_pairs", mask, N, Nq, out["cam_count"], out["cam_offset"],
                    out["pair_cam"], out["pair_q"], out["slot"], out["vox_count"],
                    out["valid_index"], out["totals"], ws)
+        out["row_of"] = ws[:Nq]            # inverse of valid_index (-1: seen by no camera), left in the workspace
         return out
 
     # ---- 4. pair-list gathers ------------------------------------------------
@@ -518,6 +519,45 @@ class TensorOps:
                    stride, 1 if transposed else 0, int(relu), ws, ws_n,
                    _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
         return y, og
+
+    @staticmethod
+    def pack_b_fragments(w):
+        """[..., N, K] (N % 32 == 0, K % 16 == 0) -> the fragment-packed layout [N/32, K/16, 64, 8] of ``sgc_level_tail``:
+        packed[b, kk, l, j] = w[32 b + (l & 31), 16 kk + 8 (l >> 5) + j]."""
+        N, K = w.shape[-2], w.shape[-1]
+        if N % 32 or K % 16:
+            raise RuntimeError("pack_b_fragments: needs N % 32 == 0 and K % 16 == 0")
+        return w.reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N // 32, K // 16, 64, 8)
+
+    def level_tail_supported(self, C, F):
+        return bool(self.lib._dll.sgc_level_tail_supported(int(C), int(F)))
+
+    def level_tail(self, ctx, row_of, wo, bo, ln1, w1, b1, w2, b2, ln2, out=None):
+        """The tail of a VoxFormer level in one launch (``sgc_level_tail``): out_proj on the seen voxels (zero rows
+        elsewhere) -> LayerNorm -> FFN with identity -> LayerNorm.  ``wo`` / ``w1`` / ``w2``: (hi, lo) bf16 pairs of
+        ``split_bf16`` ([1, N, K] or [N, K]); they are fragment-packed here (``pack_b_fragments``) unless the caller passes
+        already packed 4-D tensors (a module packs once and caches).  ``ln1`` / ``ln2``: (gamma, beta, eps).  Returns [Nq, C]."""
+        self._check(ctx=ctx, row_of=row_of, bo=bo, b1=b1, b2=b2, out=out)
+        self._f32(ctx=ctx, bo=bo, b1=b1, b2=b2, out=out)
+        self._i32(row_of=row_of)
+        Nq, C = row_of.shape[0], ctx.shape[1]
+        def packed(name, pair, n, k):
+            hi, lo = pair
+            if hi.dtype != torch.bfloat16 or lo.dtype != torch.bfloat16 or hi.shape != lo.shape:
+                raise RuntimeError(f"level_tail: {name} must be a bfloat16 (hi, lo) pair")
+            if hi.dim() == 4 and tuple(hi.shape) == (n // 32, k // 16, 64, 8):
+                return hi, lo
+            if tuple(hi.shape[-2:]) != (n, k) or hi.numel() != n * k:
+                raise RuntimeError(f"level_tail: {name} must be [{n}, {k}] (or fragment-packed)")
+            return self.pack_b_fragments(hi.reshape(n, k)), self.pack_b_fragments(lo.reshape(n, k))
+        F = b1.shape[0]
+        wo, w1, w2 = packed("wo", wo, C, C), packed("w1", w1, F, C), packed("w2", w2, C, F)
+        y = out if out is not None else torch.empty((Nq, C), dtype=torch.float32, device=ctx.device)
+        if y.shape != (Nq, C):
+            raise RuntimeError("level_tail: bad `out` tensor")
+        self._call("sgc_level_tail", ctx, row_of, wo[0], wo[1], bo, ln1[0], ln1[1], float(ln1[2]), w1[0], w1[1], b1, w2[0], w2[1],
+                   b2, ln2[0], ln2[1], float(ln2[2]), y, Nq, C, F, _meta=dict(V=Nq, Cin=C, Cout=5 * C, taps=1, OV=Nq))
+        return y
 
     def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None):
         """y[r] = x[r] @ W^T + shift for the first ``count`` rows (int32 device tensor; None = all rows) of

@@ -794,3 +794,40 @@ def test_persistent_row_gemm_head_major_and_epilogues(N, S, cin, M, oracle_ops, 
         finally:
             gpu_ops.lib.call("sgc_set_tuning", b"rows_gemm", 1)
         assert torch.equal(y, y_tile), (relu, r is not None)
+
+
+@pytest.mark.parametrize("Nq,C,seen", [(400, 256, 0.7), (6401, 256, 0.95), (33, 256, 0.0), (1000, 128, 0.6), (31, 128, 1.0)])
+def test_level_tail_equals_the_six_launches_it_replaces(Nq, C, seen, oracle_ops, gpu_ops):
+    """sgc_level_tail (out_proj on the seen voxels + zero rows elsewhere -> LayerNorm -> FFN with identity -> LayerNorm in one
+    launch; reference: TU/deformable_cross_attention.py:826-837, TU/encoder.py:311-338, mmcv FFN) against (a) the CPU
+    oracle's composition, 1e-4 of the scale, and (b) the separate HIP launches it replaces -- bit for bit."""
+    F = 2 * C
+    g = torch.Generator().manual_seed(Nq + C)
+    vis = torch.rand(Nq, generator=g) < seen
+    row_of = torch.full((Nq,), -1, dtype=torch.int32)
+    row_of[vis] = torch.arange(int(vis.sum()), dtype=torch.int32)
+    n_valid = max(1, int(vis.sum()))
+    ctx = torch.randn(n_valid, C, generator=g)
+    mk = lambda o, i, s: torch.randn(o, i, generator=g) * s            # noqa: E731
+    wo, w1, w2 = mk(C, C, 0.08), mk(F, C, 0.08), mk(C, F, 0.06)
+    bo, b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(F, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ln1 = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, 1e-5)
+    ln2 = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, 1e-5)
+    sp = lambda w: gpu_ops.split_bf16(w.view(1, *w.shape))             # noqa: E731
+    so, s1, s2 = sp(wo), sp(w1), sp(w2)
+    cu = lambda t: t.cuda() if isinstance(t, torch.Tensor) else t      # noqa: E731
+    cup = lambda pr: tuple(cu(t) for t in pr)                          # noqa: E731
+    y = gpu_ops.level_tail(cu(ctx), cu(row_of), cup(so), cu(bo), cup(ln1), cup(s1), cu(b1), cup(s2), cu(b2), cup(ln2))
+    y_o = oracle_ops.level_tail(ctx, row_of, so, bo, ln1, s1, b1, s2, b2, ln2)
+    close(y, y_o, tol=1e-4)
+    # the six launches
+    valid_index = torch.nonzero(vis).view(-1).to(torch.int32).cuda()
+    x0 = torch.zeros(Nq, C, device="cuda")
+    if int(vis.sum()):
+        pooled = gpu_ops.linear_rows_bf16x3(cu(ctx), so[0].cuda(), so[1].cuda(), cu(bo))
+        gpu_ops.scatter_rows(pooled, valid_index, x0)
+    x1 = gpu_ops.layer_norm_rows(x0, cu(ln1[0]), cu(ln1[1]), ln1[2])
+    h, _ = gpu_ops.conv3d_cl_bf16x3(x1, s1[0].cuda(), s1[1].cuda(), (Nq, 1, 1), 1, 1, False, None, cu(b1), None, 2)
+    x2, _ = gpu_ops.conv3d_cl_bf16x3(h, s2[0].cuda(), s2[1].cuda(), (Nq, 1, 1), 1, 1, False, None, cu(b2), x1, 0)
+    want = gpu_ops.layer_norm_rows(x2, cu(ln2[0]), cu(ln2[1]), ln2[2])
+    assert torch.equal(y, want)
