@@ -283,7 +283,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         S = feat.shape[1]              # == H*W, or the camera stride of channels-last maps that kept the cropped rows
         Cm = C // da.num_heads
         tiled = None
-        if (self.deformable_attn and use_mfma and CONV_MODE == "bf16x3" and TILED_GATHER["enabled"] and da.num_levels == 1
+        if (self.deformable_attn and use_mfma and CONV_MODE in ("bf16x3", "f32") and TILED_GATHER["enabled"] and da.num_levels == 1
                 and da.num_points == 4 and Cm in (16, 32) and TILED_GATHER["min_pixels"] <= H * W < 32767
                 and dist.shape[-1] >= 2):
             tiled = TILED_GATHER["cm32" if Cm == 32 else "cm16"]
@@ -297,8 +297,14 @@ class DeformCrossAttention_DFA3D(BaseModule):
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
             if tiled is not None:
-                value = gemm["value"].headmajor(feat.view(N * S, C), N, S, da.num_heads,
-                                                out_dtype=torch.bfloat16 if TILED_GATHER["storage"] == "bf16" else torch.float32)
+                if CONV_MODE == "bf16x3":
+                    value = gemm["value"].headmajor(feat.view(N * S, C), N, S, da.num_heads,
+                                                    out_dtype=torch.bfloat16 if TILED_GATHER["storage"] == "bf16" else torch.float32)
+                else:
+                    # strict fp32 products: the fp32 GEMM kernel stores row-major; one permuting copy puts the value map into
+                    # the head-major layout the tiled gather stages its windows from (the copy costs ~70 us at the finest
+                    # config-2 level, the tiled gather saves ~180 against the wave kernel)
+                    value = gemm["value"](feat.view(N * S, C)).view(N, S, da.num_heads, Cm).permute(0, 2, 1, 3).contiguous()
                 raw = gemm["raw_hm"](geo, count=pairs_cnt)
                 del geo
                 per_pair = ops.pairs_deform_gather_tiled(value, dist, pc["pair_ref"], pc["bin_offset"], raw, H, W,

@@ -831,3 +831,55 @@ def test_level_tail_equals_the_six_launches_it_replaces(Nq, C, seen, oracle_ops,
     x2, _ = gpu_ops.conv3d_cl_bf16x3(h, s2[0].cuda(), s2[1].cuda(), (Nq, 1, 1), 1, 1, False, None, cu(b2), x1, 0)
     want = gpu_ops.layer_norm_rows(x2, cu(ln2[0]), cu(ln2[1]), ln2[2])
     assert torch.equal(y, want)
+
+
+@pytest.mark.timeout(1200)
+def test_reference_stress_shape_at_full_size():
+    """The reference's own stress shape (packages/3D-deformable-attention/unittest_DFA3D.py:43-56: value [6, 30825, 8, 32],
+    depth distributions of 112 bins, 4 levels 116x200 .. 15x25, 9 502 queries, 8 points -- the reference only checks it for
+    NaN) at FULL size against the OpenMP build of the oracle: fused forward, one-stage == two-stage (the reference's
+    MultiScale3DDeformableAttnFunction_fp32 runs the two _ext operators back to back), and the fused backward."""
+    import oracle
+    from sgcdet_amd import ext
+    oo, go_ = oracle.ops(omp=True), ext.ops()
+    levels = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    B, M, Cm, D, Q, P, L = 6, 8, 32, 112, 9502, 8, 4
+    S = sum(h * w for h, w in levels)
+    assert S == 30825
+    g = torch.Generator().manual_seed(2024)
+    shapes3 = torch.tensor([[h, w, D] for h, w in levels], dtype=torch.int64)
+    lsi = torch.tensor([0, 23200, 29000, 30450], dtype=torch.int64)
+    value = torch.randn(B, S, M, Cm, generator=g)
+    dist = torch.randn(B, S, M, D, generator=g).softmax(-1).contiguous()
+    loc = torch.rand(B, Q, M, L, P, 3, generator=g)
+    attn = torch.rand(B, Q, M, L, P, generator=g)
+    cu = lambda t: t.cuda()                                             # noqa: E731
+    out_c, sc_c = oo.dfa3d_forward(value, dist, shapes3, lsi, loc, attn, want_score=True)
+    out_g, sc_g = go_.dfa3d_forward(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), want_score=True)
+    close(out_g, out_c)
+    # per-corner depth scores: the sampled value is continuous across a pixel / bin border, its split over the four
+    # corners is not.  `loc * size - 0.5` is one fma on the GPU (as nvcc contracts it in the reference kernel) and two
+    # roundings in the oracle's plain C, so a sample within an ulp of a border (4 of 58 M here) may floor to the other
+    # side: those samples are compared through `out` only.
+    size = torch.stack([shapes3[:, 1], shapes3[:, 0], shapes3[:, 2]], -1).double()          # (W, H, D) per level
+    im = loc.double() * size.view(1, 1, 1, L, 1, 3) - 0.5
+    safe = ((im - im.round()).abs() > 1e-4).all(-1)                                           # [B,Q,M,L,P]
+    assert float((~safe).float().mean()) < 1e-3
+    close(sc_g.cpu()[safe], sc_c[safe])
+    # two-stage form through the _ext-compatible operators == the fused kernel
+    sc2 = ext.ms_depth_score_sample_forward(cu(dist), cu(shapes3), cu(lsi), cu(loc), im2col_step=32)
+    out2 = ext.wms_deform_attn_forward(cu(value), cu(shapes3)[:, :2].contiguous(), cu(lsi), cu(loc)[..., :2].contiguous(), cu(attn), sc2,
+                                       im2col_step=32)
+    assert torch.equal(sc2, sc_g)
+    close(out2, out_c)
+    go = torch.randn(B, Q, M * Cm, generator=g)
+    rc = oo.dfa3d_backward(value, dist, shapes3, lsi, loc, attn, go)
+    rg = go_.dfa3d_backward(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(go))
+    for name, a, b in zip(("grad_value", "grad_dist", "grad_loc", "grad_attn"), rg, rc):
+        a = a.cpu()
+        if name == "grad_loc":                     # the derivative w.r.t. the location is discontinuous across a border: see `safe`
+            a, b = a[safe], b[safe]
+        try:
+            close(a, b, tol=5e-5)
+        except AssertionError as e:
+            raise AssertionError(f"{name}: {e}")

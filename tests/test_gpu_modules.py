@@ -142,6 +142,49 @@ def test_hot_path_against_oracle(name, n_views):
             assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
 
 
+@pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 2), ("cfg2_scannet", 6)])
+def test_hot_path_in_strict_fp32_mode(name, n_views):
+    """The same scenes with --conv-mode f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every Linear and
+    convolution; the tiled gather behind a permuting copy): the volume must agree with the fp32 oracle at least as well
+    as in the default bf16x3 mode, and the near-tie flips of the finest cut are counted in both modes -- exact products
+    may not produce MORE flips than the 3-way split (AdaptiveSparseHead.py:9-13: top-k of fp32 scores)."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin.conv_plan import set_conv_mode
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from oracle.ref_path import RefPath
+    from oracle.compare import check_sparse_head
+    w = workload(name)
+    torch.manual_seed(7)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+    feats, dpt, meta = make_scene(n_views, w["embed_dims"], kind=w["kind"], seed=5)
+    rp = RefPath(det.voxel_head.state_dict(), dict(embed_dims=w["embed_dims"], n_voxels_list=w["n_voxels_list"],
+                                                   voxel_size_list=w["voxel_size_list"], topk_list=w["topk_list"],
+                                                   dbound=(0.2, 5.0), num_heads=8, num_points=4))
+    vol_c, valid_c, occ_c = rp.adaptive_sparse_head(feats, meta, depth_pyramid(dpt))
+    det = det.cuda()
+    det.use_graph = det.scene_graph = False
+    n_fin = w["n_voxels_list"][-1][0] * w["n_voxels_list"][-1][1] * w["n_voxels_list"][-1][2]
+    res = {}
+    try:
+        for mode in ("bf16x3", "f32"):
+            set_conv_mode(mode)
+            with torch.no_grad():
+                r = det.forward_features([f.cuda() for f in feats], [meta], dpt.cuda())
+            res[mode] = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"])
+            if mode == "f32":                       # neck + head in strict mode on the product's own volume when no voxel flipped
+                rp2 = _neck_head_oracle(det, w)
+                _check_neck_head_on(det, vol_c, rp2)
+    finally:
+        set_conv_mode("bf16x3")
+    assert res["f32"]["tie_flips"] <= res["bf16x3"]["tie_flips"] <= 4, res
+    assert res["f32"]["max_err"] <= max(res["bf16x3"]["max_err"] * 1.5, 2e-5 * res["f32"]["scale"]), res
+
+
 def _check_neck_head_on(det, vol_c, rp2):
     """FastIndoorImVoxelNeck + ImVoxelHeadV2 of the product (HIP convolutions) against the oracle's torch-CPU
     restatement on the SAME input volume: every head tensor within 1e-3 of its scale (north-star bar)."""
@@ -212,13 +255,44 @@ def test_full_view_count_scenes_against_the_oracle(name, img_hw):
     gap = topk_cut(aux[1]["occ"], w["topk_list"][0])[1]
     if gap > 2e-6:
         res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"])
-        assert res["tie_flips"] <= max(8, n_fin // 20000), res
     else:
-        import warnings
-        warnings.warn(f"{name}: coarse top-k gaps of seeds {gaps} are at rounding-noise level; end-to-end voxel comparison "
-                      "skipped, level-wise comparison done")
+        # every seed's coarse cut is at rounding-noise level (config 5: 9 216 of 36 864 candidates): which voxel is refined
+        # there is a coin toss on EITHER side.  The end-to-end comparison still runs -- with the oracle's coarse selection
+        # forced into the product's first top-k, everything downstream (level 1 on that selection, the second upsample +
+        # occupancy, the finest top-k, level 2, the scatter-adds) is the product's own and is compared voxel by voxel.
+        r = _forward_with_injected_coarse_selection(det, feats, meta, dpt, aux[1]["idx"])
+        assert int(r["valid"].sum()) == w["topk_list"][1]
+        res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"], coarse_injected=True)
+    assert res["tie_flips"] <= max(8, n_fin // 20000), res
     # (3) neck + head (HIP convolutions) on the oracle's volume
     _check_neck_head_on(det, vol_c, _neck_head_oracle(det, w))
+
+
+def _forward_with_injected_coarse_selection(det, feats, meta, dpt, coarse_idx):
+    """det.forward_features with the FIRST top-k of AdaptiveSparseHead replaced by ``coarse_idx`` (the oracle's ascending
+    selection); every other launch is the product's."""
+    from sgcdet_amd import ext
+    ops = ext.ops()
+    orig, calls = ops.topk_select, []
+
+    def patched(occ, k, **kw):
+        if not calls:
+            calls.append(k)
+            assert coarse_idx.numel() == k
+            return coarse_idx.to(device=occ.device, dtype=torch.int64).contiguous(), None, None
+        return orig(occ, k, **kw)
+
+    ops.topk_select = patched
+    graph = det.use_graph, det.scene_graph
+    det.use_graph = det.scene_graph = False
+    try:
+        with torch.no_grad():
+            r = det.forward_features([f.cuda() for f in feats], [meta], dpt.cuda())
+    finally:
+        del ops.topk_select                       # back to the class's method
+        det.use_graph, det.scene_graph = graph
+    assert len(calls) == 1
+    return r
 
 
 def _check_levels_against_oracle(head, feats, meta, dpts, aux, volumes_c):
