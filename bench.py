@@ -51,9 +51,11 @@ def parse():
                     help="HxW of the resized input images.  Default: 256x320 for cfg2_scannet (the size BASELINE.json's "
                          "north star quotes); `config` = the reference config's own 239x320 (ScanNet) / 240x320 (ARKit), "
                          "which is also the default of the other workloads")
-    ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="neck/head convolution arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
-                         "default) or exact fp32 products on the fp32 MFMA")
+    ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32", "bf16"],
+                    help="convolution / Linear arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
+                         "default, the headline), exact fp32 products on the fp32 MFMA, or -- opt-in reduced precision of "
+                         "BASELINE.json configs #2 / #5, its own line, never the headline -- plain bf16 products (operands "
+                         "rounded to bfloat16, fp32 accumulate: 1/3 of the matrix work)")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU: consecutive steps alternate over this many HIP streams so the host "
                          "syncs / launch gaps of one scene overlap the kernels of the other")
@@ -265,7 +267,7 @@ def main():
     det = build_path(w, device)
     if args.no_graph:
         args.graph = "none"
-    if args.graph == "scene" and args.conv_mode != "bf16x3":
+    if args.graph == "scene" and args.conv_mode == "f32":
         args.graph = "tail"                      # the device-count GEMM entry point exists for the bf16x3 path only
     det.masked_tail = os.environ.get("SGC_MASKED_TAIL", "0") == "1" or args.masked_tail
     from sgcdet_amd.plugin import voxformer as _vf
@@ -452,16 +454,17 @@ def main():
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
     roofline_mfma = None
-    cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode == "bf16x3" else "sgc_conv3d_cl_f32", [])
+    cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode != "f32" else "sgc_conv3d_cl_f32", [])
     cv = [(t, m) for t, m in cv if m.get("taps") == 27]
     if cv:
         flops = lambda m: 2.0 * m["taps"] * m["Cin"] * m["Cout"] * m["OV"]      # noqa: E731
         top = max(flops(m) for _, m in cv)
         big_c = [(t, m) for t, m in cv if flops(m) >= 0.99 * top]
         t_c = sum(t for t, _ in big_c) / len(big_c)
-        bf = args.conv_mode == "bf16x3"
+        bf = args.conv_mode != "f32"
+        nprod = 3 if args.conv_mode == "bf16x3" else 1
         peak = 2500.0 if bf else 157.0      # dense bf16 / fp32 MFMA peak (MI355X_MICROARCH.md)
-        issued = top * (3 if bf else 1) / t_c / 1e12
+        issued = top * nprod / t_c / 1e12
         m0 = big_c[0][1]
         roofline_mfma = dict(bound="mfma", achieved=round(issued, 1), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
                              kernel=("sgc::conv3d_halo_bf16x3_kernel" if bf else "sgc::conv3d_igemm_f32_kernel") +
@@ -472,7 +475,8 @@ def main():
                              avg_launch_us=round(t_c * 1e6, 1), launches=len(big_c),
                              note=("achieved = MFMA work actually issued (three bf16 products per fp32 multiply-add: lo*hi + "
                                    "hi*lo + hi*hi); fp32_equivalent_tflops = algorithmic FLOPs of the fp32 convolution / time")
-                             if bf else "exact fp32 products on v_mfma_f32_32x32x2_f32")
+                             if nprod == 3 else "one bf16 product per multiply-add (opt-in bf16 mode)" if bf
+                             else "exact fp32 products on v_mfma_f32_32x32x2_f32")
     # ---- the whole path against its own roofline (north star: "as a fraction of the HBM roofline"): compulsory gather bytes at
     #      8 TB/s + the matrix work actually issued at the dense MFMA peak, per scene, over the measured time per scene ----
     path_roofline = None
@@ -489,8 +493,8 @@ def main():
                 elif name == "sgc_pairs_geometry_sample":     # raw map + depth map + (u, v, z) per pair + output (B_gs)
                     gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * (12 + m["C"] * 4)
         gbytes /= n_e
-        bf = args.conv_mode == "bf16x3"
-        issued = gemm * (3 if bf else 1)
+        bf = args.conv_mode != "f32"
+        issued = gemm * (3 if args.conv_mode == "bf16x3" else 1)
         floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         path_roofline = dict(gather_mb_algorithmic=round(gbytes / 1e6, 1), gemm_gflop_algorithmic=round(gemm / 1e9, 1),
                              gemm_gflop_issued=round(issued / 1e9, 1), floor_ms_per_scene=round(floor_ms, 3),
@@ -538,7 +542,7 @@ def main():
         el_f = sgc_dist.max_over_ranks(time.perf_counter() - tf, device=device)
         strict = dict(value=round(world * n_f32 / el_f, 3), unit="scenes/sec", steps=n_f32, ms_per_step=round(el_f / n_f32 * 1e3, 3),
                       dtype="f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every convolution and Linear; wave-kernel gather)")
-        set_conv_mode("bf16x3")
+        set_conv_mode(args.conv_mode)
         det.scene_graph, det.use_graph = sg, ug
 
     if rank == 0:
@@ -553,7 +557,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16 storage (value map of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
+            "dtype": ("bf16 (opt-in reduced precision: every convolution / Linear with operands rounded to bfloat16, one MFMA product, "
+                      "fp32 accumulate" + ("; value map of the gather stored in bfloat16" if args.storage == "bf16" else "") +
+                      "; NOT parity-exact, not the headline)" if args.conv_mode == "bf16" else
+                      "bf16 storage (value map of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
                       if args.storage == "bf16" else
                       "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)"),
             "data": "synthetic",

@@ -59,6 +59,17 @@ int sgc_abi_version(void);
 /* Development knob (A/B of kernel variants in one process); keys: "fwd_variant" (0 block-barrier,
  * 1 wave-private gather).  Results never depend on it.                                        */
 int sgc_set_tuning(const char *key, int value);
+/* Arithmetic mode of every bf16 MFMA kernel of the library (sgc_conv3d_cl_bf16x3 and its 2-D / masked forms,
+ * sgc_linear_rows_*_bf16x3, sgc_level_tail):
+ *   3 (default) = fp32-faithful: operands split a = a_hi + a_lo in bf16, products a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32
+ *       accumulate -- agrees with exact fp32 products to ~1e-5 of the tensor scale (the parity mode, the headline);
+ *   1 = plain bf16: a_hi*b_hi only, i.e. both operands ROUNDED to bfloat16 (RNE), fp32 accumulate -- the opt-in
+ *       reduced-precision mode of BASELINE.json configs #2 ("bf16") / #5 ("fp16"; the reference's fp16 twin of the operator:
+ *       TU/multi_scale_3ddeformable_attn_function.py:353-428); 1/3 of the matrix work, ~2^-8 relative per operand.
+ * It changes results (that is its purpose) and is therefore NOT a sgc_set_tuning key.  Process-wide; returns SGC_EINVAL for
+ * any other value.  The w_lo arguments are ignored in mode 1. */
+int sgc_set_conv_products(int products);
+int sgc_get_conv_products(void);
 const char *sgc_last_error(void);
 /* "hip-gfx950" for the product library, "cpu-oracle" for oracle/libsgc_oracle.so */
 const char *sgc_backend(void);

@@ -66,6 +66,16 @@ static int fail(int code, const char *msg) {
 }
 
 int sgc_abi_version(void) { return SGC_ABI_VERSION; }
+
+/* arithmetic mode of the bf16 MFMA entry points (include/sgcdet_amd.h): 3 = fp32 truth of the 3-way split, 1 = both
+ * operands rounded to bfloat16 (RNE), products and sums in fp32 */
+static int g_conv_products = 3;
+int sgc_set_conv_products(int products) {
+  if (products != 1 && products != 3) return fail(SGC_EINVAL, "1 (bf16) or 3 (bf16x3)");
+  g_conv_products = products;
+  return SGC_OK;
+}
+int sgc_get_conv_products(void) { return g_conv_products; }
 int sgc_set_tuning(const char *key, int value) { (void)key; (void)value; return SGC_OK; }
 const char *sgc_last_error(void) { return g_err; }
 const char *sgc_backend(void) { return "cpu-oracle"; }
@@ -942,6 +952,8 @@ int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, i
   return 0;
 }
 
+static uint16_t f32_to_bf16_rne(float f);
+
 int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
@@ -953,10 +965,17 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const size_t n = (size_t)taps * Cout * Cin;
   float *w = (float *)malloc(n * sizeof(float));
   if (!w) return fail(SGC_EINVAL, "out of memory");
-  for (size_t i = 0; i < n; ++i) w[i] = bf16_to_f32(w_hi[i]) + bf16_to_f32(w_lo[i]);
-  const int rc = sgc_conv3d_cl_f32(x, w, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride,
+  for (size_t i = 0; i < n; ++i) w[i] = bf16_to_f32(w_hi[i]) + (g_conv_products == 3 ? bf16_to_f32(w_lo[i]) : 0.f);
+  float *xr = NULL;
+  if (g_conv_products == 1) {                     /* plain bf16 mode: the activations are rounded to bfloat16 as well */
+    const size_t nx = (size_t)ix * iy * iz * Cin;
+    xr = (float *)malloc(nx * sizeof(float));
+    if (!xr) { free(w); return fail(SGC_EINVAL, "out of memory"); }
+    for (size_t i = 0; i < nx; ++i) xr[i] = bf16_to_f32(f32_to_bf16_rne(x[i]));
+  }
+  const int rc = sgc_conv3d_cl_f32(xr ? xr : x, w, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride,
                                    transposed, relu, NULL, 0, stream);
-  free(w);
+  free(w); free(xr);
   return rc;
 }
 
@@ -981,7 +1000,9 @@ int sgc_conv2d_nhwc_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
               if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
               const float *xi = x + (((int64_t)n * H + hh) * W + ww) * Cin;
               const int64_t wo = ((int64_t)(ky * ksize + kx) * Cout + co) * Cin;
-              for (int ci = 0; ci < Cin; ++ci) acc += xi[ci] * (bf16_to_f32(w_hi[wo + ci]) + bf16_to_f32(w_lo[wo + ci]));
+              for (int ci = 0; ci < Cin; ++ci)
+                acc += (g_conv_products == 1 ? bf16_to_f32(f32_to_bf16_rne(xi[ci])) : xi[ci]) *
+                       (bf16_to_f32(w_hi[wo + ci]) + (g_conv_products == 3 ? bf16_to_f32(w_lo[wo + ci]) : 0.f));
             }
           float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
           if (relu == 2 && v < 0.f) v = 0.f;

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sgc_upsample2x_backward": [_p, _p] + [_i] * 4 + [_p],
     "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],
     "sgc_set_tuning": [C.c_char_p, _i],
+    "sgc_set_conv_products": [_i],
 }
 
 INTROSPECTION = {
@@ -66,6 +67,7 @@ INTROSPECTION = {
     "sgc_conv3d_wgrad_workspace_floats": (C.c_int64, [_i] * 7),
     "sgc_topk_select_workspace_bytes": (C.c_int64, [_i]),
     "sgc_level_tail_supported": (C.c_int, [_i] * 2),
+    "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
 }
 

@@ -29,6 +29,9 @@
 #include "common.hpp"
 
 namespace sgc {
+int g_conv_products = 3;     // NOT a tuning knob (it changes results; sgc_set_conv_products): 3 = fp32-faithful 3-way bf16 split
+                             // (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), 1 = plain bf16 (a_hi*b_hi only: operands rounded to bf16,
+                             // fp32 accumulate) -- the opt-in reduced-precision mode of BASELINE.json configs #2 / #5
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
@@ -243,7 +246,7 @@ struct ConvParamsB : ConvParams {
   const __bf16 *w_hi, *w_lo;   // [taps][Cout][Cin]
 };
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int NP = 3>   // NP: bf16 products per multiply-add (3 = fp32-faithful split, 1 = hi * hi only)
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const ConvParamsB p) {
   constexpr int NT = WM * WN * 64;                     // threads per workgroup (256 or 512)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       if (n < p.Cout) {
 #endif
         rbh[i] = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-        rbl[i] = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+        if constexpr (NP == 3) rbl[i] = *reinterpret_cast<const uint4 *>(p.w_lo + off);
       } else {
         rbh[i] = make_uint4(0, 0, 0, 0);
         rbl[i] = make_uint4(0, 0, 0, 0);
@@ -348,13 +351,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       }
       const int o = (r0 + AROWS * i) * LDKH + c4 * 4;
       *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
-      *reinterpret_cast<bf16x4 *>(a_lo + o) = l;
+      if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(a_lo + o) = l;
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int o = (br0 + BROWS_ * i) * LDKH + bc * 8;
       *reinterpret_cast<uint4 *>(b_hi + o) = rbh[i];
-      *reinterpret_cast<uint4 *>(b_lo + o) = rbl[i];
+      if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b_lo + o) = rbl[i];
     }
   };
 
@@ -383,12 +386,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + i * 32 * LDKH + kk * 16);
-        al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + i * 32 * LDKH + kk * 16);
+        if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + i * 32 * LDKH + kk * 16);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8 *>(b_hi + j * 32 * LDKH + kk * 16);
-        bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + j * 32 * LDKH + kk * 16);
+        if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + j * 32 * LDKH + kk * 16);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -401,8 +404,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #elif defined(SGC_DIAG_IG_REORDER)
           (void)0;
 #else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (NP == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #endif
         }
@@ -577,8 +582,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 unsigned long long *g_halo_stamp_buf = nullptr;
 #endif
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128>
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
+  static_assert(NP == 3 || !RING, "the single-product mode uses the staged form");
   static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
   constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             l[e] = (__bf16)(v[e] - (float)hb);
           }
           *reinterpret_cast<bf16x4 *>(A_hi + lrow * LDKH + c4 * 4) = h;
-          *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
+          if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
         }
       }
     };
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       if (bn_ok) {
         const int64_t off = ((int64_t)tap * p.Cout + n0 + bn) * p.Cin + cc * BK + bc * 8;
         rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-        rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+        if constexpr (NP == 3) rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
       } else {
         rbh = make_uint4(0, 0, 0, 0);
         rbl = make_uint4(0, 0, 0, 0);
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       if (tid >= BNV * 4) return;
       __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
       *reinterpret_cast<uint4 *>(b) = rbh;
-      *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
+      if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
     };
 
     int g = 0;                       // global step counter -> B buffer parity
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       for (int i = 0; i < 2; ++i) {
         const int o = (arow[i] + toff) * LDKH + fh * 8;
         ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-        al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+        if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
       }
     };
     read_A0(0);
@@ -954,20 +960,22 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             } else {
               const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
               ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-              al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+              if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
             }
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
-            bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+            if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              if constexpr (NP == 3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              }
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -1100,15 +1108,24 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3>
+static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st);
+
 template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
+  if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1>(p, OV, st);
+  return launch_halo_np<BX, BY, BZ, RING, BNV, 3>(p, OV, st);
+}
+
+template <int BX, int BY, int BZ, bool RING, int BNV, int NP>
+static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
 #if defined(SGC_HALO_STAMPS)
   p.stamps = g_halo_stamp_buf;
 #endif
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
   const size_t smem = halo_tab_offset(LROWS, RING) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
@@ -1124,7 +1141,7 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
@@ -1256,6 +1273,25 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   return conv_finish(p, OV, st);
 }
 
+// one launch of the tile-per-workgroup implicit-GEMM kernel in the arithmetic mode of g_conv_products
+static void launch_igemm(const ConvParamsB &p, bool narrow, dim3 grid, size_t smem, hipStream_t st) {
+  static std::atomic<uint64_t> done[6];
+  const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
+  if (g_conv_products == 1) {
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2, 1>, big, done[0]);
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 1>, big, done[1]);
+    if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1, 1>), grid, dim3(256), smem, st, p);
+    else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 1>), grid, dim3(512), smem, st, p);
+    else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2, 1>), grid, dim3(256), smem, st, p);
+    return;
+  }
+  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, done[2]);
+  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, done[3]);
+  if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
+  else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+}
+
 // Same contract with the weights pre-split on the host: w_hi = bf16(w), w_lo = bf16(w - float(w_hi)),
 // both [taps][Cout][Cin] bf16 (raw 16-bit patterns).
 static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
@@ -1308,18 +1344,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
-  {
-    static std::atomic<uint64_t> attr_done_a{0}, attr_done_b{0};
-    const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, attr_done_a);
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, attr_done_b);
-  }
-  if (narrow)
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
-  else if (g_tune_conv_waves == 8)
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
-  else
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+  launch_igemm(p, narrow, grid, smem, st);
   rc = check_launch("conv3d_igemm_bf16x3_kernel");
   if (rc) return rc;
   return conv_finish(p, OV, st);
@@ -1690,18 +1715,7 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   hipStream_t st = (hipStream_t)stream;
-  {
-    static std::atomic<uint64_t> attr_done_a{0}, attr_done_b{0};
-    const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, attr_done_a);
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, attr_done_b);
-  }
-  if (narrow)
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
-  else if (g_tune_conv_waves == 8)
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
-  else
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+  launch_igemm(p, narrow, grid, smem, st);
   return check_launch("conv3d_igemm_bf16x3_kernel (linear rows)");
 }
 
@@ -1730,3 +1744,12 @@ extern "C" int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *
 #if defined(SGC_HALO_STAMPS)
 extern "C" void sgc_diag_halo_stamp_buffer(unsigned long long *buf) { sgc::g_halo_stamp_buf = buf; }
 #endif
+
+// Arithmetic mode of every bf16 MFMA kernel of the library (convolutions, Linears, the fused level tail): 3 = the
+// fp32-faithful 3-way split (default), 1 = plain bf16 products.  Changes results (that is its purpose): not a tuning knob.
+extern "C" int sgc_set_conv_products(int products) {
+  if (products != 1 && products != 3) return set_error(SGC_EINVAL, "sgc_set_conv_products: 1 (bf16) or 3 (bf16x3, fp32-faithful)");
+  sgc::g_conv_products = products;
+  return SGC_OK;
+}
+extern "C" int sgc_get_conv_products(void) { return sgc::g_conv_products; }

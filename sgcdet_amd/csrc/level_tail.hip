@@ -45,7 +45,7 @@ struct LevelTailParams {
 
 constexpr int LT_ROWS = 32;
 
-template <int C>
+template <int C, int NP = 3>   // NP: bf16 products per multiply-add (conv3d.hip: g_conv_products)
 __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailParams p) {
   constexpr int NW = C / 32, NT = NW * 64, F = 2 * C;
   constexpr int KS = C / 16;                       // k-steps of a K chunk of C
@@ -83,9 +83,11 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rh, lane16, soff + kk * 1024, 0);
-      const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rl, lane16, soff + kk * 1024, 0);
       bh[kk] = __builtin_bit_cast(bf16x8, vh);
-      bl[kk] = __builtin_bit_cast(bf16x8, vl);
+      if constexpr (NP == 3) {
+        const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rl, lane16, soff + kk * 1024, 0);
+        bl[kk] = __builtin_bit_cast(bf16x8, vl);
+      }
     }
   };
   constexpr int PD = 3;                            // A fragments read PD k-steps ahead (see rows_gemm.hip)
@@ -95,16 +97,18 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
 #pragma unroll
     for (int kk = 0; kk < PD; ++kk) {
       ah[kk] = *reinterpret_cast<const bf16x8 *>(a_hi + kk * 16);
-      al[kk] = *reinterpret_cast<const bf16x8 *>(a_lo + kk * 16);
+      if constexpr (NP == 3) al[kk] = *reinterpret_cast<const bf16x8 *>(a_lo + kk * 16);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       if (kk + PD < KS) {
         ah[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_hi + (kk + PD) * 16);
-        al[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_lo + (kk + PD) * 16);
+        if constexpr (NP == 3) al[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_lo + (kk + PD) * 16);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
+      if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -243,11 +247,13 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
   }
 }
 
-template <int C>
+extern int g_conv_products;      // conv3d.hip
+
+template <int C, int NP>
 static int launch_level_tail(const LevelTailParams &p, hipStream_t st) {
   constexpr int smem = 2 * LT_ROWS * (C + 8) * 2 + LT_ROWS * C * 4 + 2 * LT_ROWS * (2 * C + 8) * 2 + LT_ROWS * 4;
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)level_tail_kernel<C>, smem, attr_done);
+  ensure_dynamic_lds((const void *)level_tail_kernel<C, NP>, smem, attr_done);
   const int ntiles = ceil_div(p.Nq, LT_ROWS);
   int cus = 256;
   {
@@ -261,7 +267,7 @@ static int launch_level_tail(const LevelTailParams &p, hipStream_t st) {
   }
   const int per_cu = C == 256 ? 1 : 2;
   const int grid = ntiles < cus * per_cu ? ntiles : cus * per_cu;
-  hipLaunchKernelGGL(level_tail_kernel<C>, dim3(grid), dim3(C * 2), smem, st, p);
+  hipLaunchKernelGGL((level_tail_kernel<C, NP>), dim3(grid), dim3(C * 2), smem, st, p);
   return check_launch("level_tail_kernel");
 }
 
@@ -293,5 +299,7 @@ extern "C" int sgc_level_tail(const float *ctx, const int32_t *row_of, const uin
   p.w2_hi = reinterpret_cast<const __bf16 *>(w2_hi); p.w2_lo = reinterpret_cast<const __bf16 *>(w2_lo); p.b2 = b2;
   p.ln2_g = ln2_gamma; p.ln2_b = ln2_beta; p.eps2 = eps2;
   p.out = out; p.Nq = Nq;
-  return C == 256 ? launch_level_tail<256>(p, (hipStream_t)stream) : launch_level_tail<128>(p, (hipStream_t)stream);
+  if (g_conv_products == 1)
+    return C == 256 ? launch_level_tail<256, 1>(p, (hipStream_t)stream) : launch_level_tail<128, 1>(p, (hipStream_t)stream);
+  return C == 256 ? launch_level_tail<256, 3>(p, (hipStream_t)stream) : launch_level_tail<128, 3>(p, (hipStream_t)stream);
 }

@@ -80,7 +80,7 @@ constexpr unsigned RG_OOB = 0xfffffff0u;    // a byte offset no buffer of < 4 Gi
 
 // EPI: 0 = y = acc * scale + shift (optional relu), row-major; 1 = head-major fp32 store (value_proj); 2 = row-major with
 // residual; 3 = head-major bf16 store (opt-in storage mode)
-template <int K, int NW, int DEPTH, int EPI>
+template <int K, int NW, int DEPTH, int EPI, int NP = 3>   // NP: bf16 products per multiply-add (conv3d.hip: g_conv_products)
 __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const RowsGemmParams p) {
   constexpr int NT = NW * 64;
   constexpr int KS = K / 16;                       // 16-deep k-steps
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       bh[kk] = *reinterpret_cast<const bf16x8 *>(wh + kk * 16);
-      bl[kk] = *reinterpret_cast<const bf16x8 *>(wl + kk * 16);
+      if constexpr (NP == 3) bl[kk] = *reinterpret_cast<const bf16x8 *>(wl + kk * 16);
     }
   }
   const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
         l[e] = (__bf16)(v[e] - (float)hb);
       }
       *reinterpret_cast<bf16x4 *>(a_hi + row * PITCH + c4 * 4) = h;
-      *reinterpret_cast<bf16x4 *>(a_lo + row * PITCH + c4 * 4) = l;
+      if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(a_lo + row * PITCH + c4 * 4) = l;
     }
   };
   // A fragments are read PD k-steps ahead of the MFMAs that use them (ring of PD + 1 register slots, static indices
@@ -178,16 +178,18 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
 #pragma unroll
     for (int kk = 0; kk < PD; ++kk) {
       ah[kk] = *reinterpret_cast<const bf16x8 *>(a_hi + kk * 16);
-      al[kk] = *reinterpret_cast<const bf16x8 *>(a_lo + kk * 16);
+      if constexpr (NP == 3) al[kk] = *reinterpret_cast<const bf16x8 *>(a_lo + kk * 16);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       if (kk + PD < KS) {
         ah[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_hi + (kk + PD) * 16);
-        al[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_lo + (kk + PD) * 16);
+        if constexpr (NP == 3) al[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_lo + (kk + PD) * 16);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
+      if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -365,13 +367,21 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
   }
 }
 
-template <int K, int NW, int DEPTH, int EPI>
-static int launch_rows_gemm_e(const RowsGemmParams &p, int grid, hipStream_t st) {
+extern int g_conv_products;      // conv3d.hip
+
+template <int K, int NW, int DEPTH, int EPI, int NP>
+static int launch_rows_gemm_np(const RowsGemmParams &p, int grid, hipStream_t st) {
   constexpr int smem = 2 * 2 * RG_ROWS * (K + 8) * (int)sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)rows_gemm_bf16x3_kernel<K, NW, DEPTH, EPI>, smem, attr_done);
-  hipLaunchKernelGGL((rows_gemm_bf16x3_kernel<K, NW, DEPTH, EPI>), dim3(grid), dim3(NW * 64), smem, st, p);
+  ensure_dynamic_lds((const void *)rows_gemm_bf16x3_kernel<K, NW, DEPTH, EPI, NP>, smem, attr_done);
+  hipLaunchKernelGGL((rows_gemm_bf16x3_kernel<K, NW, DEPTH, EPI, NP>), dim3(grid), dim3(NW * 64), smem, st, p);
   return check_launch("rows_gemm_bf16x3_kernel");
+}
+
+template <int K, int NW, int DEPTH, int EPI>
+static int launch_rows_gemm_e(const RowsGemmParams &p, int grid, hipStream_t st) {
+  if (g_conv_products == 1) return launch_rows_gemm_np<K, NW, 1, EPI, 1>(p, grid, st);      // single-product mode: the lockstep-1 form
+  return launch_rows_gemm_np<K, NW, DEPTH, EPI, 3>(p, grid, st);
 }
 
 template <int K, int NW, int DEPTH>

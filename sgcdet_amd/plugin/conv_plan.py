@@ -16,14 +16,22 @@ _PAD = 32
 
 # "bf16x3": fp32 operands split hi/lo onto the bf16 matrix cores (fp32-faithful to ~1e-5, default);
 # "f32": exact fp32 products on the fp32 MFMA (5x slower matrix pipe).  Both are tested against the oracle.
+# "bf16" (opt-in, BASELINE.json configs #2 / #5): the bf16x3 code path with ONE product per multiply-add -- both operands
+# rounded to bfloat16, fp32 accumulate (sgc_set_conv_products(1)); 1/3 of the matrix work, NOT parity-exact: its own bench
+# line, never the headline.  CONV_MODE stays "bf16x3" (same kernels, same launch sequence); CONV_PRODUCTS says which.
 CONV_MODE = "bf16x3"
+CONV_PRODUCTS = 3
 
 
 def set_conv_mode(mode):
-    global CONV_MODE
-    if mode not in ("bf16x3", "f32"):
+    global CONV_MODE, CONV_PRODUCTS
+    if mode not in ("bf16x3", "f32", "bf16"):
         raise ValueError(mode)
-    CONV_MODE = mode
+    CONV_MODE = "bf16x3" if mode == "bf16" else mode
+    CONV_PRODUCTS = 1 if mode == "bf16" else 3
+    import torch
+    if torch.cuda.is_available():
+        ext.ops().lib.call("sgc_set_conv_products", CONV_PRODUCTS)
 
 
 def _pad_to(n, m=_PAD):
