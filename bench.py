@@ -440,7 +440,7 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
         traffic, traffic_source = None, None
-        pmc_name = ("r02_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
+        pmc_name = ("r03_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if args.workload == "cfg2_scannet" and args.views in (None, 40) and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")

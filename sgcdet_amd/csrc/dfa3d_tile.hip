@@ -496,10 +496,13 @@ static bool diag_allowed() {
 }
 int g_tune_tile_nbuf = 0;       // value-window buffers; 2 = the next head's window lands while the current head is computed
                                 // (needs heads-per-workgroup > 1).  auto: 1
-int g_tune_tile_xcd = 0;        // 1: camera n's workgroups on XCD n % 8 (head-major, bins innermost); 0: (camera, bin, head) order,
-                                // i.e. head h on XCD h.  Interleaved A/B in one process (5 / 4 alternations): config 2 102.3 vs 102.6 us
-                                // (no difference), config 4 with the depth window in LDS 385 vs 420 us (8 % SLOWER) -- the 1.30x HBM
-                                // overfetch (the depth maps through 8 L2s) is not what bounds the kernel
+int g_tune_tile_xcd = -1;       // 1: camera n's workgroups on XCD n % 8 (head-major, bins innermost); 0: (camera, bin, head) order,
+                                // i.e. head h on XCD h; -1 (default): 1 at Cm = 32, 0 at Cm = 16.  Same time at config 2 (round 3,
+                                // alternated bench runs: 95.8 / 97.5 vs 96.6 / 96.4 us) but a third less traffic on the memory side
+                                // of the L2s: rocprofv3 --pmc FETCH_SIZE (doubled) + WRITE_SIZE = 435 MB -> 335 MB per launch = 1.30 ->
+                                // 1.00 x the algorithmic bytes (profiles/r03_gather_tile_pmc_hbm.json) -- with head h on XCD h every
+                                // camera's depth map was fetched through all eight L2s.  Config 4 (Cm = 16, depth window in LDS) was
+                                // 8 % slower with 1 (round 2: 385 vs 420 us) and keeps 0.
 int g_tune_tile_hg = 0;         // heads per workgroup.  auto: 1 (most workgroups: (camera, bin, head))
 
 }  // namespace sgc
@@ -613,7 +616,7 @@ extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf1
   p.hx = halo_x; p.hy = halo_y; p.smx = smx; p.smy = smy; p.diag = diag_allowed() ? g_tune_tile_diag : 0;
   p.tw = g.tw; p.th = g.th; p.dw = g.dw; p.dh = g.dh;
   p.HG = (g_tune_tile_hg > 0 && M % g_tune_tile_hg == 0) ? g_tune_tile_hg : 1;
-  p.xcd_map = g_tune_tile_xcd;
+  p.xcd_map = g_tune_tile_xcd >= 0 ? g_tune_tile_xcd : (Cm == 32 ? 1 : 0);
   if (g.lds > 160 * 1024)
     return set_error(SGC_EUNSUP, "sgc_pairs_deform_gather_tiled: window %dx%d needs %zu bytes of LDS", g.tw, g.th, g.lds);
   if (((int64_t)g.tw * g.th + 1) * (Cm / 4) >= 0x10000)
