@@ -520,6 +520,17 @@ int sgc_level_tail(const float *ctx, const int32_t *row_of, const uint16_t *wo_h
                    const float *b1, const uint16_t *w2_hi, const uint16_t *w2_lo, const float *b2, const float *ln2_gamma,
                    const float *ln2_beta, float eps2, float *out, int Nq, int C, int F, sgc_stream_t stream);
 
+/* Weight layout passes of the training step (row f-3), one launch each instead of a strided torch copy + three
+ * conversion kernels per layer and pass:
+ *   sgc_pack_conv_weight: parameter w [A][B][T] fp32 (nn.Conv3d [Cout][Cin][k^3]; nn.ConvTranspose3d [Cin][Cout][8];
+ *     nn.Linear T = 1) -> w_hi / w_lo [T][R][C] bf16 (hi = bf16_rne(w), lo = bf16_rne(w - hi)) with
+ *     out[t][r][c] = w[a][b][flip ? T-1-t : t], (a, b) = transpose ? (c, r) : (r, c); R >= rows, C >= cols: zero padding.
+ *   sgc_unpack_conv_wgrad: the inverse map without the split, for the weight gradient: dw_trc [T][R][C] fp32 -> dw [A][B][T]. */
+int sgc_pack_conv_weight(const float *w, uint16_t *w_hi, uint16_t *w_lo, int A, int B, int T, int R, int C, int transpose,
+                         int flip, sgc_stream_t stream);
+int sgc_unpack_conv_wgrad(const float *dw_trc, float *dw, int A, int B, int T, int R, int C, int transpose, int flip,
+                          sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 8. Post-processing
  * ------------------------------------------------------------------------- */

@@ -1251,6 +1251,39 @@ int sgc_level_tail(const float *ctx, const int32_t *row_of, const uint16_t *wo_h
   return rc;
 }
 
+/* weight layout passes of the training step (include/sgcdet_amd.h) */
+int sgc_pack_conv_weight(const float *w, uint16_t *w_hi, uint16_t *w_lo, int A, int B, int T, int R, int C, int transpose,
+                         int flip, sgc_stream_t stream) {
+  (void)stream;
+  if (!w || !w_hi || !w_lo) return fail(SGC_EINVAL, "null pointer");
+  if (A <= 0 || B <= 0 || T <= 0 || R < (transpose ? B : A) || C < (transpose ? A : B)) return fail(SGC_EINVAL, "bad size");
+  for (int t = 0; t < T; ++t)
+    for (int r = 0; r < R; ++r)
+      for (int c = 0; c < C; ++c) {
+        const int a = transpose ? c : r, b = transpose ? r : c;
+        const float v = (a < A && b < B) ? w[((int64_t)a * B + b) * T + (flip ? T - 1 - t : t)] : 0.f;
+        const uint16_t hb = f32_to_bf16_rne(v);
+        const int64_t o = ((int64_t)t * R + r) * C + c;
+        w_hi[o] = hb;
+        w_lo[o] = f32_to_bf16_rne(v - bf16_to_f32(hb));
+      }
+  return SGC_OK;
+}
+
+int sgc_unpack_conv_wgrad(const float *dw_trc, float *dw, int A, int B, int T, int R, int C, int transpose, int flip,
+                          sgc_stream_t stream) {
+  (void)stream;
+  if (!dw_trc || !dw) return fail(SGC_EINVAL, "null pointer");
+  if (A <= 0 || B <= 0 || T <= 0 || R < (transpose ? B : A) || C < (transpose ? A : B)) return fail(SGC_EINVAL, "bad size");
+  for (int a = 0; a < A; ++a)
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t) {
+        const int r = transpose ? b : a, c = transpose ? a : b;
+        dw[((int64_t)a * B + b) * T + (flip ? T - 1 - t : t)] = dw_trc[((int64_t)t * R + r) * C + c];
+      }
+  return SGC_OK;
+}
+
 /* ---- coarse-to-fine glue (AdaptiveSparseHead.py:64-82), torch upsample_trilinear3d index rule ---- */
 int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,
                        float *occ_or_null, int ix, int iy, int iz, int C, sgc_stream_t stream) {

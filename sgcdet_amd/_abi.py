@@ -57,6 +57,8 @@ SIGNATURES = {
     "sgc_scatter_add_rows": [_p] * 3 + [_i, _i, _p],
     "sgc_set_tuning": [C.c_char_p, _i],
     "sgc_set_conv_products": [_i],
+    "sgc_pack_conv_weight": [_p] * 3 + [_i] * 7 + [_p],
+    "sgc_unpack_conv_wgrad": [_p] * 2 + [_i] * 7 + [_p],
 }
 
 INTROSPECTION = {

@@ -159,8 +159,8 @@ class ChannelsLastConv3dFunction(Function):
     def forward(ctx, x, weight, grid, ksize, stride):
         ops = ext.ops()
         cout, cin = weight.shape[:2]
-        wt = _pad_cols(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(ksize ** 3, cout, cin).transpose(1, 2), 4).transpose(1, 2)
-        hi, lo = ops.split_bf16(wt.contiguous())
+        # parameter [Cout, Cin, k, k, k] -> the kernel's [taps, Cout (multiple of 4), Cin] bf16 hi / lo planes in ONE launch
+        hi, lo = ops.pack_conv_weight(weight.detach().float(), pad_rows=4)
         x = x.float().contiguous()
         y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, ksize, stride)
         ctx.save_for_backward(x, weight)
@@ -179,8 +179,7 @@ class ChannelsLastConv3dFunction(Function):
         if ctx.needs_input_grad[0]:
             # dx[i] = sum_d dy[(i - d + pad) / stride] W[d]^T: a stride-1 convolution of (zero-interleaved) dy with the
             # mirrored taps; its "input channels" are Cout, padded to the kernel's multiple of 32
-            wt = weight.detach().float().flip(2, 3, 4).permute(2, 3, 4, 1, 0).reshape(ksize ** 3, cin, cout)
-            hi, lo = ops.split_bf16(_pad_cols(wt, 32).contiguous())
+            hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True, flip=True, pad_cols=32)
             g = _pad_cols(dy, 32)
             if stride == 2:
                 up = torch.zeros((grid[0], grid[1], grid[2], g.shape[1]), dtype=torch.float32, device=dy.device)
@@ -189,7 +188,7 @@ class ChannelsLastConv3dFunction(Function):
             dx, _ = ops.conv3d_cl_bf16x3(g.contiguous(), hi, lo, grid, ksize, 1)
         if ctx.needs_input_grad[1]:
             dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), grid, ksize, stride)        # [taps, cout_p, cin]
-            dw = dwk[:, :cout].permute(1, 2, 0).reshape(cout, cin, ksize, ksize, ksize).to(weight.dtype)
+            dw = ops.unpack_conv_wgrad(dwk, weight.shape).to(weight.dtype)
         return dx, dw, None, None, None
 
 
@@ -203,7 +202,7 @@ class ChannelsLastConvTranspose3dFunction(Function):
     def forward(ctx, x, weight, grid):
         ops = ext.ops()
         cin, cout = weight.shape[:2]
-        hi, lo = ops.split_bf16(weight.detach().float().permute(2, 3, 4, 1, 0).reshape(8, cout, cin).contiguous())
+        hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True)            # [Cin, Cout, 8] -> [8, Cout, Cin]
         x = x.float().contiguous()
         y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, 2, 2, True)
         ctx.save_for_backward(x, weight)
@@ -220,11 +219,11 @@ class ChannelsLastConvTranspose3dFunction(Function):
         dy = dy.float().contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            hi, lo = ops.split_bf16(weight.detach().float().permute(2, 3, 4, 0, 1).reshape(8, cin, cout).contiguous())
+            hi, lo = ops.pack_conv_weight(weight.detach().float())                        # [Cin, Cout, 8] -> [8, Cin, Cout]
             dx, _ = ops.conv3d_cl_bf16x3(dy, hi, lo, og, 2, 2)                  # dx[x] = sum_p dy[2x + p] W[:, :, p]^T
         if ctx.needs_input_grad[1]:
             dwk = ops.conv3d_wgrad_bf16x3(dy, x, og, 2, 2)                      # [8, cin, cout]
-            dw = dwk.permute(1, 2, 0).reshape(cin, cout, 2, 2, 2).to(weight.dtype)
+            dw = ops.unpack_conv_wgrad(dwk, weight.shape).to(weight.dtype)
         return dx, dw, None
 
 
@@ -239,8 +238,7 @@ class LinearRowsFunction(Function):
         ops = ext.ops()
         cout, cin = weight.shape
         x = x.float().contiguous()
-        wp = _pad_cols(weight.detach().float().t(), 4).t().contiguous()                 # Cout padded to a multiple of 4
-        hi, lo = ops.split_bf16(wp.view(1, wp.shape[0], cin))
+        hi, lo = ops.pack_conv_weight(weight.detach().float(), pad_rows=4)            # [1, Cout (multiple of 4), Cin]
         shift = None if bias is None else _pad_cols(bias.detach().float().view(1, -1), 4).view(-1).contiguous()
         y = ops.linear_rows_bf16x3(x, hi, lo, shift)
         ctx.save_for_backward(x, weight)
@@ -256,8 +254,7 @@ class LinearRowsFunction(Function):
         dy = dy.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = _pad_cols(weight.detach().float().t().contiguous(), 32)               # [Cin, Cout -> mult of 32]: dx = dy @ W
-            hi, lo = ops.split_bf16(wt.view(1, cin, wt.shape[1]).contiguous())
+            hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True, pad_cols=32)   # [1, Cin, Cout -> mult of 32]: dx = dy @ W
             dx = ops.linear_rows_bf16x3(_pad_cols(dy, 32).contiguous(), hi, lo, None)
         if ctx.needs_input_grad[1]:
             dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), (x.shape[0], 1, 1), 1, 1)     # [1, cout_p, cin]

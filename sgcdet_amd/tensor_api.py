@@ -599,6 +599,34 @@ class TensorOps:
                    _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=taps, OV=rows))
         return y
 
+    def pack_conv_weight(self, w, transpose=False, flip=False, pad_rows=1, pad_cols=1):
+        """Module parameter [A, B, *taps] (Conv3d [Cout, Cin, k, k, k], ConvTranspose3d [Cin, Cout, 2, 2, 2], Linear [Cout, Cin])
+        -> (hi, lo) bf16 [T, R, C] in the kernels' layout: rows = A (or B with ``transpose``), taps mirrored with ``flip``,
+        R / C zero-padded to multiples of ``pad_rows`` / ``pad_cols`` (``sgc_pack_conv_weight``)."""
+        self._check(w=w)
+        self._f32(w=w)
+        w = w.contiguous()
+        A, B = w.shape[0], w.shape[1]
+        T = w.numel() // (A * B)
+        rows, cols = (B, A) if transpose else (A, B)
+        R, Cc = -(-rows // pad_rows) * pad_rows, -(-cols // pad_cols) * pad_cols
+        hi = torch.empty((T, R, Cc), dtype=torch.bfloat16, device=w.device)
+        lo = torch.empty_like(hi)
+        self._call("sgc_pack_conv_weight", w, hi, lo, A, B, T, R, Cc, int(bool(transpose)), int(bool(flip)))
+        return hi, lo
+
+    def unpack_conv_wgrad(self, dw_trc, shape, transpose=False, flip=False):
+        """[T, R, C] fp32 (``conv3d_wgrad_bf16x3``) -> the parameter's layout ``shape`` = [A, B, *taps] (``sgc_unpack_conv_wgrad``)."""
+        self._check(dw_trc=dw_trc)
+        self._f32(dw_trc=dw_trc)
+        T, R, Cc = dw_trc.shape
+        A, B = shape[0], shape[1]
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=dw_trc.device)
+        if out.numel() != A * B * T:
+            raise RuntimeError("unpack_conv_wgrad: tap count mismatch")
+        self._call("sgc_unpack_conv_wgrad", dw_trc.contiguous(), out, A, B, T, R, Cc, int(bool(transpose)), int(bool(flip)))
+        return out
+
     def conv3d_wgrad_bf16x3(self, x, dy, grid, ksize, stride=1):
         """dW [ksize^3, Cout, Cin] of the channels-last convolution: x [IV, Cin] on ``grid``, dy [OV, Cout] on the output
         grid (``sgc_conv3d_wgrad_bf16x3``; ksize 2 = stride 2, no padding)."""

@@ -332,3 +332,26 @@ def test_plain_bf16_mode_against_the_oracle_and_its_error_bound(oracle_ops, gpu_
     finally:
         gpu_ops.lib.call("sgc_set_conv_products", 3)
         oracle_ops.lib.call("sgc_set_conv_products", 3)
+
+
+@pytest.mark.parametrize("shape", [(96, 64, 3, 3, 3), (70, 33, 3, 3, 3), (64, 128, 2, 2, 2), (130, 256), (28, 128, 3, 3, 3)])
+def test_weight_pack_and_unpack_equal_their_torch_formulation(shape, oracle_ops, gpu_ops):
+    """sgc_pack_conv_weight / sgc_unpack_conv_wgrad (the training step's layout passes, one launch each) == the permute /
+    flip / pad / split chain of torch ops they replace, bit for bit, on the GPU and in the oracle."""
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(*shape, generator=g)
+    A, B = shape[0], shape[1]
+    T = w.numel() // (A * B)
+    w3 = w.reshape(A, B, T)
+    for transpose, flip, pr, pc in ((False, False, 4, 1), (True, True, 1, 32), (True, False, 1, 1), (False, False, 1, 32)):
+        src = w3.flip(2) if flip else w3
+        ref = src.permute(2, 1, 0) if transpose else src.permute(2, 0, 1)              # [T, R, C]
+        R, C = -(-ref.shape[1] // pr) * pr, -(-ref.shape[2] // pc) * pc
+        full = torch.zeros(T, R, C)
+        full[:, :ref.shape[1], :ref.shape[2]] = ref
+        hi_ref, lo_ref = gpu_ops.split_bf16(full)
+        for ops, dev in ((gpu_ops, "cuda"), (oracle_ops, "cpu")):
+            hi, lo = ops.pack_conv_weight(w.to(dev), transpose=transpose, flip=flip, pad_rows=pr, pad_cols=pc)
+            assert hi.shape == (T, R, C) and torch.equal(hi.cpu(), hi_ref) and torch.equal(lo.cpu(), lo_ref), (transpose, flip, dev)
+            back = ops.unpack_conv_wgrad(full.to(dev), w.shape, transpose=transpose, flip=flip)
+            assert torch.equal(back.cpu(), w), (transpose, flip, dev)
