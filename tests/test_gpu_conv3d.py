@@ -355,3 +355,29 @@ def test_weight_pack_and_unpack_equal_their_torch_formulation(shape, oracle_ops,
             assert hi.shape == (T, R, C) and torch.equal(hi.cpu(), hi_ref) and torch.equal(lo.cpu(), lo_ref), (transpose, flip, dev)
             back = ops.unpack_conv_wgrad(full.to(dev), w.shape, transpose=transpose, flip=flip)
             assert torch.equal(back.cpu(), w), (transpose, flip, dev)
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,s,tr", [(64, 128, (8, 8, 8), 3, 2, False), (64, 128, (10, 10, 4), 3, 1, False),
+                                                  (512, 128, (8, 8, 4), 2, 2, True), (512, 256, (20, 10, 2), 1, 1, False)])
+def test_big_tile_form_of_the_implicit_gemm_against_oracle_and_tile_kernel(cin, cout, grid, k, s, tr, oracle_ops, gpu_ops):
+    """conv3d_igemm_big_kernel (512 x 128 tiles, K range split evenly over workgroups; option `conv_big`, not the default --
+    measured slower, csrc/conv3d.hip) stays a tested variant: oracle within the bf16x3 bound and the same layers on the
+    128 x 128 tile kernel within fp32 summation noise (the K splits differ, so the partial sums are added in another order)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    V = grid[0] * grid[1] * grid[2]
+    taps = 8 if tr else k ** 3
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(taps, cout, cin, generator=g) * (1.0 / (cin * (1 if tr else taps)) ** 0.5)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    y_o, og = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, k, s, tr, sc, sh, None, 1)
+    y_t, _ = gpu_ops.conv3d_cl_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), grid, k, s, tr, sc.cuda(), sh.cuda(), None, 1)
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"conv_big", 1)
+        y_b, og_b = gpu_ops.conv3d_cl_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), grid, k, s, tr, sc.cuda(), sh.cuda(), None, 1)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"conv_big", 0)
+    assert og_b == og
+    scale = max(1.0, float(y_o.abs().max()))
+    assert float((y_b.cpu() - y_o).abs().max()) <= 1e-4 * scale
+    assert float((y_b - y_t).abs().max()) <= 2e-5 * scale
