@@ -324,6 +324,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    lib_calls_per_scene = None
     eager_events = not det.scene_graph      # kernels inside a replayed scene graph cannot carry host-side events
     if eager_events:
         ops.event_log = []
@@ -366,12 +367,14 @@ def main():
         tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
         ops.event_names = None if args.breakdown else PATH_KERNELS
+        calls0 = ops.n_calls
         with torch.no_grad():
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
                 det.forward_features(feats, metas, dpt)
                 torch.cuda.synchronize()
         log, ops.event_log = ops.event_log, None
+        lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
         det.scene_graph, det.use_graph = True, tail_graph
         roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                          "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
@@ -528,7 +531,7 @@ def main():
         sg, ug = det.scene_graph, det.use_graph
         det.scene_graph, det.use_graph = False, True        # eager view transform + hipGraph tail (no device-count GEMMs in f32)
         n_f32 = max(4, min(args.steps, 10))
-        for i in range(3):
+        for i in range(max(3, n_scenes * max(1, args.streams))):     # every (scene, stream) tail graph of this mode captured before the clock starts
             step(i)
         torch.cuda.synchronize()
         if dist is not None:
@@ -541,7 +544,7 @@ def main():
             dist.barrier()
         el_f = sgc_dist.max_over_ranks(time.perf_counter() - tf, device=device)
         strict = dict(value=round(world * n_f32 / el_f, 3), unit="scenes/sec", steps=n_f32, ms_per_step=round(el_f / n_f32 * 1e3, 3),
-                      dtype="f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every convolution and Linear; wave-kernel gather)")
+                      dtype="f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every convolution and Linear; LDS-tiled gather behind a permuting copy of the value map)")
         set_conv_mode(args.conv_mode)
         det.scene_graph, det.use_graph = sg, ug
 
@@ -573,7 +576,8 @@ def main():
                        "launch": {"scene": "one hipGraph replay per scene (device-side pair counts, no host read-back)",
                                   "tail": "eager view transform (one host read-back per level) + hipGraph replay of neck/head",
                                   "none": "eager"}[args.graph],
-                       "sharding": "scenes across ranks, no collective"},
+                       "sharding": "scenes across ranks, no collective",
+                       "library_calls_per_scene": lib_calls_per_scene},
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
             "path_roofline": path_roofline,

@@ -68,7 +68,10 @@ class TensorOps:
             if t is not None and t.dtype != torch.int32:
                 raise RuntimeError(f"{name} must be int32 (got {t.dtype})")
 
+    n_calls = 0          # library entry points called through this front end (bench.py reports calls per scene)
+
     def _call(self, name, *args, _meta=None):
+        self.n_calls += 1
         ptrs = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
         if self.device_type == "cuda":
             dev = next(a.device for a in args if isinstance(a, torch.Tensor))
