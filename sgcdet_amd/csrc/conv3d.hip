@@ -42,11 +42,19 @@ int g_tune_conv_big = 0;     // 1: the 512 x 128 big-tile implicit GEMM (conv3d_
                              // these layers need is activations split ONCE by their producer, not a bigger tile.
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
-int g_tune_halo_brick = 0;        // 0: brick shape by depth (4x4x16 / 4x8x8 / 8x8x4), 1: prefer 4x8x8, 2: force 8x8x4
+int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4x8x8, 2: force 8x8x4, 3: the round-2 rule (4x4x16 at depth >= 16).
+                                  // Round 3, interleaved A/B of the three shapes on the 40x40x16 and 80x80x32 layers (bit-identical
+                                  // results): 8x8x4 is 1.5 - 2.5 % faster than 4x4x16 (236 vs 241 us, 129.5 vs 133, 534 vs 546;
+                                  // 600 halo rows instead of 648) -> it is the choice wherever it tiles the grid exactly
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_narrow = 1;       // halo kernel: 64-column tiles for layers with <= 64 output channels
+int g_tune_halo_nb = 2;           // halo kernel: weight buffers of the staged form (3 = staged two taps ahead; 8x8x4 brick only, see the kernel).
+                                  // Round 3, interleaved A/B on the 8x8x4 brick, bit-identical: 3 buffers 246 - 249 vs 236 - 239 us (2 buffers);
+                                  // with the fragment reads pinned by scheduling barriers (second k-half before the first half's MFMAs, next
+                                  // tap's first half before the second half's) 252 - 254 us with 2 buffers, 254 - 255 with 3: the compiler's own
+                                  // schedule of the plain loop is the fastest of the four -> 2 stays
 int g_tune_halo_ring = 0;         // halo kernel: 0 weights staged through registers (default), 1 LDS-DMA ring on the 256 -> 256 layers,
                                   // 2 ring everywhere.  Interleaved A/B, 8 rounds x 40 launches of the 90-GF layer on two boxes:
                                   // staged 229.7 / 231.3 us, ring 237.2 / 238.1 us once the clocks have settled (the ring only wins the
@@ -760,9 +768,9 @@ __host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ 
 constexpr int HALO_AP = 32;              // ring form: bf16 per LDS row (64 B, no padding; 16-byte chunks XOR-swizzled by the row)
 constexpr int HALO_NST = 4;              // ring form: weight stages in LDS = 2 groups of 2 taps (one barrier per group)
 constexpr int HALO_BSTAGE = 2 * 128 * HALO_AP * 2;   // bytes of one weight stage: hi|lo planes of [128][32] bf16 = 16 KB
-__host__ __device__ constexpr size_t halo_tab_offset(int lrows, bool ring) {
+__host__ __device__ constexpr size_t halo_tab_offset(int lrows, bool ring, int nb = 2) {
   const size_t planes = ring ? (size_t)2 * lrows * HALO_AP * sizeof(uint16_t) + (size_t)HALO_NST * HALO_BSTAGE
-                             : (size_t)(2 * lrows + 4 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
+                             : (size_t)(2 * lrows + 2 * nb * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + nb x B hi|lo
   const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                    // epilogue tile [256][BNV + 8]
   return planes > stage ? planes : stage;
 }
@@ -778,9 +786,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 unsigned long long *g_halo_stamp_buf = nullptr;
 #endif
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3>
+// NB: weight buffers of the staged form.  2: a tap's weights are written while the previous tap is multiplied and can only be
+// read after the barrier that publishes them.  3 (round 3, where the LDS holds it: the 8x8x4 brick): weights are staged TWO
+// taps ahead, so the buffer of tap t + 1 is complete while tap t is multiplied and its first-k-half B fragments are read
+// BEFORE the barrier, next to the A fragments -- no LDS round trip at the head of a tap.  Same k order: bit-identical.
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   static_assert(NP == 3 || !RING, "the single-product mode uses the staged form");
+  static_assert(NB == 2 || !RING, "three weight buffers belong to the staged form");
   static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
   constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
@@ -793,7 +806,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
   // [8 tiles][32 lanes], behind both the staging planes and the epilogue's output tile that later overlays them
-  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, RING));
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, RING, NB));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -1113,17 +1126,24 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
     };
 
-    int g = 0;                       // global step counter -> B buffer parity
+    int g = 0;                       // global step counter -> B buffer
+    const int steps_total = (c_hi - c_lo) * 27;
+    auto step_tap = [&](int st) { return st % 27; };
+    auto step_cc = [&](int st) { return c_lo + st / 27; };
     load_A(c_lo);
     load_B(0, c_lo);
     store_A();
     store_B(0);
+    if constexpr (NB == 3) {
+      if (steps_total > 1) { load_B(step_tap(1), step_cc(1)); store_B(1); }
+    }
     __syncthreads();
     // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
     // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
     // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
     //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
     bf16x8 ah_n[2] = {}, al_n[2] = {};
+    bf16x8 bh_n[TN] = {}, bl_n[TN] = {};          // NB == 3: first-k-half B fragments of the next tap
     auto read_A0 = [&](int tap) {
       const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
       const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
@@ -1134,17 +1154,31 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
       }
     };
+    auto read_B0 = [&](int buf) {
+      const __bf16 *b = Bbase + buf * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh_n[j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * LDKH);
+        if constexpr (NP == 3) bl_n[j] = *reinterpret_cast<const bf16x8 *>(b + B_PLANE + j * 32 * LDKH);
+      }
+    };
     read_A0(0);
+    if constexpr (NB == 3) read_B0(0);
+    int bcur = 0;                    // buffer of the tap being multiplied (NB == 3: g % 3 without the division)
     for (int cc = c_lo; cc < c_hi; ++cc) {
       for (int tap = 0; tap < 27; ++tap, ++g) {
         const bool last_tap = tap == 26;
         const bool more = !last_tap || cc + 1 < c_hi;
-        if (more) load_B(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc);
+        const int ahead = NB == 3 ? 2 : 1;                       // taps the weight staging runs ahead
+        const bool more_b = g + ahead < steps_total;
+        if (more_b) load_B(step_tap(g + ahead), step_cc(g + ahead));
         if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
-        const __bf16 *bh_ = Bbase + (g & 1) * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
+        const int bsel = NB == 3 ? bcur : (g & 1);
+        const __bf16 *bh_ = Bbase + bsel * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
         const __bf16 *bl_ = bh_ + B_PLANE;
+        const int bnext = NB == 3 ? (bcur == 2 ? 0 : bcur + 1) : 0;
         if (wave_live) {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -1161,8 +1195,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
-            if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+            if (NB == 3 && kk == 0) {
+              bh[j] = bh_n[j]; bl[j] = bl_n[j];
+            } else {
+              bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
+              if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+            }
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -1176,8 +1214,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             }
         }
         if (!last_tap) read_A0(tap + 1);
+        if constexpr (NB == 3) { if (more) read_B0(bnext); }     // published by the barrier that ended the previous tap
         }
-        if (more) store_B((g + 1) & 1);
+        if (more_b) store_B(NB == 3 ? (bnext == 2 ? 0 : bnext + 1) : ((g + 1) & 1));
+        bcur = bnext;
         __syncthreads();
       }
       if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
@@ -1297,6 +1337,15 @@ static int zero_fill(float *y, int64_t n, hipStream_t st) {      // n floats, n 
 //  matters: 203 vs 164 us on the 188,800-row Linear, 168 vs 140 us on the 400-voxel 1024-channel layer; it only wins
 //  on the 6,400-row Linears (16 vs 20 us).  The exposed regs -> LDS phase between its two barriers costs more than
 //  the deeper loads hide.)
+// brick of the halo kernel for a grid: 0 = 4x4x16, 1 = 4x8x8, 2 = 8x8x4
+static int halo_brick_shape(int gx, int gy, int gz) {
+  if (g_tune_halo_brick == 2) return 2;
+  if (g_tune_halo_brick == 0 && gz >= 16 && gx % 8 == 0 && gy % 8 == 0 && gz % 4 == 0) return 2;
+  if (gz >= 16 && (g_tune_halo_brick == 0 || g_tune_halo_brick == 3)) return 0;
+  if (gz >= 8) return 1;
+  return 2;
+}
+
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;
@@ -1304,24 +1353,32 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3>
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2>
 static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st);
 
 template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
+  // three weight buffers where the LDS holds them: the 8x8x4 brick (157.9 KB); never with the LDS-DMA ring
+  constexpr bool nb3_fits = halo_tab_offset((BX + 2) * (BY + 2) * halo_pitch(BZ), false, 3) + 512 <= 160 * 1024;
+  if constexpr (nb3_fits && !RING) {
+    if (g_tune_halo_nb == 3) {
+      if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1, 3>(p, OV, st);
+      return launch_halo_np<BX, BY, BZ, false, BNV, 3, 3>(p, OV, st);
+    }
+  }
   if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1>(p, OV, st);
   return launch_halo_np<BX, BY, BZ, RING, BNV, 3>(p, OV, st);
 }
 
-template <int BX, int BY, int BZ, bool RING, int BNV, int NP>
+template <int BX, int BY, int BZ, bool RING, int BNV, int NP, int NB>
 static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
 #if defined(SGC_HALO_STAMPS)
   p.stamps = g_halo_stamp_buf;
 #endif
   constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
-  const size_t smem = halo_tab_offset(LROWS, RING) + 256 * sizeof(uint16_t);
+  const size_t smem = halo_tab_offset(LROWS, RING, NB) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
@@ -1337,7 +1394,7 @@ static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
@@ -1512,12 +1569,13 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
     // ring form: an option (see g_tune_halo_ring); 1 = the 256 -> 256 layers on the 4x4x16 brick, 2 = everywhere
-    const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && p.gz >= 16 && g_tune_halo_brick == 0 && Cout >= 256 && Cin <= 256)) &&
+    const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && halo_brick_shape(p.gx, p.gy, p.gz) == 0 && Cout >= 256 && Cin <= 256)) &&
                       (int64_t)ix * iy * iz * Cin * 4 < 0x7fffffff;   // 32-bit buffer offsets
     const bool narrow_n = g_tune_halo_narrow && Cout <= 64;          // 64-column tiles for the head's 28 / 32-column layers
-    if (p.gz >= 16 && g_tune_halo_brick == 0)
+    const int brick = halo_brick_shape(p.gx, p.gy, p.gz);
+    if (brick == 0)
       rc = narrow_n ? launch_halo<4, 4, 16, false, 64>(p, OV, st) : ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);
-    else if (p.gz >= 8 && g_tune_halo_brick != 2)
+    else if (brick == 1)
       rc = narrow_n ? launch_halo<4, 8, 8, false, 64>(p, OV, st) : ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
     else
       rc = narrow_n ? launch_halo<8, 8, 4, false, 64>(p, OV, st) : ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
@@ -1897,7 +1955,8 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
   const int64_t OV = (int64_t)ox * oy * oz, M = (int64_t)gx * gy * gz;
   int splitk = 1;
   if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && M >= g_tune_halo_min_m) {
-    const int bx = gz >= 16 ? 4 : (gz >= 8 ? 4 : 8), by = gz >= 16 ? 4 : 8, bz = gz >= 16 ? 16 : (gz >= 8 ? 8 : 4);
+    const int shape = halo_brick_shape(gx, gy, gz);
+    const int bx = shape == 2 ? 8 : 4, by = shape == 0 ? 4 : 8, bz = shape == 0 ? 16 : (shape == 1 ? 8 : 4);
     splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, (g_tune_halo_narrow && Cout <= 64) ? 64 : 128), Cin / BK);
   } else {
     ConvParams p = {};
