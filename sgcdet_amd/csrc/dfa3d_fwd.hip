@@ -413,6 +413,7 @@ extern int g_tune_halo_min_m;
 extern int g_tune_halo_brick;
 extern int g_tune_halo_ring;
 extern int g_tune_halo_nb;
+extern int g_tune_view_group;
 extern int g_tune_halo_narrow;
 extern int g_tune_split_target;
 extern int g_tune_wgrad_waves;
@@ -598,6 +599,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "halo_brick")) { g_tune_halo_brick = value; return SGC_OK; }
   if (!strcmp(key, "halo_ring")) { g_tune_halo_ring = value; return SGC_OK; }
   if (!strcmp(key, "halo_nb")) { g_tune_halo_nb = value; return SGC_OK; }
+  if (!strcmp(key, "view_group")) { g_tune_view_group = value; return SGC_OK; }
   if (!strcmp(key, "halo_narrow")) { g_tune_halo_narrow = value; return SGC_OK; }
   if (!strcmp(key, "split_target")) { g_tune_split_target = value; return SGC_OK; }
   if (!strcmp(key, "wgrad_waves")) { g_tune_wgrad_waves = value; return SGC_OK; }

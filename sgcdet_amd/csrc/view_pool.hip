@@ -8,7 +8,56 @@
 
 namespace sgc {
 
+int g_tune_view_group = 1;     // 0: the per-camera loops of rounds 1-2 in view_mean / view_attend (A/B; results identical)
+
 // mean over the cameras that see voxel valid_index[i]; C/4 lanes per voxel (float4 rows)
+// LG = C/4 in {32, 64}: the lanes of a voxel form a GROUP inside one wave.  Round 3: the group reads the voxel's slot column
+// 32 / 64 cameras at a time with ONE load per lane, and walks only the visible cameras (ballot + shuffle), with the next
+// camera's row requested before the current one is added -- instead of one dependent slot load per camera (28 of config 2's 40
+// cameras do not see a voxel) followed by a dependent row load.  Same cameras in the same order, same sums: bit-identical.
+template <int LG>
+__global__ __launch_bounds__(256) void view_mean_group_kernel(const float *__restrict__ feat, const int32_t *__restrict__ slot,
+                                                              const int32_t *__restrict__ valid_index, float *__restrict__ mean,
+                                                              int N, int Nq, int n_valid, const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);
+  constexpr int C = LG * 4;
+  const int lane = threadIdx.x & 63, gl = lane & (LG - 1), gbase = lane & ~(LG - 1);
+  const int64_t total = (int64_t)n_valid * LG, span = ((total + 63) / 64) * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < span; idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = idx < total;
+    const int i = (int)((live ? idx : total - 1) / LG);
+    const int q = valid_index[i];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int nb = 0; nb < N; nb += LG) {
+      const int pl = nb + gl < N ? slot[(int64_t)(nb + gl) * Nq + q] : -1;
+      unsigned long long m = __ballot(pl >= 0);
+      if (LG == 32) m = (m >> gbase) & 0xffffffffull;
+      if (!m) continue;
+      int p = __shfl(pl, gbase + __builtin_ctzll(m));
+      float4 v = reinterpret_cast<const float4 *>(feat + (int64_t)p * C)[gl];
+      m &= m - 1;
+      while (true) {
+        float4 vn = v;
+        const bool more = m != 0;
+        if (more) {
+          const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
+          vn = reinterpret_cast<const float4 *>(feat + (int64_t)pn * C)[gl];
+          m &= m - 1;
+        }
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        ++cnt;
+        if (!more) break;
+        v = vn;
+      }
+    }
+    if (live) {
+      const float fc = (float)cnt;
+      reinterpret_cast<float4 *>(mean + (int64_t)i * C)[gl] = make_float4(acc.x / fc, acc.y / fc, acc.z / fc, acc.w / fc);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void view_mean_kernel(const float *__restrict__ feat,
                                                         const int32_t *__restrict__ slot,
                                                         const int32_t *__restrict__ valid_index,
@@ -52,6 +101,69 @@ __global__ void view_mean_scalar_kernel(const float *__restrict__ feat, const in
       ++cnt;
     }
     mean[idx] = acc / (float)cnt;
+  }
+}
+
+// Group form of view_attend_kernel<4> for heads * G in {32, 64} lanes per voxel (C = 128 / 256 with 8 heads): the voxel's slot
+// column comes in with one load per lane, only the visible cameras are walked, and the next camera's k | v row is requested
+// before the current one enters the online softmax (see view_mean_group_kernel).  Same cameras, same order, same arithmetic as
+// the generic kernel below: bit-identical.
+template <int LG>
+__global__ __launch_bounds__(256) void view_attend_group_kernel(const float *__restrict__ q, const float *__restrict__ kv,
+                                                                const int32_t *__restrict__ slot,
+                                                                const int32_t *__restrict__ valid_index, float *__restrict__ ctx,
+                                                                int N, int Nq, int heads, int n_valid, float scale,
+                                                                const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);
+  if (n_valid <= 0) return;
+  constexpr int C = LG * 4;
+  const int G = LG / heads;                          // lanes per head
+  const int lane = threadIdx.x & 63, gl = lane & (LG - 1), gbase = lane & ~(LG - 1);
+  const int64_t total = (int64_t)n_valid * LG, span = ((total + 63) / 64) * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < span; idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = idx < total;
+    const int i = (int)((live ? idx : total - 1) / LG);
+    const int vq = valid_index[i];
+    const int c0 = gl * 4;                           // == h * hd + g * 4 of the generic kernel
+    const float4 q4 = *reinterpret_cast<const float4 *>(q + (int64_t)i * C + c0);
+    const float qv[4] = {q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, sum = 0.f;
+    for (int nb = 0; nb < N; nb += LG) {
+      const int pl = nb + gl < N ? slot[(int64_t)(nb + gl) * Nq + vq] : -1;
+      unsigned long long m = __ballot(pl >= 0);
+      if (LG == 32) m = (m >> gbase) & 0xffffffffull;
+      if (!m) continue;
+      int p = __shfl(pl, gbase + __builtin_ctzll(m));
+      m &= m - 1;
+      float4 k4 = *reinterpret_cast<const float4 *>(kv + (int64_t)p * 2 * C + c0);
+      float4 v4 = *reinterpret_cast<const float4 *>(kv + (int64_t)p * 2 * C + C + c0);
+      while (true) {
+        float4 kn = k4, vn = v4;
+        const bool more = m != 0;
+        if (more) {
+          const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
+          m &= m - 1;
+          kn = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + c0);
+          vn = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + C + c0);
+        }
+        const float kx[4] = {k4.x, k4.y, k4.z, k4.w}, vx[4] = {v4.x, v4.y, v4.z, v4.w};
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) d += qv[v] * kx[v];
+        for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+        const float nm = fmaxf(mx, d);
+        const float corr = expf(mx - nm);
+        const float e = expf(d - nm);
+        sum = sum * corr + e;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = acc[v] * corr + e * vx[v];
+        mx = nm;
+        if (!more) break;
+        k4 = kn; v4 = vn;
+      }
+    }
+    if (live) *reinterpret_cast<float4 *>(ctx + (int64_t)i * C + c0) = make_float4(acc[0] / sum, acc[1] / sum, acc[2] / sum, acc[3] / sum);
   }
 }
 
@@ -329,7 +441,14 @@ extern "C" int sgc_view_mean(const float *feat, const int32_t *slot, const int32
   const int32_t *n_dev = n_valid_dev_or_null;
   if (!feat || !slot || !valid_index || !mean) return set_error(SGC_EINVAL, "sgc_view_mean: null pointer");
   if (n_valid <= 0) return SGC_OK;
-  if (C % 4 == 0 && !((uintptr_t)feat & 15) && !((uintptr_t)mean & 15))
+  const bool al16 = !((uintptr_t)feat & 15) && !((uintptr_t)mean & 15);
+  if (C == 256 && al16 && g_tune_view_group)
+    hipLaunchKernelGGL(view_mean_group_kernel<64>, dim3(grid_for((int64_t)n_valid * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
+  else if (C == 128 && al16 && g_tune_view_group)
+    hipLaunchKernelGGL(view_mean_group_kernel<32>, dim3(grid_for((int64_t)n_valid * 32, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
+  else if (C % 4 == 0 && al16)
     hipLaunchKernelGGL(view_mean_kernel, dim3(grid_for((int64_t)n_valid * (C / 4), 256)), dim3(256), 0,
                        (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, C, n_valid, n_dev);
   else
@@ -353,7 +472,13 @@ extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *s
   if (hd % 4 || (G & (G - 1)) || G > 64 || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15)) { vec = 1; G = hd; }
   if ((G & (G - 1)) || G > 64) return set_error(SGC_EUNSUP, "sgc_view_attend: head_dim %d not supported", hd);
   const int64_t work = (int64_t)n_valid * heads * G;
-  if (vec == 4)
+  if (vec == 4 && heads * G == 64 && g_tune_view_group)
+    hipLaunchKernelGGL(view_attend_group_kernel<64>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
+  else if (vec == 4 && heads * G == 32 && g_tune_view_group)
+    hipLaunchKernelGGL(view_attend_group_kernel<32>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
+  else if (vec == 4)
     hipLaunchKernelGGL(view_attend_kernel<4>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
                        slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale, n_dev);
   else
