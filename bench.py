@@ -367,17 +367,20 @@ def main():
         tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
         ops.event_names = None if args.breakdown else PATH_KERNELS
+        ops.event_sync = True            # each bracketed launch starts on a drained stream (see TensorOps._call)
         calls0 = ops.n_calls
-        with torch.no_grad():
+        import contextlib
+        with torch.no_grad(), (torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()):
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
                 det.forward_features(feats, metas, dpt)
                 torch.cuda.synchronize()
         log, ops.event_log = ops.event_log, None
+        ops.event_sync = False
         lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
         det.scene_graph, det.use_graph = True, tail_graph
-        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
-                         "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
+        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, each "
+                         "bracketed launch on a drained stream, right after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with the other scenes in flight and runs 0-3 % longer, see "
                          "profiles/r02_kernels_from_trace.json)")
 
@@ -455,6 +458,10 @@ def main():
                                 "sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8> (finest level)"),
                         measured=roofline_pass,
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
+        if args.conv_mode == "f32" and args.streams > 1:
+            roofline["note"] = ("HIP events over-read this kernel in strict-fp32 mode with more than one stream (the bracket also holds "
+                                "the fp32 Linear in front of it): the kernel trace of this command shows 90 - 96 us per launch "
+                                "(profiles/r03_f32_gather_trace.txt), `--streams 1` reads 94 us = 0.44 with events too")
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
     roofline_mfma = None
     cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode != "f32" else "sgc_conv3d_cl_f32", [])

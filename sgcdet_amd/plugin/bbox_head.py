@@ -18,9 +18,9 @@ import torch
 from torch import nn
 
 from .. import ext
-from ..mmcv_lite import HEADS, Scale, bias_init_with_prob, multi_apply, normal_init
+from ..mmcv_lite import HEADS, LOSSES, Scale, bias_init_with_prob, multi_apply, normal_init
 from .conv_plan import train_conv_on_hip, ConvSpec, module_fingerprint, rows_to_ncdhw, to_channels_last_rows
-from . import losses
+from . import losses  # noqa: F401  (registers the LOSSES entries the head builds)
 
 
 @torch.no_grad()
@@ -43,19 +43,21 @@ def rotation_3d_in_axis_z(points, angles):
 
 
 class ImVoxelHeadV2(nn.Module):
+    default_loss_bbox = None                      # set per head class (the configs always name one, :111 / :114)
+
     def __init__(self, n_classes, n_channels, n_reg_outs, n_scales, limit, centerness_topk=-1,
                  loss_centerness=None, loss_bbox=None, loss_cls=None, train_cfg=None, test_cfg=None,
-                 nms_fn=None, loss_bbox_fn=None):
+                 nms_fn=None):
         super().__init__()
         self.n_classes = n_classes
         self.n_scales = n_scales
         self.limit = limit
         self.centerness_topk = centerness_topk
-        self.loss_cfgs = dict(loss_centerness=loss_centerness, loss_bbox=loss_bbox, loss_cls=loss_cls)
-        lc = loss_cls or {}                       # reference defaults (:50-62): FocalLoss(gamma 2, alpha .25), weights 1
-        self.focal_gamma, self.focal_alpha = lc.get("gamma", 2.0), lc.get("alpha", 0.25)
-        self.loss_weights = tuple((c or {}).get("loss_weight", 1.0) for c in (loss_centerness, loss_bbox, loss_cls))
-        self.loss_bbox_fn = loss_bbox_fn
+        # the three losses are built from the LOSSES registry like the reference's build_loss (:67-69); defaults = :46-57
+        self.loss_centerness = LOSSES.build(loss_centerness or dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0))
+        self.loss_bbox = LOSSES.build(loss_bbox or dict(type=self.default_loss_bbox, loss_weight=1.0))
+        self.loss_cls = LOSSES.build(loss_cls or dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25,
+                                                      loss_weight=1.0))
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.nms_fn = nms_fn
@@ -207,9 +209,6 @@ class ImVoxelHeadV2(nn.Module):
         return ext.ops().assign_targets(pts, scales, self._gt_rows(gt_bboxes, dev), gt_labels.to(torch.int64).contiguous(),
                                         self.rotated_targets, self.n_scales, self.limit, self.centerness_topk)
 
-    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
-        raise NotImplementedError
-
     def _loss_single(self, centernesses, bbox_preds, cls_scores, valids, img_meta, gt_bboxes, gt_labels):
         """(:147-235)."""
         dev = centernesses[0].device
@@ -229,20 +228,18 @@ class ImVoxelHeadV2(nn.Module):
             torch.distributed.all_reduce(n_pos.div_(torch.distributed.get_world_size()))
         n_pos = max(float(n_pos), 1.0)
         if torch.any(val):
-            loss_cls = losses.sigmoid_focal_loss(cls[val], labels[val], gamma=self.focal_gamma, alpha=self.focal_alpha,
-                                                 avg_factor=n_pos)
+            loss_cls = self.loss_cls(cls[val], labels[val], avg_factor=n_pos)
         else:
             loss_cls = cls[val].sum()
         pos_ctr, pos_reg = ctr[pos_inds], reg[pos_inds]
         if len(pos_inds) > 0:
             pos_ctr_t = ctr_t[pos_inds]
-            loss_centerness = losses.sigmoid_bce_loss(pos_ctr, pos_ctr_t, avg_factor=n_pos)
-            loss_bbox = self._loss_bbox(self._bbox_pred_to_bbox(points[pos_inds], pos_reg), box_t[pos_inds], pos_ctr_t,
-                                        pos_ctr_t.sum())
+            loss_centerness = self.loss_centerness(pos_ctr, pos_ctr_t, avg_factor=n_pos)
+            loss_bbox = self.loss_bbox(self._bbox_pred_to_bbox(points[pos_inds], pos_reg), box_t[pos_inds],
+                                       weight=pos_ctr_t, avg_factor=pos_ctr_t.sum())
         else:
             loss_centerness, loss_bbox = pos_ctr.sum(), pos_reg.sum()
-        wc, wb, wl = self.loss_weights
-        return loss_centerness * wc, loss_bbox * wb, loss_cls * wl, labels, geo_occ
+        return loss_centerness, loss_bbox, loss_cls, labels, geo_occ
 
     def forward_single(self, x, scale):
         raise NotImplementedError
@@ -256,14 +253,13 @@ class ImVoxelHeadV2(nn.Module):
 
 @HEADS.register_module()
 class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
+    default_loss_bbox = "AxisAlignedIoULoss"      # configs/SGCDet_ScanNet.py:111
+
     def forward_single(self, x, scale):
         return self.centerness_conv(x), torch.exp(scale(self.reg_conv(x))), self.cls_conv(x)
 
     def _reg_activation(self, reg, scale):
         return torch.exp(scale(reg))
-
-    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
-        return losses.axis_aligned_iou_loss(pred_boxes, target_boxes, weight=weight, avg_factor=avg_factor)   # config :111
 
     def _bbox_pred_to_bbox(self, points, bbox_pred):
         """point -/+ distances -> (x0,y0,z0,x1,y1,z1), :456-464."""
@@ -293,11 +289,7 @@ class ScanNetImVoxelHeadV2(ImVoxelHeadV2):
 @HEADS.register_module()
 class SunRgbdImVoxelHeadV2(ImVoxelHeadV2):
     rotated_targets = True
-
-    def _loss_bbox(self, pred_boxes, target_boxes, weight, avg_factor):
-        if self.loss_bbox_fn is not None:
-            return self.loss_bbox_fn(pred_boxes, target_boxes, weight, avg_factor)
-        return losses.rotated_iou_3d_loss(pred_boxes, target_boxes, weight=weight, avg_factor=avg_factor)   # ARKit config :114
+    default_loss_bbox = "RotatedIoU3DLoss"        # configs/SGCDet_ARKit.py:114
 
     def forward_single(self, x, scale):
         reg = self.reg_conv(x)

@@ -17,7 +17,10 @@ pairs at once in torch), which yields the same polygon and the same gradients al
 mmcv; its forward is checked against the float64 polygon clip of the NMS fixture and its gradients by gradcheck.
 """
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
+
+from ..mmcv_lite import LOSSES
 
 _FLT_MIN = 1.1754943508222875e-38
 
@@ -34,20 +37,31 @@ def axis_aligned_iou(pred, target, eps=1e-6):
     return overlap / union
 
 
-def _reduce(loss, weight, avg_factor, loss_weight):
+def _reduce(loss, weight, avg_factor, loss_weight, reduction="mean"):
+    """mmdet ``weight_reduce_loss``: element weights, then 'none' | 'sum' | 'mean' (``avg_factor`` replaces the count
+    under 'mean' and is refused under 'sum')."""
     if weight is not None:
         loss = loss * weight
+    if reduction == "none":
+        return loss_weight * loss
+    if reduction == "sum":
+        if avg_factor is not None:
+            raise ValueError('avg_factor can not be used with reduction="sum"')
+        return loss_weight * loss.sum()
+    if reduction != "mean":
+        raise ValueError(f"unknown reduction {reduction!r}")
     loss = loss.sum() / avg_factor if avg_factor is not None else loss.mean()
     return loss_weight * loss
 
 
-def axis_aligned_iou_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0):
-    if weight is not None and not torch.any(weight > 0):
+def axis_aligned_iou_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0, reduction="mean"):
+    if weight is not None and not torch.any(weight > 0) and reduction != "none":
         return (pred * weight.reshape(-1, *([1] * (pred.dim() - 1)))).sum() * loss_weight
-    return _reduce(1 - axis_aligned_iou(pred, target), weight, avg_factor, loss_weight)
+    return _reduce(1 - axis_aligned_iou(pred, target), weight, avg_factor, loss_weight, reduction)
 
 
-def sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25, weight=None, avg_factor=None, loss_weight=1.0):
+def sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25, weight=None, avg_factor=None, loss_weight=1.0,
+                       reduction="mean"):
     """pred [N, C] logits, target [N] int64 class index (anything outside [0, C) = background)."""
     C = pred.shape[1]
     p = pred.sigmoid()
@@ -57,15 +71,15 @@ def sigmoid_focal_loss(pred, target, gamma=2.0, alpha=0.25, weight=None, avg_fac
     loss = torch.where(pos, term_pos, term_neg)
     if weight is not None:
         weight = weight.reshape(-1, 1)
-    return _reduce(loss, weight, avg_factor, loss_weight)
+    return _reduce(loss, weight, avg_factor, loss_weight, reduction)
 
 
-def sigmoid_bce_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0):
+def sigmoid_bce_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0, reduction="mean"):
     """pred [N] logits, target [N] float in [0, 1] (the centerness targets)."""
     loss = F.binary_cross_entropy_with_logits(pred, target.float(), reduction="none")
     valid = (target >= 0).float()                      # mmdet's ignore mask; centerness targets are >= 0
     weight = valid if weight is None else weight * valid
-    return _reduce(loss, weight, avg_factor, loss_weight)
+    return _reduce(loss, weight, avg_factor, loss_weight, reduction)
 
 
 def _rect_corners(x, y, w, h, a):
@@ -129,7 +143,75 @@ def rotated_iou_3d(pred, target):
     return inter / (vol - inter)
 
 
-def rotated_iou_3d_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0):
+def rotated_iou_3d_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0, reduction="mean"):
     if weight is not None and not torch.any(weight > 0):
         return pred.sum() * 0
-    return _reduce(1 - rotated_iou_3d(pred, target), weight, avg_factor, loss_weight)
+    return _reduce(1 - rotated_iou_3d(pred, target), weight, avg_factor, loss_weight, reduction)
+
+
+# ---- the LOSSES registry (config ``loss_*=dict(type=...)`` entries resolve here) -----------------
+class _RegisteredLoss(nn.Module):
+    """Shared shell of the registered losses: mmdet's calling convention
+    ``loss(pred, target, weight=None, avg_factor=None, reduction_override=None)`` over one of the functions above."""
+    fn = None
+
+    def __init__(self, reduction="mean", loss_weight=1.0, **fn_kwargs):
+        super().__init__()
+        if reduction not in ("none", "sum", "mean"):
+            raise ValueError(f"reduction must be 'none', 'sum' or 'mean', got {reduction!r}")
+        self.reduction = reduction
+        self.loss_weight = loss_weight
+        self.fn_kwargs = fn_kwargs
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        if reduction_override not in (None, "none", "sum", "mean"):
+            raise ValueError(f"reduction_override must be None, 'none', 'sum' or 'mean', got {reduction_override!r}")
+        return type(self).fn(pred, target, weight=weight, avg_factor=avg_factor, loss_weight=self.loss_weight,
+                             reduction=reduction_override or self.reduction, **self.fn_kwargs)
+
+    def extra_repr(self):
+        return f"reduction={self.reduction!r}, loss_weight={self.loss_weight}"
+
+
+@LOSSES.register_module()
+class AxisAlignedIoULoss(_RegisteredLoss):
+    """``dict(type='AxisAlignedIoULoss', loss_weight=1.0)`` of the ScanNet configs (configs/SGCDet_ScanNet.py:111;
+    mmdet3d/models/losses/axis_aligned_iou_loss.py:30-80): boxes [..., 6] as (x1, y1, z1, x2, y2, z2)."""
+    fn = staticmethod(axis_aligned_iou_loss)
+
+
+@LOSSES.register_module()
+class RotatedIoU3DLoss(_RegisteredLoss):
+    """``dict(type='RotatedIoU3DLoss', loss_weight=1.0)`` of the ARKit configs (configs/SGCDet_ARKit.py:114;
+    mmdet3d/models/losses/rotated_iou_loss.py:29-84): boxes [n, 7] as (x, y, z, w, l, h, alpha); a per-coordinate
+    weight [n, 7] is averaged over its last axis first, as the reference wrapper does (:75-76)."""
+    fn = staticmethod(rotated_iou_3d_loss)
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        if weight is not None and weight.dim() > 1:
+            weight = weight.mean(-1)
+        return super().forward(pred, target, weight, avg_factor, reduction_override)
+
+
+@LOSSES.register_module()
+class FocalLoss(_RegisteredLoss):
+    """The head's default ``loss_cls`` (imvoxel_head_v2.py:52-57): mmdet ``FocalLoss(use_sigmoid=True)`` on integer
+    targets.  Only the sigmoid form exists (mmdet refuses the other too)."""
+    fn = staticmethod(sigmoid_focal_loss)
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0, activated=False):
+        if not use_sigmoid or activated:
+            raise NotImplementedError("FocalLoss: only use_sigmoid=True on logits (activated=False) is implemented")
+        super().__init__(reduction, loss_weight, gamma=gamma, alpha=alpha)
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(_RegisteredLoss):
+    """The head's default ``loss_centerness`` (imvoxel_head_v2.py:46-50): mmdet ``CrossEntropyLoss(use_sigmoid=True)``
+    = binary cross-entropy on logits with soft targets.  The softmax / mask forms are not on the path."""
+    fn = staticmethod(sigmoid_bce_loss)
+
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction="mean", class_weight=None, loss_weight=1.0):
+        if not use_sigmoid or use_mask or class_weight is not None:
+            raise NotImplementedError("CrossEntropyLoss: only use_sigmoid=True without mask / class weights is implemented")
+        super().__init__(reduction, loss_weight)

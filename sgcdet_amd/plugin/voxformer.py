@@ -190,6 +190,59 @@ class MSDeformableAttention3D_DFA3D(BaseModule):
         return output, weight_update
 
 
+class _ZeroLinear:
+    """Stands where ``sampling_offsets_depth`` is in the DFA3D class: a weight / bias of zeros that is no parameter
+    (nothing to learn, nothing in the state dict), on whatever device the module lives."""
+
+    def __init__(self, like, out_features):
+        self.weight = like.weight.new_zeros((out_features, like.weight.shape[1]))
+        self.bias = like.weight.new_zeros((out_features,))
+
+    def __call__(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+@ATTENTION.register_module()
+class MSDeformableAttention3D(MSDeformableAttention3D_DFA3D):
+    """The 2-D deformable attention (deformable_cross_attention.py:119-341; no SGCDet config selects it).  The reference
+    hands it to mmcv's ``MultiScaleDeformableAttnFunction``; here it is the same HIP gather as the DFA3D class, run on a
+    one-bin depth map of ones with every sample at the centre of that bin: the depth interpolation then weighs every
+    sample with exactly 1.0, and what is left is the bilinear 2-D operator (pinned against ``F.grid_sample`` in
+    tests/test_oracle_identity.py and, through the kernels, in tests/test_gpu_modules.py)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        del self._modules["sampling_offsets_depth"]
+
+    @property
+    def sampling_offsets_depth(self):
+        if "sampling_offsets_depth" in self._modules:          # only while the parent constructor runs
+            return self._modules["sampling_offsets_depth"]
+        z = self.__dict__.get("_zero_depth")
+        w = self.sampling_offsets.weight
+        if z is None or z.weight.device != w.device or z.weight.dtype != w.dtype:
+            z = self.__dict__["_zero_depth"] = _ZeroLinear(self.sampling_offsets, self.num_heads * self.num_levels * self.num_points)
+        return z
+
+    def init_weights(self):
+        super().init_weights()                                  # writes its depth-offset bias into the stand-in ...
+        self.__dict__.pop("_zero_depth", None)                  # ... which is dropped: the next access builds zeros again
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, value_dpt_dist=None, **kwargs):
+        """query [bs,Q,C]; value [bs,S,C]; reference_points [bs,Q,Z,2] -> [bs,Q,C] (:215-341)."""
+        if reference_points.shape[-1] != 2:
+            raise ValueError(f"Last dim of reference_points must be 2, but get {reference_points.shape[-1]} instead.")
+        v = query if value is None else value
+        n_rows = v.shape[1] if self.batch_first else v.shape[0]
+        bs = v.shape[0] if self.batch_first else v.shape[1]
+        ones = v.new_ones((bs, n_rows, 1))
+        ref3 = torch.cat([reference_points, reference_points.new_full((*reference_points.shape[:-1], 1), 0.5)], -1)
+        out, _ = super().forward(query, key, value, ones, identity, query_pos, key_padding_mask, ref3, spatial_shapes,
+                                 level_start_index, **kwargs)
+        return out
+
+
 # ----------------------------------------------------------------------------------------
 @ATTENTION.register_module()
 class DeformCrossAttention_DFA3D(BaseModule):
@@ -212,6 +265,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
 
     def init_weight(self):
         xavier_init(self.output_proj, distribution="uniform", bias=0.0)
+
+    # the 2-D class adds the sampled feature back onto the deformable attention's output
+    # (deformable_cross_attention.py:647 ``queries = queries + queries_per_image``); this one does not (:795-800)
+    geo_residual = False
 
     def _gemm_plan(self):
         """The Linears of a level on the MFMA kernel (value_proj over N*S rows; the fused offset/logit projection
@@ -306,7 +363,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
                     # config-2 level, the tiled gather saves ~180 against the wave kernel)
                     value = gemm["value"](feat.view(N * S, C)).view(N, S, da.num_heads, Cm).permute(0, 2, 1, 3).contiguous()
                 raw = gemm["raw_hm"](geo, count=pairs_cnt)
-                del geo
+                if not self.geo_residual:
+                    del geo
                 per_pair = ops.pairs_deform_gather_tiled(value, dist, pc["pair_ref"], pc["bin_offset"], raw, H, W,
                                                          da.num_points, bw, bh, tiled["halo"][0], tiled["halo"][1],
                                                          head_shift=gemm["head_shift"], max_shift=gemm["max_shift"],
@@ -317,12 +375,15 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 zero_row = use_mfma and CONV_MODE == "bf16x3"
                 value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
                 raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
-                del geo                                   # capacity-sized in static mode: let the allocator reuse it
+                if not self.geo_residual:
+                    del geo                               # capacity-sized in static mode: let the allocator reuse it
                 per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,
                                                    ref_cam, raw, pair_cam, pair_q, n_pairs, H, W,
                                                    da.num_heads, da.num_points, totals=totals,
                                                    dist_pairs=ops.depth_pairs(dist, H, W), zero_row=zero_row)
             del raw, value
+            if self.geo_residual:
+                per_pair = per_pair.add_(geo[:per_pair.shape[0]])
         else:
             per_pair = geo
         slot, valid_index = pc["slot"], pc["valid_index"]
@@ -374,11 +435,14 @@ class DeformCrossAttention_DFA3D(BaseModule):
             from ..functions import linear_rows                    # the Linears' three passes on the MFMA kernels
             value = linear_rows(da.value_proj, feat).view(N, S, M, C // M)
             off_uv = linear_rows(da.sampling_offsets, geo).view(n_pairs, M, L, P, 2)
-            off_d = linear_rows(da.sampling_offsets_depth, geo).view(n_pairs, M, L, P, 1)
+            off_d = (geo.new_zeros((n_pairs, M, L, P, 1)) if isinstance(da.sampling_offsets_depth, _ZeroLinear)
+                     else linear_rows(da.sampling_offsets_depth, geo).view(n_pairs, M, L, P, 1))
             attn = linear_rows(da.attention_weights, geo).view(n_pairs, M, L * P).softmax(-1).view(n_pairs, M, L, P)
             normalizer = torch.stack([shapes3[..., 1], shapes3[..., 0], shapes3[..., 2]], -1).to(feat.dtype)   # (W, H, D) per level
             loc = ref.view(n_pairs, 1, 1, 1, 3) + torch.cat([off_uv, off_d], -1) / normalizer[None, None, :, None, :]
             per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item)
+            if self.geo_residual:
+                per_pair = per_pair + geo
         else:
             per_pair = geo
         count = mask.sum(0)
@@ -432,9 +496,14 @@ class DeformCrossAttention_DFA3D(BaseModule):
             feat.view(N, -1, 1, C), dist.view(N, feat.shape[1], 1, -1), shapes3, level_start_index,
             ref_rebatch.view(N, max_len, 1, 1, 1, 3), ones, 128)
         if self.deformable_attn:
-            queries, _ = self.deformable_attention(query=geo, key=feat, value=feat, value_dpt_dist=dist,
-                                                   reference_points=ref_rebatch, spatial_shapes=spatial_shapes,
-                                                   level_start_index=level_start_index)
+            two_d = isinstance(self.deformable_attention, MSDeformableAttention3D)
+            queries = self.deformable_attention(query=geo, key=feat, value=feat, value_dpt_dist=dist,
+                                                reference_points=ref_rebatch[..., :2] if two_d else ref_rebatch,
+                                                spatial_shapes=spatial_shapes,
+                                                level_start_index=level_start_index)
+            queries = queries[0] if isinstance(queries, tuple) else queries
+            if self.geo_residual:
+                queries = queries + geo
         else:
             queries = geo
         slots = torch.zeros((N, Nq, C), dtype=feat.dtype, device=feat.device)
@@ -453,6 +522,9 @@ class DeformCrossAttention_DFA3D(BaseModule):
         out = out.index_put((torch.zeros_like(valid_index), valid_index), pooled)
         return self.dropout(out) + query
 
+    def _depth_inputs(self, value_dpt_dist, reference_points_cam, N, S, Nq, feat):
+        return value_dpt_dist.reshape(N, S, -1), reference_points_cam.reshape(N, Nq, 3)
+
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None, bev_mask=None,
                 level_start_index=None, value_dpt_dist=None, flag="encoder", **kwargs):
@@ -466,8 +538,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         assert bs == 1
         N, S = value.shape[0], value.shape[1]
         feat = value.reshape(N, S, C)
-        dist = value_dpt_dist.reshape(N, S, -1)
-        ref_cam = reference_points_cam.reshape(N, Nq, 3)
+        dist, ref_cam = self._depth_inputs(value_dpt_dist, reference_points_cam, N, S, Nq, feat)
         if torch.is_grad_enabled() and (query.requires_grad or feat.requires_grad or dist.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
             fn = self._forward_pairs_train if self.train_pair_list else self._forward_reference_layout
@@ -482,6 +553,27 @@ class DeformCrossAttention_DFA3D(BaseModule):
         return self._forward_pairs(query, feat.contiguous(), dist.contiguous(), ref_cam.contiguous(),
                                    mask_u8.contiguous(), hw[0], hw[1], zero_query=bool(kwargs.get("zero_query")),
                                    static_counts=bool(kwargs.get("static_counts")), want_ctx=bool(kwargs.get("want_ctx")))
+
+
+@ATTENTION.register_module()
+class DeformCrossAttention(DeformCrossAttention_DFA3D):
+    """The 2-D cross attention (deformable_cross_attention.py:504-689; no SGCDet config selects it): bilinear sample of the
+    feature map at the projected voxel centre, 2-D deformable attention around it PLUS that sample (:647), then the same
+    mean / attention over views.  Runs the DFA3D pipeline on a one-bin unit depth map (see ``MSDeformableAttention3D``);
+    the tiled gather needs two depth bins, so the per-wave gather serves this class."""
+    geo_residual = True
+
+    def _depth_inputs(self, value_dpt_dist, reference_points_cam, N, S, Nq, feat):
+        ref = reference_points_cam.reshape(N, Nq, -1)
+        if ref.shape[-1] == 2:
+            ref = torch.cat([ref, ref.new_full((N, Nq, 1), 0.5)], -1)
+        else:                                              # 3-D points from the shared projection kernel: depth is not used
+            ref = ref.clone()
+            ref[..., 2] = 0.5
+        ones = self.__dict__.get("_unit_depth")
+        if ones is None or ones.shape != (N, S, 1) or ones.device != feat.device or ones.dtype != feat.dtype:
+            ones = self.__dict__["_unit_depth"] = feat.new_ones((N, S, 1))
+        return ones, ref
 
 
 # ----------------------------------------------------------------------------------------
@@ -781,6 +873,20 @@ class VoxFormerEncoder_DFA3D(TransformerLayerSequence):
         return torch.stack(intermediate) if self.return_intermediate else output
 
 
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class VoxFormerEncoder(VoxFormerEncoder_DFA3D):
+    """The 2-D encoder (encoder.py:18-155; no SGCDet config selects it): same projection and visibility mask, the
+    reference points keep only (u, v) (:99)."""
+
+    def point_sampling(self, reference_points, img_meta=None):
+        ref_cam, mask = super().point_sampling(reference_points, img_meta)
+        return ref_cam[..., 0:2], mask
+
+    def forward(self, bev_query, key, value, *args, **kwargs):
+        kwargs.pop("value_dpt_dist", None)
+        return super().forward(bev_query, key, value, *args, **kwargs)
+
+
 def _channels_last_rows(t4, h, w):
     """[N, C, h, w] top-rows crop of a map stored channels-last ([N, Hs, Ws, C] in memory, Ws == w) -> zero-copy
     [N, Hs*Ws, C] rows (the kernels take Hs*Ws as the camera stride and never address the cropped rows); None when
@@ -860,10 +966,16 @@ class PerceptionTransformer_DFA3D(BaseModule):
                 queries = bev_queries[flat_idx].unsqueeze(1)                  # [Nq,1,C]
             sel_ref = ref_3d[flat_idx].to(queries.device)                     # [Nq,3]
         feats, dists, shapes = [], [], []
-        for feat, dpt in zip(mlvl_feats, mlvl_dpt_dists):
+        for feat, dpt in zip(mlvl_feats, mlvl_dpt_dists if mlvl_dpt_dists is not None else [None] * len(mlvl_feats)):
             _, n_cam, c, h, w = feat.shape
             shapes.append((h, w))
-            if torch.is_grad_enabled() and (feat.requires_grad or dpt.requires_grad):
+            if dpt is None:                                 # the 2-D transformer: no depth maps travel
+                if torch.is_grad_enabled() and feat.requires_grad:
+                    feats.append(feat[0].flatten(2).permute(0, 2, 1))
+                else:
+                    f_rows = _channels_last_rows(feat[0], h, w) if feat.dtype == torch.float32 else None
+                    feats.append(f_rows if f_rows is not None else ops.nchw_to_nhwc_crop(feat[0].float(), h, w))
+            elif torch.is_grad_enabled() and (feat.requires_grad or dpt.requires_grad):
                 feats.append(feat[0].flatten(2).permute(0, 2, 1))
                 dists.append(dpt[0].flatten(2).permute(0, 2, 1))
             else:   # channels-last producers: no copy; otherwise one crop+transpose launch each
@@ -884,13 +996,25 @@ class PerceptionTransformer_DFA3D(BaseModule):
                 feats.append(f_rows)
                 dists.append(d_rows)
         feat_flatten = feats[0] if len(feats) == 1 else torch.cat(feats, 1)
-        dist_flatten = dists[0] if len(dists) == 1 else torch.cat(dists, 1)
+        dist_flatten = None if not dists else (dists[0] if len(dists) == 1 else torch.cat(dists, 1))
         spatial_shapes, level_start_index = self._shape_tensors(tuple(shapes), queries.device)
         pos = None
         if bev_pos is not None:
             pos = bev_pos.flatten(2).permute(2, 0, 1)[flat_idx]
         return self.encoder(queries, feat_flatten.unsqueeze(2), feat_flatten.unsqueeze(2),
-                            value_dpt_dist=dist_flatten.unsqueeze(2), ref_3d=sel_ref[None, None],
+                            value_dpt_dist=None if dist_flatten is None else dist_flatten.unsqueeze(2), ref_3d=sel_ref[None, None],
                             bev_pos=pos, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                             img_meta=img_meta, prev_bev=None, spatial_hw=shapes[0] if len(shapes) == 1 else None,
                             ref_sel=ref_sel, **kwargs)
+
+
+@TRANSFORMER.register_module()
+class PerceptionTransformer(PerceptionTransformer_DFA3D):
+    """The 2-D transformer (transformer.py:26-112; no SGCDet config selects it): ``get_vox_features`` without depth maps.
+    ``bev_queries`` may still be None (zero queries, as the heads of this build pass them)."""
+
+    def get_vox_features(self, mlvl_feats, bev_queries, ref_3d, vox_coords, unmasked_idx, bev_pos=None,
+                         prev_bev=None, img_meta=None, **kwargs):
+        kwargs.pop("mlvl_dpt_dists", None)
+        return super().get_vox_features(mlvl_feats, bev_queries, ref_3d, vox_coords, unmasked_idx, bev_pos=bev_pos,
+                                        prev_bev=prev_bev, img_meta=img_meta, mlvl_dpt_dists=None, **kwargs)

@@ -998,3 +998,118 @@ def test_fpn_on_hip_emits_channels_last_maps_the_path_reads_in_place():
     assert n_cl == 0 and sum(1 for c in calls if c == w["embed_dims"]) > 0      # only the NCHW hand-over transposed feature maps
     for k in got:
         assert torch.equal(got[k], ref[k]), k
+
+
+def _dense_2d_cross_attention(att, feat, ref_uv, mask, H, W):
+    """The published formulation of the 2-D classes on EVERY (camera, voxel), masked afterwards: bilinear sample
+    (``F.grid_sample``, zeros padding, align_corners=False), 2-D deformable attention around it plus the sample
+    (deformable_cross_attention.py:215-341, :632-647), mean / attention over the visible views (:652-676).  Torch ops only."""
+    import torch.nn.functional as F
+    da = att.deformable_attention
+    N, S, C = feat.shape
+    Nq = ref_uv.shape[1]
+    M, P = da.num_heads, da.num_points
+    fmap = feat.view(N, H, W, C).permute(0, 3, 1, 2)
+    geo = F.grid_sample(fmap, (ref_uv * 2 - 1).view(N, Nq, 1, 2), mode="bilinear", padding_mode="zeros",
+                        align_corners=False)[..., 0].permute(0, 2, 1)                       # [N,Nq,C]
+    v = da.value_proj(feat).view(N, H, W, M, C // M).permute(0, 3, 4, 1, 2).reshape(N * M, C // M, H, W)
+    off = da.sampling_offsets(geo).view(N, Nq, M, P, 2) / torch.tensor([W, H], dtype=feat.dtype, device=feat.device)
+    a = da.attention_weights(geo).view(N, Nq, M, P).softmax(-1)
+    loc = ref_uv[:, :, None, None, :] + off
+    samp = F.grid_sample(v, (loc * 2 - 1).permute(0, 2, 1, 3, 4).reshape(N * M, Nq, P, 2), mode="bilinear",
+                         padding_mode="zeros", align_corners=False).view(N, M, C // M, Nq, P)
+    per = (samp * a.permute(0, 2, 1, 3)[:, :, None]).sum(-1).permute(0, 3, 1, 2).reshape(N, Nq, C) + geo
+    count = mask.sum(0)
+    valid = count > 0
+    mean = (per * mask[..., None]).sum(0)[valid] / count[valid][:, None]
+    pooled = att.output_proj(mean)
+    pooled, _ = att.attention_pooling(pooled[None], per[:, valid], per[:, valid], ~mask[:, valid].t())
+    out = torch.zeros(Nq, C, dtype=feat.dtype, device=feat.device)
+    return out.index_put((valid.nonzero()[:, 0],), pooled[0])[None]
+
+
+def test_2d_registry_classes_run_the_hip_path_and_equal_the_published_formulation():
+    """SURVEY 8b registry surface: ``PerceptionTransformer`` / ``VoxFormerEncoder`` / ``DeformCrossAttention`` /
+    ``MSDeformableAttention3D`` (the 2-D names; no SGCDet config selects them) build from a config and run on the same HIP
+    kernels as the DFA3D classes (one unit depth bin).  Checked against torch's grid_sample formulation: the inference
+    pair-list path, both differentiable paths, and their gradients."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd import ext
+    from sgcdet_amd.mmcv_lite import TRANSFORMER
+    from sgcdet_amd.plugin import voxformer as vf
+    from sgcdet_amd.scene import make_img_meta
+    C, N, H, W = 64, 5, 15, 20
+    cfg = dict(type="PerceptionTransformer", embed_dims=C, encoder=dict(
+        type="VoxFormerEncoder", num_layers=1, return_intermediate=False, dbound=[0.2, 5.0],
+        transformerlayers=dict(
+            type="VoxFormerLayer",
+            attn_cfgs=[dict(type="DeformCrossAttention", embed_dims=C, inter_view_aggregation="attn", dropout=0,
+                            deformable_attention=dict(type="MSDeformableAttention3D", embed_dims=C, num_heads=4,
+                                                      num_levels=1, num_points=4))],
+            ffn_cfgs=dict(type="FFN", embed_dims=C, feedforward_channels=C * 2, num_fcs=2, ffn_drop=0.0,
+                          act_cfg=dict(type="ReLU", inplace=True)),
+            operation_order=("cross_attn", "norm", "ffn", "norm"))))
+    torch.manual_seed(0)
+    xf = TRANSFORMER.build(cfg).cuda()
+    layer = xf.encoder.layers[0]
+    att = layer.attentions[0]
+    assert type(xf) is vf.PerceptionTransformer and type(xf.encoder) is vf.VoxFormerEncoder
+    assert type(att) is vf.DeformCrossAttention and type(att.deformable_attention) is vf.MSDeformableAttention3D
+    assert not any("depth" in k for k in xf.state_dict())            # the 2-D classes own no depth-offset Linear (:165-170)
+    with torch.no_grad():                                            # offsets / logits / FFN that depend on the data
+        for p in xf.parameters():
+            if p.dim() > 1:
+                p.add_(0.05 * torch.randn_like(p))
+    meta = make_img_meta(N, "scannet", seed=2)
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(1, N, C, H, W, generator=g).cuda()
+    gx, gy, gz = 12, 12, 6
+    ax = [torch.arange(n, dtype=torch.float32) for n in (gx, gy, gz)]
+    pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
+    ref_3d = ((pts + 0.5) / torch.tensor([gx, gy, gz]) - 0.5) * torch.tensor([6.4, 6.4, 2.56])
+    n_vox = ref_3d.shape[0]
+    coords = torch.cat([pts.long(), torch.arange(n_vox)[:, None]], 1).cuda()
+    idx = torch.arange(0, n_vox, 2).cuda()                           # every other voxel is a query
+    ref_3d = ref_3d.cuda()
+    # what the encoder hands the attention: (u, v) only, and the shared visibility mask (encoder.py:45-99)
+    ref_uv, mask = xf.encoder.point_sampling(ref_3d[idx][None, None], meta)
+    assert ref_uv.shape == (N, 1, idx.numel(), 1, 2) and 0 < int(mask.sum()) < mask.numel()
+    ref_uv, mask = ref_uv.reshape(N, -1, 2), mask.reshape(N, -1)
+    rows = feat[0].flatten(2).permute(0, 2, 1).contiguous()
+
+    def tail(x):
+        return layer.norms[1](layer.ffns[0](layer.norms[0](x)))
+    with torch.no_grad():
+        want = tail(_dense_2d_cross_attention(att, rows, ref_uv, mask, H, W))
+        n0 = ext.ops().n_calls
+        got = xf.get_vox_features([feat], None, ref_3d, coords, idx, img_meta=meta)
+        assert ext.ops().n_calls > n0                                # the kernels of the library ran, not a torch fallback
+    scale = max(1.0, want.abs().max().item())
+    assert got.shape == want.shape and max_err(got, want) < 2e-4 * scale, max_err(got, want)
+    # the differentiable paths (pair list / the reference's padded layout): the whole level forward; gradients through the
+    # attention alone -- behind it sits a ReLU, and one pre-activation within rounding noise of zero (|h| = 2e-6 in this very
+    # scene) flips its mask between two correct Linear kernels and moves single gradient entries by 0.5 %
+    q0 = torch.zeros(1, idx.numel(), C, device="cuda")
+    ss, lsi = torch.tensor([[H, W]], device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda")
+    names = ["feat"] + [n for n, _ in att.named_parameters()]
+    params = [p for p in att.parameters()]
+    featg = feat.clone().requires_grad_()
+    want_att = _dense_2d_cross_attention(att, featg[0].flatten(2).permute(0, 2, 1), ref_uv, mask, H, W)
+    w = torch.randn(want_att.shape, generator=g).cuda()
+    (want_att * w).sum().backward()
+    want_grads = [featg.grad.clone()] + [None if p.grad is None else p.grad.clone() for p in params]
+    assert sum(b is not None for b in want_grads) >= 13
+    for mode in (True, False):
+        att.train_pair_list = mode
+        out = xf.get_vox_features([feat.clone().requires_grad_()], None, ref_3d, coords, idx, img_meta=meta)
+        assert max_err(out, want) < 2e-4 * scale, (mode, max_err(out, want))
+        xf.zero_grad(set_to_none=True)
+        featg = feat.clone().requires_grad_()
+        got_att = att(q0, None, featg[0].flatten(2).permute(0, 2, 1).unsqueeze(2), reference_points_cam=ref_uv.view(N, 1, -1, 1, 2),
+                      bev_mask=mask.view(N, 1, -1, 1), spatial_shapes=ss, level_start_index=lsi)
+        assert max_err(got_att, want_att) < 1e-4 * max(1.0, want_att.abs().max().item())
+        (got_att * w).sum().backward()
+        got_grads = [featg.grad] + [p.grad for p in params]
+        bad = [(n, tuple(b.shape), round(max_err(a, b), 6), round(b.abs().max().item(), 4)) for n, a, b in zip(names, got_grads, want_grads)
+               if (a is None) != (b is None) or (b is not None and max_err(a, b) >= 2e-4 * max(1.0, b.abs().max().item()))]
+        assert not bad, (mode, bad)

@@ -68,6 +68,28 @@ def test_backward_equals_autograd_of_grid_sample(case, oracle_ops):
         assert (w - g).abs().max() <= 2e-5 * max(1.0, w.abs().max().item())
 
 
+def test_one_unit_depth_bin_is_the_2d_deformable_attention(oracle_ops):
+    """The 2-D classes (MSDeformableAttention3D / DeformCrossAttention, deformable_cross_attention.py:119,504) run the
+    DFA3D operator on a depth map of ones with one bin and every sample at that bin's centre (z = 0.5): the result must be
+    plain multi-scale deformable attention -- 4-D ``F.grid_sample`` (bilinear, zeros, align_corners=False) per level, the
+    published formulation mmcv's ``multi_scale_deformable_attn_pytorch`` uses -- and every in-map depth score exactly 1."""
+    for case in ((2, 4, 8, 1, 40, 3, [(5, 7), (3, 4)]), (1, 8, 4, 1, 64, 4, [(15, 20)])):
+        B, M, Cm, _, Q, P, levels = case
+        value, _, shapes3, lsi, loc, attn = inputs(case, 5)
+        loc[..., 2] = 0.5
+        ones = torch.ones(B, value.shape[1], 1, 1)
+        out, score = oracle_ops.dfa3d_forward(value, ones, shapes3, lsi, loc, attn, want_score=True)
+        assert bool(((score == 1) | (score == 0)).all()) and float(score.mean()) > 0.4   # per bilinear corner: 1 inside the map, 0 off it
+        want, start = 0, 0
+        for l, (H, W) in enumerate(levels):
+            v = value[:, start:start + H * W].permute(0, 2, 3, 1).reshape(B * M, Cm, H, W)
+            g = loc[:, :, :, l, :, :2].permute(0, 2, 1, 3, 4).reshape(B * M, Q, P, 2) * 2 - 1
+            samp = F.grid_sample(v, g, mode="bilinear", padding_mode="zeros", align_corners=False).view(B, M, Cm, Q, P)
+            want = want + torch.einsum("bmcqp,bmqp->bqmc", samp, attn[:, :, :, l].permute(0, 2, 1, 3))
+            start += H * W
+        assert (out - want.reshape(B, Q, M * Cm)).abs().max() < 1e-5          # fp32 rounding of sums of up to L*P*4 products of O(1)
+
+
 def test_unreplicated_depth_equals_replicated(oracle_ops):
     """dist_heads == 1 is the reference's `.repeat(1,1,num_heads,1)` without the copy; its
     gradient is the head-sum autograd would produce through the repeat."""

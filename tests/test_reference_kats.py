@@ -49,6 +49,12 @@ def test_iou_losses_match_the_reference_tests_known_answers():
     # the reduced form the heads call (mean over boxes)
     assert abs(float(losses.axis_aligned_iou_loss(_t("aaloss_boxes1"), _t("aaloss_boxes2"))) - float(_t("aaloss_expected").mean())) < 1e-4
     assert abs(float(losses.rotated_iou_3d_loss(_t("rotloss_boxes1"), _t("rotloss_boxes2"))) - float(_t("rotloss_expected").mean())) < 1e-4
+    # as the reference's tests call them: the registered classes with reduction='none' (test_losses.py:188, :210)
+    from sgcdet_amd.mmcv_lite import LOSSES
+    got = LOSSES.build(dict(type="AxisAlignedIoULoss", reduction="none"))(_t("aaloss_boxes1"), _t("aaloss_boxes2"))
+    assert got.shape == (3,) and torch.allclose(got, _t("aaloss_expected").reshape(-1), atol=1e-4)
+    got = LOSSES.build(dict(type="RotatedIoU3DLoss", reduction="none"))(_t("rotloss_boxes1"), _t("rotloss_boxes2"))
+    assert got.shape == (5,) and torch.allclose(got, _t("rotloss_expected").reshape(-1), atol=1e-4)
 
 
 def _eval_inputs(tag):

@@ -25,11 +25,12 @@ csv.field_size_limit(1 << 30)
 rows = list(csv.DictReader(open(sys.argv[1])))
 out = {}
 tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
-for key in ("dfa3d_fwd_tile_kernel", "conv3d_halo_bf16x3_kernel<4, 4, 16, false, 128, 3>", "conv3d_halo_bf16x3_kernel<4, 8, 8, false, 128, 3>",
-            "conv3d_igemm_bf16x3_kernel<128, 4, 2, 3>", "rows_gemm_bf16x3_kernel<256, 8, 1, 1, 3>", "rows_gemm_bf16x3_kernel<256, 8, 1, 0, 3>",
-            "rows_gemm_bf16x3_kernel<256, 4, 1, 0, 3>", "level_tail_kernel", "conv_epilogue_kernel", "view_attend_kernel", "nchw_to_nhwc_kernel64"):
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]]
-    if d:
+import re, collections
+by = collections.defaultdict(list)
+for r in rows:
+    by[re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for key, d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+    if sum(d) * 1e3 / tot >= 0.004:
         d.sort()
         out[key] = dict(launches=len(d), avg_us=round(sum(d) / len(d), 2), median_us=round(d[len(d) // 2], 2), max_us=round(d[-1], 2),
                         share_of_gpu_time=round(sum(d) * 1e3 / tot, 4))
