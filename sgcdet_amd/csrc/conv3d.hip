@@ -32,6 +32,10 @@ namespace sgc {
 int g_conv_products = 3;     // NOT a tuning knob (it changes results; sgc_set_conv_products): 3 = fp32-faithful 3-way bf16 split
                              // (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), 1 = plain bf16 (a_hi*b_hi only: operands rounded to bf16,
                              // fp32 accumulate) -- the opt-in reduced-precision mode of BASELINE.json configs #2 / #5
+int g_tune_igemm_tall = 0;   // 1: 256 x 128 workgroup tiles (wave tile 64 x 64, one workgroup per CU) for the strided / transposed /
+                             // small-scale 3x3x3 layers.  Bit-identical; measured 3 - 50 % SLOWER than two resident 128 x 128
+                             // workgroups on every such layer (tools/igemm_tall_ab.py), kept as an option
+int g_tune_igemm_xcd = 0;    // tile implicit GEMM, XCD deal of the split / transposed layers (ConvParams.xcd_deal)
 int g_tune_conv_big = 0;     // 1: the 512 x 128 big-tile implicit GEMM (conv3d_igemm_big_kernel) for the strided / transposed / small-scale
                              // layers, 0 (default): 128 x 128 tiles.  Built and measured in round 3, bit-compatible (same tests), NOT
                              // faster: eager config-2 layers, tile -> big: 1024->1024 @10x10x4 150 -> 137 us, 512->1024 s2 89 -> 88, but
@@ -100,6 +104,9 @@ struct ConvParams {
   int two_d;              // 2-D convolution over a stack of images: grid (x, y, z) = (image, row, column), the taps only span (y, z)
                           // (sgc_conv2d_nhwc_bf16x3: the FPN output convolutions)
   unsigned long long *stamps;  // diagnostic builds only (SGC_HALO_STAMPS)
+  int xcd_deal;           // tile kernel: how workgroups are dealt to the 8 XCDs (hardware: linear id % 8).  0 = as launched;
+                          // 1 = consecutive ROW tiles of one (column tile, split) on one XCD (they share a weight slab);
+                          // 2 = consecutive COLUMN tiles of one (row tile, split) on one XCD (they share the gathered rows)
   int hm_bf16;            // head-major output stored as bfloat16 (RNE of the fp32 result)
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
@@ -256,31 +263,45 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDKH = BK + 8;   // bf16 elements per LDS row (80 B): conflict-free ds_read_b128
 
 struct ConvParamsB : ConvParams {
   const __bf16 *w_hi, *w_lo;   // [taps][Cout][Cin]
 };
 
-template <int BN, int WM, int WN, int NP = 3>   // NP: bf16 products per multiply-add (3 = fp32-faithful split, 1 = hi * hi only)
+// BMT: rows of the workgroup tile (128, or 256 = the tall tile of the split / transposed layers: wave tile 64 x 64, two thirds of the
+// LDS fragment reads per MFMA of the 32 x 64 wave tile).  NP: bf16 products per multiply-add (3 = fp32-faithful split, 1 = hi * hi only)
+template <int BN, int WM, int WN, int NP = 3, int BMT = 128>
 __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const ConvParamsB p) {
   constexpr int NT = WM * WN * 64;                     // threads per workgroup (256 or 512)
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int ACH = BM * 8 / NT;                     // float4 A chunks per thread (rows r0 + (NT/8) i)
+  constexpr int TM = BMT / WM / 32, TN = BN / WN / 32;
+  constexpr int ACH = BMT * 8 / NT;                     // float4 A chunks per thread (rows r0 + (NT/8) i)
   constexpr int AROWS = NT / 8;
   constexpr int BCH = BN * 4 / NT;                     // 16-byte weight chunks per thread per plane
   constexpr int BROWS_ = NT / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  // per buffer: A_hi[BM][LDKH], A_lo[BM][LDKH], B_hi[BN][LDKH], B_lo[BN][LDKH]
-  constexpr int A_PLANE = BM * LDKH, B_PLANE = BN * LDKH, BUF = 2 * A_PLANE + 2 * B_PLANE;
+  // per buffer: A_hi[BMT][LDKH], A_lo[BMT][LDKH], B_hi[BN][LDKH], B_lo[BN][LDKH]
+  constexpr int A_PLANE = BMT * LDKH, B_PLANE = BN * LDKH, BUF = 2 * A_PLANE + 2 * B_PLANE;
   __bf16 *base = reinterpret_cast<__bf16 *>(smem_b);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_deal) {
+    // the hardware deals workgroup L (x fastest) to XCD L % 8: XCD c holds L = c, c + 8, ...  Renumber so that the tiles an
+    // XCD works on are CONSECUTIVE in the chosen order -- neighbours then find their shared operand in that XCD's L2
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    const int L = bx + gridDim.x * (by + gridDim.y * bz);
+    const int q = total >> 3, r = total & 7, c = L & 7;
+    int t = c * q + min(c, r) + (L >> 3);
+    if (p.xcd_deal == 1) { bx = t % gridDim.x; t /= gridDim.x; by = t % gridDim.y; bz = t / gridDim.y; }
+    else                 { by = t % gridDim.y; t /= gridDim.y; bx = t % gridDim.x; bz = t / gridDim.x; }
+  }
+  const int m0 = bx * BMT, n0 = by * BN;
   const int Mrows = p.m_dev ? min(p.M, *p.m_dev) : p.M;
   if (m0 >= Mrows) return;
-  int zid = blockIdx.z;
+  int zid = bz;
   int parity = 0;
   if (p.transposed) { parity = zid % 8; zid /= 8; }
   const int taps_per = p.taps / p.splitk;
@@ -295,6 +316,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   const int r0 = 16 * (wid >> 1) + 2 * (wid & 1) + (rs8 >> 2) + 4 * (rs8 & 3);   // A: row r0 + AROWS i, 4 floats at c4*4
   const int bc = tid & 3, rs16 = (tid >> 2) & 15;
   const int br0 = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);                        // B: row br0 + BROWS_ i, 8 bf16 at bc*8
+  // Addressing is split by how often it changes.  Per TAP: the input row of each of this thread's A chunks (neighbour lookup,
+  // padding test) -> a 32-bit byte offset, 0xfffffff0 for "no such row".  Per STEP: one uniform offset (the channel chunk, and
+  // for the weights the tap's slab).  Loads go through buffer descriptors: an offset past the tensor returns zeros, so the loop
+  // has no branch and no per-step index arithmetic in the vector unit (it used to spend 280 instructions per step, 100 of them
+  // scalar divisions of the tap decode, on 12 MFMAs per wave).
+  constexpr unsigned OOB = 0xfffffff0u;
   int ax[ACH], ay[ACH], az[ACH];
   bool arow_ok[ACH];
 #pragma unroll
@@ -306,14 +333,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     ay[i] = (mm / p.gz) % p.gy;
     ax[i] = mm / (p.gz * p.gy);
   }
-  // (a second register stage -- loads of step s + 2 issued before the MFMAs of step s -- was tried: 156 VGPRs and
-  //  one workgroup per CU, or 128 with spills; 404 -> 507 us on the per-tap 90 GF layer, 143 -> 180-200 us on the
-  //  split-K layers.  Two resident workgroups at 88 VGPRs hide more latency than the deeper prefetch.)
-  float4 ra[ACH];
-  uint4 rbh[BCH], rbl[BCH];
-  auto load_step = [&](int s) {
-    const int tap = p.transposed ? parity : tap_lo + s / ksteps_c;
-    const int cib = (s % ksteps_c) * BK;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+  const int w_bytes = (int)(unsigned)((int64_t)(p.transposed ? 8 : p.taps) * p.Cout * p.Cin * 2);
+  const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
+  unsigned boff[BCH];                                  // this thread's weight rows: fixed for the whole kernel
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int n = n0 + br0 + BROWS_ * i;
+    boff[i] = n < p.Cout ? (unsigned)(n * p.Cin + bc * 8) * 2u : OOB;
+  }
+  unsigned aoff[ACH];                                  // this thread's input rows under the tap being loaded
+  auto set_tap = [&](int tap) {
     int dx = 0, dy = 0, dz = 0;
     if (!p.transposed && p.ksize > 1) {
       dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize;
@@ -324,28 +356,47 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       const int xx = ax[i] * p.stride + dx - p.pad, yy = ay[i] * p.stride + dy - p.pad,
                 zz = az[i] * p.stride + dz - p.pad;
       const bool ok = arow_ok[i] && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
+      aoff[i] = ok ? ((unsigned)((xx * p.iy + yy) * p.iz + zz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+    }
+  };
+  // (a second register stage -- loads of step s + 2 issued before the MFMAs of step s -- was tried: 156 VGPRs and
+  //  one workgroup per CU, or 128 with spills; 404 -> 507 us on the per-tap 90 GF layer, 143 -> 180-200 us on the
+  //  split-K layers.  Two resident workgroups at 88 VGPRs hide more latency than the deeper prefetch.)
+  float4 ra[ACH];
+  uint4 rbh[BCH], rbl[BCH];
+  int ld_tap = p.transposed ? parity : tap_lo, ld_kc = 0;        // (tap, channel chunk) of the NEXT load_step
+  set_tap(ld_tap);
+  auto load_step = [&]() {
+    const int soff_a = __builtin_amdgcn_readfirstlane(ld_kc * (BK * 4));
+    const int soff_b = __builtin_amdgcn_readfirstlane((ld_tap * p.Cout * p.Cin + ld_kc * BK) * 2);
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
 #if defined(SGC_DIAG_IG_NO_LOADS)
-      ra[i] = make_float4(0.001f * xx, 0.002f * yy, 0.003f * zz, ok ? 1.f : 0.f);
+      ra[i] = make_float4(0.001f * (float)aoff[i], 0.002f, 0.003f, 1.f);
 #else
-      ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + cib + c4 * 4)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff_a, 0);
+      ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 #endif
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      const int n = n0 + br0 + BROWS_ * i;
-      const int64_t off = ((int64_t)tap * p.Cout + n) * p.Cin + cib + bc * 8;
 #if defined(SGC_DIAG_IG_NO_LOADS)
-      if (n < 0) {
+      rbh[i] = make_uint4(0, 0, 0, 0); rbl[i] = make_uint4(0, 0, 0, 0);
 #else
-      if (n < p.Cout) {
-#endif
-        rbh[i] = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-        if constexpr (NP == 3) rbl[i] = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+      const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff[i], soff_b, 0);
+      rbh[i] = make_uint4(h[0], h[1], h[2], h[3]);
+      if constexpr (NP == 3) {
+        const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(wlr, boff[i], soff_b, 0);
+        rbl[i] = make_uint4(l[0], l[1], l[2], l[3]);
       } else {
-        rbh[i] = make_uint4(0, 0, 0, 0);
         rbl[i] = make_uint4(0, 0, 0, 0);
       }
+#endif
+    }
+    if (++ld_kc == ksteps_c) {                          // next tap: uniform branch, once per Cin / 32 steps
+      ld_kc = 0;
+      ++ld_tap;
+      if (!p.transposed && ld_tap < tap_lo + taps_per) set_tap(ld_tap);
     }
   };
   auto store_step = [&](int buf) {
@@ -385,14 +436,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
-  load_step(0);
+  load_step();
   store_step(0);
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) load_step(s + 1);
-    const __bf16 *a_hi = base + buf * BUF + (wm * (BM / WM) + fr) * LDKH + fh * 8;
+    if (s + 1 < nsteps) load_step();
+    const __bf16 *a_hi = base + buf * BUF + (wm * (BMT / WM) + fr) * LDKH + fh * 8;
     const __bf16 *a_lo = a_hi + A_PLANE;
     const __bf16 *b_hi = base + buf * BUF + 2 * A_PLANE + (wn * (BN / WN) + fr) * LDKH + fh * 8;
     const __bf16 *b_lo = b_hi + B_PLANE;
@@ -455,23 +506,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   // partial tiles of a split reduction, the residual and the scale / shift vectors move 16 bytes at a time too).
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
     constexpr int LDC = BN + 8;                              // floats per staged row: rows r and r + 4 (lane halves) 32 banks apart
-    float *cs = reinterpret_cast<float *>(smem_b);           // [BM][LDC] <= the 2 x (A + B) staging buffers
+    float *cs = reinterpret_cast<float *>(smem_b);           // [BMT][LDC] <= the 2 x (A + B) staging buffers
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          cs[(wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * (BN / WN) + j * 32 + (lane & 31)] =
+          cs[(wm * (BMT / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * (BN / WN) + j * 32 + (lane & 31)] =
               acc[i][j][k];
     __syncthreads();
     constexpr int C4 = BN / 4;
     if (p.hm_cm > 0) {
       // head-major store: the lanes of a wave instruction walk ROWS of one head (a head's rows are hm_cm * 4 bytes apart in
       // its plane), so a wave writes one contiguous 1 KiB run instead of 8 head segments 1 plane apart
-      const int cvh = p.hm_cm / 4, per_head = BM * cvh, heads = p.Cout / p.hm_cm;
+      const int cvh = p.hm_cm / 4, per_head = BMT * cvh, heads = p.Cout / p.hm_cm;
       const int ncam0 = m0 / p.hm_S, s0 = m0 - ncam0 * p.hm_S;
-      for (int e = tid; e < BM * C4; e += NT) {
+      for (int e = tid; e < BMT * C4; e += NT) {
         const int hl = e / per_head, rr = e - hl * per_head;
         const int rl = rr / cvh, c4 = hl * cvh + (rr - rl * cvh);
         const int m = m0 + rl, col = n0 + c4 * 4;
@@ -495,7 +546,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       }
       return;
     }
-    for (int e = tid; e < BM * C4; e += NT) {
+    for (int e = tid; e < BMT * C4; e += NT) {
       const int rl = e / C4, c4 = e - rl * C4;
       const int m = m0 + rl, col = n0 + c4 * 4;
       if (m >= Mrows || col >= p.Cout) continue;
@@ -538,7 +589,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int m = m0 + wm * (BM / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wm * (BMT / WM) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
         if (m >= Mrows) continue;
         int64_t orow = m;
         if (p.transposed) {
@@ -1526,6 +1577,12 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
   return conv_finish(p, OV, st);
 }
 
+// the tile kernel addresses its input and its weights with 32-bit byte offsets into buffer descriptors
+static bool igemm_fits_32bit(const ConvParamsB &p) {
+  const int64_t lim = 0xfffffff0ll - 65536;
+  return (int64_t)p.ix * p.iy * p.iz * p.Cin * 4 < lim && (int64_t)(p.transposed ? 8 : p.taps) * p.Cout * p.Cin * 2 < lim;
+}
+
 // one launch of the tile-per-workgroup implicit-GEMM kernel in the arithmetic mode of g_conv_products
 static void launch_igemm(const ConvParamsB &p, bool narrow, dim3 grid, size_t smem, hipStream_t st) {
   static std::atomic<uint64_t> done[6];
@@ -1543,6 +1600,24 @@ static void launch_igemm(const ConvParamsB &p, bool narrow, dim3 grid, size_t sm
   if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
   else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
   else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
+}
+
+// the tall tile: 256 x 128, 8 waves as 4 x 2 (wave tile 64 x 64), one workgroup per CU
+constexpr int BM_TALL = 256;
+constexpr size_t SMEM_TALL = (size_t)BM_TALL * (128 + 8) * sizeof(float) > (size_t)2 * (2 * BM_TALL + 2 * 128) * LDKH * sizeof(uint16_t)
+                                 ? (size_t)BM_TALL * (128 + 8) * sizeof(float) : (size_t)2 * (2 * BM_TALL + 2 * 128) * LDKH * sizeof(uint16_t);
+static bool use_tall_tile(const ConvParams &p, int Cout) {
+  return g_tune_igemm_tall && Cout > 64 && (p.taps > 1 || p.transposed) && !p.two_d && !p.out_mask && p.hm_cm == 0 && p.M > BM;
+}
+static void launch_igemm_tall(const ConvParamsB &p, dim3 grid, hipStream_t st) {
+  static std::atomic<uint64_t> done[2];
+  if (g_conv_products == 1) {
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 1, BM_TALL>, (int)SMEM_TALL, done[0]);
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 1, BM_TALL>), grid, dim3(512), SMEM_TALL, st, p);
+  } else {
+    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 3, BM_TALL>, (int)SMEM_TALL, done[1]);
+    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 3, BM_TALL>), grid, dim3(512), SMEM_TALL, st, p);
+  }
 }
 
 // Same contract with the weights pre-split on the host: w_hi = bf16(w), w_lo = bf16(w - float(w_hi)),
@@ -1611,8 +1686,9 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   }
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
-  const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
-  p.splitk = pick_splitk(p, mb, nb, g_tune_split_target);
+  const bool tall = use_tall_tile(p, Cout);
+  const int mb = ceil_div(p.M, tall ? BM_TALL : BM), nb = ceil_div(Cout, bn);
+  p.splitk = pick_splitk(p, mb, nb, tall ? g_tune_split_target / 2 : g_tune_split_target);   // tall: one workgroup per CU
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
     if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
@@ -1625,7 +1701,10 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   }
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
-  launch_igemm(p, narrow, grid, smem, st);
+  p.xcd_deal = (p.taps > 1 || transposed) && !p.two_d ? g_tune_igemm_xcd : 0;
+  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "conv3d: input and weight tensors must stay below 4 GiB each");
+  if (tall) launch_igemm_tall(p, grid, st);
+  else launch_igemm(p, narrow, grid, smem, st);
   rc = check_launch("conv3d_igemm_bf16x3_kernel");
   if (rc) return rc;
   return conv_finish(p, OV, st);
@@ -1968,7 +2047,8 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     }
     p.taps = transposed ? 8 : ksize * ksize * ksize;
     const int bn = bf16x3 ? (Cout <= 64 ? 64 : 128) : (Cout <= 32 ? 32 : 128);
-    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target);
+    const bool tall = bf16x3 && Cin % BK == 0 && use_tall_tile(p, Cout);               // mirrors conv3d_bf16x3
+    splitk = pick_splitk(p, ceil_div((int)M, tall ? BM_TALL : BM), ceil_div(Cout, bn), tall ? g_tune_split_target / 2 : g_tune_split_target);
   }
   return splitk > 1 ? (int64_t)splitk * OV * Cout : 0;
 }
@@ -2003,6 +2083,7 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   hipStream_t st = (hipStream_t)stream;
+  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: input and weight tensors must stay below 4 GiB each");
   launch_igemm(p, narrow, grid, smem, st);
   return check_launch("conv3d_igemm_bf16x3_kernel (linear rows)");
 }
