@@ -971,7 +971,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     // halo rows through BUFFER loads: rows outside the volume (and the padding slots past HROWS) get an out-of-range
     // offset and come back as zeros, so every wave issues exactly NA load instructions -- the counted waits below rely
     // on it (with plain loads the compiler branches around a load whose lanes are all outside the volume)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.x), 0, (int)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
     auto load_A = [&](int cc) {
@@ -1126,27 +1125,42 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   } else {
     float4 ra[NA];
     uint4 rbh, rbl;
+    // Addressing is fixed per thread for the whole kernel (the halo rows a thread stages and its weight row do not depend on the
+    // channel slice or the tap): one 32-bit byte offset per chunk, 0xfffffff0 = "outside the volume / padding slot", computed once;
+    // a slice / a tap then only moves a uniform offset.  Buffer loads return zeros past the tensor, so the loads carry no branch.
+    // (It used to redo the row decode, the bounds test and a 64-bit address per chunk in every slice: ~500 vector instructions per
+    //  wave and slice injected into the last taps' MFMA stream.)
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+    const int w_bytes = (int)(unsigned)((int64_t)27 * p.Cout * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
+    unsigned aoff[NA];
+    int alds[NA];                                   // LDS element offset of the chunk, -1 = padding slot past HROWS
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = i * NT + tid;
+      const int row = idx >> 3, c4 = idx & 7;
+      const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
+      const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+      const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
+      aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+      alds[i] = row < HROWS ? ((row / HZ) * HZP + row % HZ) * LDKH + c4 * 4 : -1;
+    }
+    const unsigned boff = bn_ok ? (unsigned)((n0 + bn) * p.Cin + bc * 8) * 2u : OOB;
     auto load_A = [&](int cc) {
+      const int soff = __builtin_amdgcn_readfirstlane(cc * (BK * 4));
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int idx = i * NT + tid;
-        const int row = idx >> 3, c4 = idx & 7;
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < HROWS) {
-          const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-          const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
-          if (gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz)
-            ra[i] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4);
-        }
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff, 0);
+        ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
       }
     };
     auto store_A = [&]() {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int idx = i * NT + tid;
-        const int row = idx >> 3, c4 = idx & 7;
-        if (row < HROWS) {
-          const int lrow = (row / HZ) * HZP + row % HZ;
+        if (alds[i] >= 0) {
           const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
           bf16x4 h, l;
 #pragma unroll
@@ -1155,18 +1169,19 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             h[e] = hb;
             l[e] = (__bf16)(v[e] - (float)hb);
           }
-          *reinterpret_cast<bf16x4 *>(A_hi + lrow * LDKH + c4 * 4) = h;
-          if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(A_lo + lrow * LDKH + c4 * 4) = l;
+          *reinterpret_cast<bf16x4 *>(A_hi + alds[i]) = h;
+          if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(A_lo + alds[i]) = l;
         }
       }
     };
     auto load_B = [&](int tap, int cc) {
-      if (bn_ok) {
-        const int64_t off = ((int64_t)tap * p.Cout + n0 + bn) * p.Cin + cc * BK + bc * 8;
-        rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-        if constexpr (NP == 3) rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
+      const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
+      const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff, soff, 0);
+      rbh = make_uint4(h[0], h[1], h[2], h[3]);
+      if constexpr (NP == 3) {
+        const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(wlr, boff, soff, 0);
+        rbl = make_uint4(l[0], l[1], l[2], l[3]);
       } else {
-        rbh = make_uint4(0, 0, 0, 0);
         rbl = make_uint4(0, 0, 0, 0);
       }
     };
@@ -1636,6 +1651,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.scale = scale; p.shift = shift; p.residual = residual_or_null;
   p.ws = workspace_or_null; p.ws_floats = workspace_or_null ? workspace_floats : 0;
+  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_bf16x3: input and weight tensors must stay below 4 GiB each");
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
   // 1x1x1 stride-1 layers are row GEMMs (the FFN of a level, TU/encoder.py:311-338): persistent weight-stationary kernel
@@ -1702,7 +1718,6 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   p.xcd_deal = (p.taps > 1 || transposed) && !p.two_d ? g_tune_igemm_xcd : 0;
-  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "conv3d: input and weight tensors must stay below 4 GiB each");
   if (tall) launch_igemm_tall(p, grid, st);
   else launch_igemm(p, narrow, grid, smem, st);
   rc = check_launch("conv3d_igemm_bf16x3_kernel");
