@@ -1744,6 +1744,7 @@ struct WgradParams {
   int ix, iy, iz, ox, oy, oz;
   int ksize, stride, pad, taps;
   int OV, ksteps, splits, steps_per_split;
+  int ax, by, cz;           // 32 = ax * (oy * oz) + by * oz + cz: the per-step advance of a voxel's (x, y, z) (see load_step)
 };
 
 // WM = 2: 4 waves (2 x 2, 64 x 64 each), every thread stages one block of BOTH operands; WM = 4: 8 waves (4 x 2, 32 x 64 each),
@@ -1764,24 +1765,56 @@ __global__ __launch_bounds__(WM * 128) void conv3d_wgrad_bf16x3_kernel(const Wgr
   int dx = 0, dy_ = 0, dz = 0;
   if (p.ksize > 1) { dx = tap / (p.ksize * p.ksize); dy_ = (tap / p.ksize) % p.ksize; dz = tap % p.ksize; }
 
-  const int role = WM == 4 ? (tid >> 8) : 2;                // 0: stages dy, 1: stages x, 2: both
+  const int role = WM == 4 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 2;   // 0: stages dy, 1: stages x, 2: both (wave-uniform)
   const int kb = tid & 7, cb = (tid & 255) >> 3;            // this thread's block: voxels 4 kb .. + 3 of the step, channels 4 cb .. + 3
   const bool a_ok = role != 1 && co0 + 4 * cb < p.Cout, b_ok = role != 0 && ci0 + 4 * cb < p.Cin;
   float4 ra[4], rb[4];
-  auto load_step = [&](int s) {
+  // Addressing without a division in the loop: a thread's four voxels advance by 32 per step, so their (x, y, z) are carried
+  // (32 = ax * oy * oz + by * oz + cz, uniform digits from the host: z += cz, y += by + carry, x += ax + carry) instead of decoded from the flat index with two runtime divisions per voxel and step; loads go
+  // through buffer descriptors, an out-of-range offset (voxel past OV, neighbour outside the volume, channel block past the
+  // tensor) returns zeros, so there is no branch either.
+  constexpr unsigned OOB = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.dy), 0, (int)(unsigned)((int64_t)p.OV * p.Cout * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+  int vx[4], vy[4], vz[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = s_lo * 32 + 4 * kb + j;                   // may be >= OV: the coordinates then run past ox and the loads are OOB
+    vz[j] = o % p.oz; vy[j] = (o / p.oz) % p.oy; vx[j] = o / (p.oz * p.oy);
+  }
+  int o_base = s_lo * 32 + 4 * kb;
+  auto load_step = [&]() {                                  // loads the step the carried coordinates stand at, then advances them
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int o = s * 32 + 4 * kb + j;
-      ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[j] = ra[j];
-      if (o < p.OV) {
-        if (a_ok) ra[j] = *reinterpret_cast<const float4 *>(p.dy + (int64_t)o * p.Cout + co0 + 4 * cb);
-        const int z = o % p.oz, y = (o / p.oz) % p.oy, x = o / (p.oz * p.oy);
-        const int xx = x * p.stride + dx - p.pad, yy = y * p.stride + dy_ - p.pad, zz = z * p.stride + dz - p.pad;
-        if (b_ok && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz)
-          rb[j] = *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + ci0 + 4 * cb);
+      const int o = o_base + j;
+      const bool live = o < p.OV;
+      if (role != 1) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dyr, live && a_ok ? (unsigned)(o * p.Cout + co0 + 4 * cb) * 4u : OOB, 0, 0);
+        ra[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      }
+      if (role != 0) {
+        const int xx = vx[j] * p.stride + dx - p.pad, yy = vy[j] * p.stride + dy_ - p.pad, zz = vz[j] * p.stride + dz - p.pad;
+        const bool in = live && b_ok && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+            xr, in ? ((unsigned)((xx * p.iy + yy) * p.iz + zz) * (unsigned)p.Cin + ci0 + 4 * cb) * 4u : OOB, 0, 0);
+        rb[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
       }
     }
+    if (role != 0) {                                        // carry the coordinates to the next step: selects only, no branch
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vz[j] += p.cz;                                      // 32 = ax * (oy * oz) + by * oz + cz: one carry per digit, always exact
+        const int c1 = vz[j] >= p.oz ? 1 : 0;
+        vz[j] -= c1 ? p.oz : 0;
+        vy[j] += p.by + c1;
+        const int c2 = vy[j] >= p.oy ? 1 : 0;
+        vy[j] -= c2 ? p.oy : 0;
+        vx[j] += p.ax + c2;
+      }
+    }
+    o_base += 32;
   };
   auto store_block = [&](const float4 (&r)[4], __bf16 *hi, __bf16 *lo) {
     const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
@@ -1815,13 +1848,13 @@ __global__ __launch_bounds__(WM * 128) void conv3d_wgrad_bf16x3_kernel(const Wgr
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
   if (s_lo < s_hi) {
-    load_step(s_lo);
+    load_step();
     store_step(0);
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
     for (int s = s_lo; s < s_hi; ++s) {
       const int buf = (s - s_lo) & 1;
-      if (s + 1 < s_hi) load_step(s + 1);
+      if (s + 1 < s_hi) load_step();
       const __bf16 *a_hi = base + buf * BUF + (wm * (32 * TMW) + fr) * LDKH + fh * 8;
       const __bf16 *a_lo = a_hi + PLANE;
       const __bf16 *b_hi = base + buf * BUF + 2 * PLANE + (wn * 64 + fr) * LDKH + fh * 8;
@@ -1901,6 +1934,9 @@ static int wgrad_geometry(WgradParams &p, int ix, int iy, int iz, int Cin, int C
   while (tiles * splits < 512 && p.ksteps / (splits * 2) >= 16) splits *= 2;     // fill the chip twice over; >= 16 K-steps per split
   p.steps_per_split = ceil_div(p.ksteps, splits);
   p.splits = ceil_div(p.ksteps, p.steps_per_split);
+  p.ax = 32 / (p.oy * p.oz); p.by = (32 % (p.oy * p.oz)) / p.oz; p.cz = 32 % p.oz;
+  if ((int64_t)p.OV * Cout * 4 >= 0xfffffff0ll - 65536 || (int64_t)ix * iy * iz * Cin * 4 >= 0xfffffff0ll - 65536)
+    return set_error(SGC_EUNSUP, "sgc_conv3d_wgrad_bf16x3: x and dy must stay below 4 GiB each");
   return SGC_OK;
 }
 

@@ -27,30 +27,35 @@ struct PackParams {
 
 constexpr int PK = 32;
 
-__global__ __launch_bounds__(512) void pack_conv_weight_kernel(const PackParams p) {
-  extern __shared__ float pk_lds[];                 // [PK a][PK b][T] (+1 pad per a-row)
-  const int T = p.T, pitch = PK * T + 1;
-  const int a0 = blockIdx.y * PK, b0 = blockIdx.x * PK;
-  const int tid = threadIdx.x;
-  // load: for every a of the tile the run [b0, b0 + PK) x T is contiguous in w (4 bytes per lane, 256-byte wave accesses)
-  const int run = PK * T;
-  const int nvalid_b = (p.B - b0 < PK ? p.B - b0 : PK) * T;
-  for (int a = 0; a < PK; ++a) {
+// Block of the pack kernel: PA x PB x T parameter elements, PB * T of them contiguous in the source.  The OUTPUT is contiguous
+// along c, and a block has to carry 32 of them (64-byte segments per plane): c = b in the plain layout -> 8 a x 32 b; c = a in
+// the transposed one -> 32 a x 8 b.  27.6 KB of LDS at 27 taps: five workgroups per CU (the first version moved 32 x 32 x T
+// blocks, 110 KB and one 8-wave workgroup per CU, through one barrier: 0.5 TB/s, 2.4 ms per training step).
+template <int PA, int PB>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const PackParams p) {
+  extern __shared__ float pk_lds[];                 // [PA a][PB b][T] (+1 pad per a-row)
+  constexpr bool TR = PA == 32;                     // the transposed layout (c = a)
+  const int T = p.T, run = PB * T, pitch = run + 1;
+  const int a0 = blockIdx.y * PA, b0 = blockIdx.x * PB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // load: for every a of the block the run [b0, b0 + PB) x T is contiguous in w; a wave takes whole runs
+  const int nvalid_b = (p.B - b0 < PB ? p.B - b0 : PB) * T;
+  for (int a = wid; a < PA; a += 4) {
     const int nvalid = a0 + a < p.A ? nvalid_b : 0;
     const float *wrow = p.w + ((int64_t)(a0 + a) * p.B + b0) * T;
-    for (int i = tid; i < run; i += 512) pk_lds[a * pitch + i] = i < nvalid ? wrow[i] : 0.f;
+    for (int i = lane; i < run; i += 64) pk_lds[a * pitch + i] = i < nvalid ? wrow[i] : 0.f;
   }
   __syncthreads();
-  // store: units of 8 consecutive c of one (t, r): 16-byte hi and lo stores, a 32-column row segment = 4 lanes
-  const int units = T * PK * 4;
+  // store: units of 8 consecutive c of one (t, r): 16-byte hi and lo stores, the 4 units of a 32-column row segment on 4 lanes
+  const int units = T * 8 * 4;
   const bool vec = (p.C & 7) == 0;
-  for (int u = tid; u < units; u += 512) {
-    const int c8 = u & 3, r = (u >> 2) & (PK - 1), t = u >> 7;
-    const int gr = (p.transpose ? b0 : a0) + r, gc = (p.transpose ? a0 : b0) + c8 * 8;
+  for (int u = tid; u < units; u += 256) {
+    const int c8 = u & 3, r = (u >> 2) & 7, t = u >> 5;
+    const int gr = (TR ? b0 : a0) + r, gc = (TR ? a0 : b0) + c8 * 8;
     if (gr >= p.R || gc >= p.C) continue;
     const int ts = p.flip ? T - 1 - t : t;
-    const float *src = p.transpose ? pk_lds + (c8 * 8) * pitch + r * T + ts : pk_lds + r * pitch + (c8 * 8) * T + ts;
-    const int step = p.transpose ? pitch : T;
+    const float *src = TR ? pk_lds + (c8 * 8) * pitch + r * T + ts : pk_lds + r * pitch + (c8 * 8) * T + ts;
+    const int step = TR ? pitch : T;
     __bf16 h[8], l[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -105,15 +110,23 @@ __global__ __launch_bounds__(512) void unpack_conv_wgrad_kernel(const PackParams
 }
 
 static int pack_launch(bool unpack, const PackParams &p, hipStream_t st) {
+  if (!unpack) {
+    const size_t smem = (size_t)8 * 32 * p.T * sizeof(float) + 32 * sizeof(float);       // [PA][PB * T + 1], PA * PB = 256
+    if (smem > 64 * 1024) return set_error(SGC_EUNSUP, "weight pack: %d taps do not fit the block in LDS", p.T);
+    if (p.transpose) {
+      hipLaunchKernelGGL((pack_conv_weight_kernel<32, 8>), dim3(ceil_div(p.B, 8), ceil_div(p.A, 32)), dim3(256), smem, st, p);
+    } else {
+      hipLaunchKernelGGL((pack_conv_weight_kernel<8, 32>), dim3(ceil_div(p.B, 32), ceil_div(p.A, 8)), dim3(256), smem, st, p);
+    }
+    return check_launch("pack_conv_weight_kernel");
+  }
   const size_t smem = (size_t)PK * (PK * p.T + 1) * sizeof(float);
   if (smem > 160 * 1024) return set_error(SGC_EUNSUP, "weight pack: %d taps do not fit the 32 x 32 block in LDS", p.T);
-  static std::atomic<uint64_t> done_a{0}, done_b{0};
-  ensure_dynamic_lds((const void *)pack_conv_weight_kernel, 160 * 1024, done_a);
+  static std::atomic<uint64_t> done_b{0};
   ensure_dynamic_lds((const void *)unpack_conv_wgrad_kernel, 160 * 1024, done_b);
   const dim3 grid(ceil_div(p.B, PK), ceil_div(p.A, PK));
-  if (unpack) hipLaunchKernelGGL(unpack_conv_wgrad_kernel, grid, dim3(512), smem, st, p);
-  else hipLaunchKernelGGL(pack_conv_weight_kernel, grid, dim3(512), smem, st, p);
-  return check_launch(unpack ? "unpack_conv_wgrad_kernel" : "pack_conv_weight_kernel");
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, grid, dim3(512), smem, st, p);
+  return check_launch("unpack_conv_wgrad_kernel");
 }
 
 }  // namespace sgc
