@@ -367,20 +367,17 @@ def main():
         tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
         ops.event_log = []
         ops.event_names = None if args.breakdown else PATH_KERNELS
-        ops.event_sync = True            # each bracketed launch starts on a drained stream (see TensorOps._call)
         calls0 = ops.n_calls
-        import contextlib
-        with torch.no_grad(), (torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()):
+        with torch.no_grad():
             for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
                 feats, dpt, metas = scenes[i % n_scenes]
                 det.forward_features(feats, metas, dpt)
                 torch.cuda.synchronize()
         log, ops.event_log = ops.event_log, None
-        ops.event_sync = False
         lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
         det.scene_graph, det.use_graph = True, tail_graph
-        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, each "
-                         "bracketed launch on a drained stream, right after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
+        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
+                         "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
                          "events; inside it the kernel shares the chip with the other scenes in flight and runs 0-3 % longer, see "
                          "profiles/r02_kernels_from_trace.json)")
 

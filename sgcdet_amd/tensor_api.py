@@ -28,7 +28,6 @@ class TensorOps:
         # when set to a list, every CUDA call is bracketed by HIP events on the launch stream
         # and (name, meta, start, end) is appended -- bench.py's per-kernel timing
         self.event_log = None
-        self.event_sync = False
         self.event_names = None      # optional set of entry points to time (None = all)
 
     # ---- argument checks ------------------------------------------------
@@ -84,8 +83,6 @@ class TensorOps:
                 return self.lib.call(name, *ptrs, _stream_ptr("cuda", idx))
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            if self.event_sync:         # drain the stream first: the start event then never carries a tail of earlier work
-                torch.cuda.current_stream().synchronize()
             e0.record()
             rc = self.lib.call(name, *ptrs, _stream_ptr("cuda", idx))
             e1.record()
