@@ -54,7 +54,9 @@ int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 12
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_narrow = 1;       // halo kernel: 64-column tiles for layers with <= 64 output channels
-int g_tune_halo_nb = 2;           // halo kernel: weight buffers of the staged form (3 = staged two taps ahead; 8x8x4 brick only, see the kernel).
+int g_tune_halo_nb = 2;           // halo kernel: weight buffers of the staged form (3 = staged two taps ahead; 8x8x4 brick only, see the kernel;
+                                  // 0 = direct-B form: weights straight into registers, no barrier per tap -- bit-identical, measured equal
+                                  // on the 90-GF layer (236 vs 229-240 us warm) and 2-7 % slower on the others, tools/halo_nb_ab.py).
                                   // Round 3, interleaved A/B on the 8x8x4 brick, bit-identical: 3 buffers 246 - 249 vs 236 - 239 us (2 buffers);
                                   // with the fragment reads pinned by scheduling barriers (second k-half before the first half's MFMAs, next
                                   // tap's first half before the second half's) 252 - 254 us with 2 buffers, 254 - 255 with 3: the compiler's own
@@ -844,9 +846,18 @@ unsigned long long *g_halo_stamp_buf = nullptr;
 template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   static_assert(NP == 3 || !RING, "the single-product mode uses the staged form");
-  static_assert(NB == 2 || !RING, "three weight buffers belong to the staged form");
+  static_assert(NB == 2 || !RING, "three / no weight buffers belong to the staged form");
   static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
-  constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
+  // NB == 0: DIRECT-B form.  The weights never pass through LDS: the 8 waves are laid out 2 (voxels) x 4 (columns), a wave
+  // owns 128 voxels x 32 columns and loads the B fragments of its own 32 columns straight from global memory into registers,
+  // one tap ahead (each fragment is fetched by the two voxel-waves only, 32 KB per tap and CU through the L1).  No weight
+  // ds_write, no barrier per tap: the halo image is read-only within a channel slice, so waves run free for 27 taps.
+  // (Ablations of the staged form, warm, 90-GF layer: 236 us; without the weight loads 215, without the weight ds_writes 210,
+  //  without the barrier per tap 225, without all three 187 -- tools/halo_ablate.py.)
+  constexpr bool DB = NB == 0;
+  static_assert(!DB || (BNV == 128 && !RING), "the direct-B form is built for 128-column tiles of the staged form");
+  constexpr int RT = DB ? 4 : 2;                        // 32-row tiles per wave
+  constexpr int TN = DB ? 1 : BNV / 64, WCOL = DB ? 32 : BNV / 2;   // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int NT = 512;
@@ -860,7 +871,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, RING, NB));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = DB ? wid >> 2 : wid >> 1, wn = DB ? wid & 3 : wid & 1;
   const int nbx = (p.gx + BX - 1) / BX, nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
   (void)nbx;
   int bid = blockIdx.x;
@@ -896,10 +907,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   }
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
-  int arow[2];
+  int arow[RT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = vox_tab[(wm * 2 + i) * 32 + fr];
+  for (int i = 0; i < RT; ++i) {
+    const int r = vox_tab[(wm * RT + i) * 32 + fr];
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
     arow[i] = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
   }
@@ -908,8 +919,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   if (p.out_mask) {
     bool mine = false;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = vox_tab[(wm * 2 + i) * 32 + fr];
+    for (int i = 0; i < RT; ++i) {
+      const int r = vox_tab[(wm * RT + i) * 32 + fr];
       const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
       if (x < p.gx && y < p.gy && z < p.gz) mine |= p.out_mask[((int64_t)x * p.gy + y) * p.gz + z] != 0;
     }
@@ -943,9 +954,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   const int bn = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);
   const bool bn_ok = tid < BNV * 4 && n0 + bn < p.Cout;     // BNV * 4 sixteen-byte chunks per plane and tap
 
-  f32x16 acc[2][TN];
+  f32x16 acc[RT][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1175,6 +1186,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       }
     };
     auto load_B = [&](int tap, int cc) {
+#if defined(SGC_DIAG_HALO_NO_BLOAD)
+      rbh = make_uint4(tap, cc, 0, 0); rbl = rbh;
+      return;
+#endif
       const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
       const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff, soff, 0);
       rbh = make_uint4(h[0], h[1], h[2], h[3]);
@@ -1187,112 +1202,192 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     };
     auto store_B = [&](int buf) {
       if (tid >= BNV * 4) return;
+#if defined(SGC_DIAG_HALO_NO_BWRITE)
+      if (rbh.x == 0x12345678u)
+#endif
+      {
       __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
       *reinterpret_cast<uint4 *>(b) = rbh;
       if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
+      }
     };
 
-    int g = 0;                       // global step counter -> B buffer
-    const int steps_total = (c_hi - c_lo) * 27;
-    auto step_tap = [&](int st) { return st % 27; };
-    auto step_cc = [&](int st) { return c_lo + st / 27; };
-    load_A(c_lo);
-    load_B(0, c_lo);
-    store_A();
-    store_B(0);
-    if constexpr (NB == 3) {
-      if (steps_total > 1) { load_B(step_tap(1), step_cc(1)); store_B(1); }
-    }
-    __syncthreads();
-    // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
-    // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
-    // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
-    //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
-    bf16x8 ah_n[2] = {}, al_n[2] = {};
-    bf16x8 bh_n[TN] = {}, bl_n[TN] = {};          // NB == 3: first-k-half B fragments of the next tap
-    auto read_A0 = [&](int tap) {
-      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-      const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+    if constexpr (DB) {
+      // ---- direct-B form ----
+      const int bcol = n0 + wn * 32 + fr;                                  // this lane's weight row (MFMA B operand: column fr of the tile)
+      const unsigned bfoff = bcol < p.Cout ? (unsigned)(bcol * p.Cin + fh * 8) * 2u : OOB;
+      bf16x8 bh_c[2], bl_c[2], bh_x[2], bl_x[2];                           // fragments of the tap being multiplied / of the next one
+      auto load_Bf = [&](int tap, int cc, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
+        const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int o = (arow[i] + toff) * LDKH + fh * 8;
-        ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-        if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-      }
-    };
-    auto read_B0 = [&](int buf) {
-      const __bf16 *b = Bbase + buf * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh_n[j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * LDKH);
-        if constexpr (NP == 3) bl_n[j] = *reinterpret_cast<const bf16x8 *>(b + B_PLANE + j * 32 * LDKH);
-      }
-    };
-    read_A0(0);
-    if constexpr (NB == 3) read_B0(0);
-    int bcur = 0;                    // buffer of the tap being multiplied (NB == 3: g % 3 without the division)
-    for (int cc = c_lo; cc < c_hi; ++cc) {
-      for (int tap = 0; tap < 27; ++tap, ++g) {
-        const bool last_tap = tap == 26;
-        const bool more = !last_tap || cc + 1 < c_hi;
-        const int ahead = NB == 3 ? 2 : 1;                       // taps the weight staging runs ahead
-        const bool more_b = g + ahead < steps_total;
-        if (more_b) load_B(step_tap(g + ahead), step_cc(g + ahead));
-        if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+        for (int kk = 0; kk < 2; ++kk) {
+          h[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(whr, bfoff, soff + kk * 32, 0));
+          if constexpr (NP == 3) l[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wlr, bfoff, soff + kk * 32, 0));
+        }
+      };
+      bf16x8 ah_n[RT] = {}, al_n[RT] = {};
+      auto read_A0 = [&](int tap) {
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
-        const int bsel = NB == 3 ? bcur : (g & 1);
-        const __bf16 *bh_ = Bbase + bsel * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
-        const __bf16 *bl_ = bh_ + B_PLANE;
-        const int bnext = NB == 3 ? (bcur == 2 ? 0 : bcur + 1) : 0;
-        if (wave_live) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 ah[2], al[2], bh[TN], bl[TN];
+        for (int i = 0; i < RT; ++i) {
+          const int o = (arow[i] + toff) * LDKH + fh * 8;
+          ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+          if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+        }
+      };
+      load_A(c_lo);
+      load_Bf(0, c_lo, bh_c, bl_c);
+      store_A();
+      __syncthreads();
+      if (wave_live) read_A0(0);
+      for (int cc = c_lo; cc < c_hi; ++cc) {
+        for (int tap = 0; tap < 27; ++tap) {
+          const bool last_tap = tap == 26;
+          const bool more = !last_tap || cc + 1 < c_hi;
+          if (more) load_Bf(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc, bh_x, bl_x);
+          if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);          // next slice's halo rides under the last taps
+          const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+          const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+          if (wave_live) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            if (kk == 0) {
-              ah[i] = ah_n[i]; al[i] = al_n[i];
-            } else {
-              const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
-              ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-              if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-            }
-          }
+            for (int kk = 0; kk < 2; ++kk) {
+              bf16x8 ah[RT], al[RT];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if (NB == 3 && kk == 0) {
-              bh[j] = bh_n[j]; bl[j] = bl_n[j];
-            } else {
-              bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
-              if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              if constexpr (NP == 3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              for (int i = 0; i < RT; ++i) {
+                if (kk == 0) {
+                  ah[i] = ah_n[i]; al[i] = al_n[i];
+                } else {
+                  const int o = (arow[i] + toff) * LDKH + fh * 8 + 16;
+                  ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+                  if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+                }
               }
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < RT; ++i) {
+                if constexpr (NP == 3) {
+                  acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh_c[kk], acc[i][0], 0, 0, 0);
+                  acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl_c[kk], acc[i][0], 0, 0, 0);
+                }
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh_c[kk], acc[i][0], 0, 0, 0);
+              }
             }
+            if (!last_tap) read_A0(tap + 1);
+          }
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) { bh_c[kk] = bh_x[kk]; bl_c[kk] = bl_x[kk]; }
         }
-        if (!last_tap) read_A0(tap + 1);
-        if constexpr (NB == 3) { if (more) read_B0(bnext); }     // published by the barrier that ended the previous tap
+        if (cc + 1 < c_hi) {
+          __syncthreads();              // every wave is past the last tap of this slice: the halo can be replaced
+          store_A();
+          __syncthreads();
+          if (wave_live) read_A0(0);
         }
-        if (more_b) store_B(NB == 3 ? (bnext == 2 ? 0 : bnext + 1) : ((g + 1) & 1));
-        bcur = bnext;
-        __syncthreads();
       }
-      if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
-        store_A();
-        __syncthreads();
-        if (wave_live) read_A0(0);
+    } else {
+      int g = 0;                       // global step counter -> B buffer
+      const int steps_total = (c_hi - c_lo) * 27;
+      auto step_tap = [&](int st) { return st % 27; };
+      auto step_cc = [&](int st) { return c_lo + st / 27; };
+      load_A(c_lo);
+      load_B(0, c_lo);
+      store_A();
+      store_B(0);
+      if constexpr (NB == 3) {
+        if (steps_total > 1) { load_B(step_tap(1), step_cc(1)); store_B(1); }
+      }
+      __syncthreads();
+      // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
+      // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
+      // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
+      //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
+      bf16x8 ah_n[2] = {}, al_n[2] = {};
+      bf16x8 bh_n[TN] = {}, bl_n[TN] = {};          // NB == 3: first-k-half B fragments of the next tap
+      auto read_A0 = [&](int tap) {
+        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+  #pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int o = (arow[i] + toff) * LDKH + fh * 8;
+          ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+          if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+        }
+      };
+      auto read_B0 = [&](int buf) {
+        const __bf16 *b = Bbase + buf * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh_n[j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * LDKH);
+          if constexpr (NP == 3) bl_n[j] = *reinterpret_cast<const bf16x8 *>(b + B_PLANE + j * 32 * LDKH);
+        }
+      };
+      read_A0(0);
+      if constexpr (NB == 3) read_B0(0);
+      int bcur = 0;                    // buffer of the tap being multiplied (NB == 3: g % 3 without the division)
+      for (int cc = c_lo; cc < c_hi; ++cc) {
+        for (int tap = 0; tap < 27; ++tap, ++g) {
+          const bool last_tap = tap == 26;
+          const bool more = !last_tap || cc + 1 < c_hi;
+          const int ahead = NB == 3 ? 2 : 1;                       // taps the weight staging runs ahead
+          const bool more_b = g + ahead < steps_total;
+          if (more_b) load_B(step_tap(g + ahead), step_cc(g + ahead));
+          if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+          const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+          const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+          const int bsel = NB == 3 ? bcur : (g & 1);
+          const __bf16 *bh_ = Bbase + bsel * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
+          const __bf16 *bl_ = bh_ + B_PLANE;
+          const int bnext = NB == 3 ? (bcur == 2 ? 0 : bcur + 1) : 0;
+          if (wave_live) {
+  #pragma unroll
+          for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 ah[2], al[2], bh[TN], bl[TN];
+  #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              if (kk == 0) {
+                ah[i] = ah_n[i]; al[i] = al_n[i];
+              } else {
+                const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+                if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+              }
+            }
+  #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (NB == 3 && kk == 0) {
+                bh[j] = bh_n[j]; bl[j] = bl_n[j];
+              } else {
+                bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
+                if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
+              }
+            }
+  #pragma unroll
+            for (int i = 0; i < 2; ++i)
+  #pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                if constexpr (NP == 3) {
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          }
+          if (!last_tap) read_A0(tap + 1);
+          if constexpr (NB == 3) { if (more) read_B0(bnext); }     // published by the barrier that ended the previous tap
+          }
+          if (more_b) store_B(NB == 3 ? (bnext == 2 ? 0 : bnext + 1) : ((g + 1) & 1));
+          bcur = bnext;
+  #if !defined(SGC_DIAG_HALO_NO_TAPBARRIER)
+          __syncthreads();
+  #endif
+        }
+        if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
+          store_A();
+          __syncthreads();
+          if (wave_live) read_A0(0);
+        }
       }
     }
-
   }
 
 #if defined(SGC_HALO_STAMPS)
@@ -1303,13 +1398,14 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
     constexpr int LDC = BNV + 8;
     float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 139 KB (launch_halo sizes LDS for it)
+    if constexpr (DB) __syncthreads();                       // free-running waves: the tile overlays the halo image others may still read
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          cs[(wm * 64 + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * WCOL + j * 32 + (lane & 31)] = acc[i][j][k];
+          cs[(wm * (RT * 32) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * WCOL + j * 32 + (lane & 31)] = acc[i][j][k];
     __syncthreads();
     constexpr int C4 = BNV / 4;
     for (int e = tid; e < 256 * C4; e += NT) {
@@ -1345,7 +1441,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   }
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WCOL + j * 32 + (lane & 31);
@@ -1353,7 +1449,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int r = vox_tab[(wm * 2 + i) * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)];
+        const int r = vox_tab[(wm * RT + i) * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)];
         const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
         if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
         const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
@@ -1426,6 +1522,12 @@ template <int BX, int BY, int BZ, bool RING, int BNV = 128>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   // three weight buffers where the LDS holds them: the 8x8x4 brick (157.9 KB); never with the LDS-DMA ring
   constexpr bool nb3_fits = halo_tab_offset((BX + 2) * (BY + 2) * halo_pitch(BZ), false, 3) + 512 <= 160 * 1024;
+  if constexpr (BNV == 128 && !RING) {
+    if (g_tune_halo_nb == 0) {                                 // direct-B form (no weight buffers in LDS)
+      if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1, 0>(p, OV, st);
+      return launch_halo_np<BX, BY, BZ, false, BNV, 3, 0>(p, OV, st);
+    }
+  }
   if constexpr (nb3_fits && !RING) {
     if (g_tune_halo_nb == 3) {
       if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1, 3>(p, OV, st);
