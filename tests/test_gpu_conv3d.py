@@ -381,3 +381,65 @@ def test_big_tile_form_of_the_implicit_gemm_against_oracle_and_tile_kernel(cin, 
     scale = max(1.0, float(y_o.abs().max()))
     assert float((y_b.cpu() - y_o).abs().max()) <= 1e-4 * scale
     assert float((y_b - y_t).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("grid,cin,cout,relu,res", [((40, 40, 16), 256, 256, 1, True), ((12, 9, 19), 64, 160, 2, False),
+                                                     ((20, 20, 8), 128, 128, 0, False), ((17, 6, 8), 512, 256, 0, False)])
+def test_halo_direct_b_form_is_bit_identical_to_the_staged_form(grid, cin, cout, relu, res, gpu_ops):
+    """Option `halo_nb=0` (weights straight from global memory into registers, 2 x 4 wave layout, no barrier per tap; measured no
+    faster, csrc/conv3d.hip) stays a tested variant: same accumulation order as the staged form on every brick shape, ragged
+    grids, split-K slices, ragged column counts, with an output mask; repeated launches, because its waves run unsynchronised
+    through a channel slice."""
+    g = torch.Generator().manual_seed(sum(grid) + cin + cout + 1)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g).cuda()
+    hi, lo = gpu_ops.split_bf16(torch.randn(27, cout, cin, generator=g) * 0.05)
+    hi, lo = hi.cuda(), lo.cuda()
+    scale, shift = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    residual = torch.randn(V, cout, generator=g).cuda() if res else None
+    mask = (torch.rand(grid, generator=g) < 0.3).reshape(-1).to(torch.uint8).cuda()
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 1)
+        staged, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+        staged_m, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=mask)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_nb", 0)
+        for _ in range(5):
+            direct, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+            assert torch.equal(direct, staged)
+        direct_m, _ = gpu_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu, out_mask=mask)
+        assert torch.equal(direct_m[mask.bool()], staged_m[mask.bool()])
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_nb", 2)
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_min_m", 2048)
+
+
+@pytest.mark.parametrize("cin,cout,grid,k,s,tr", [(64, 128, (8, 8, 8), 3, 2, False), (128, 256, (10, 10, 4), 3, 1, False),
+                                                  (512, 128, (8, 8, 4), 2, 2, True), (96, 192, (13, 7, 5), 3, 2, False)])
+def test_tile_kernel_options_are_bit_identical(cin, cout, grid, k, s, tr, oracle_ops, gpu_ops):
+    """The tile implicit GEMM's options -- 256 x 128 workgroup tiles (`igemm_tall`), the XCD deals of its workgroups (`igemm_xcd`
+    1 / 2), four waves per tile (`conv_waves`) -- only move work around: same K order, same split, same bits as the default,
+    which itself stays within the bf16x3 bound of the oracle (ragged row / column counts, a stride, a transposed layer)."""
+    g = torch.Generator().manual_seed(cin + cout + 7)
+    V = grid[0] * grid[1] * grid[2]
+    taps = 8 if tr else k ** 3
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(taps, cout, cin, generator=g) * (1.0 / (cin * (1 if tr else taps)) ** 0.5)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    y_o, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, k, s, tr, sc, sh, None, 1)
+    args = (x.cuda(), hi.cuda(), lo.cuda(), grid, k, s, tr, sc.cuda(), sh.cuda(), None, 1)
+    y_d, _ = gpu_ops.conv3d_cl_bf16x3(*args)
+    assert float((y_d.cpu() - y_o).abs().max()) <= 1e-4 * max(1.0, float(y_o.abs().max()))
+    for key, val, back in ((b"igemm_xcd", 1, 0), (b"igemm_xcd", 2, 0), (b"conv_waves", 4, 8)):
+        try:
+            gpu_ops.lib.call("sgc_set_tuning", key, val)
+            y_v, _ = gpu_ops.conv3d_cl_bf16x3(*args)
+        finally:
+            gpu_ops.lib.call("sgc_set_tuning", key, back)
+        assert torch.equal(y_v, y_d), (key, val)
+    try:                                   # the tall tile halves the split target: compared where the split count stays the same
+        gpu_ops.lib.call("sgc_set_tuning", b"igemm_tall", 1)
+        y_t, _ = gpu_ops.conv3d_cl_bf16x3(*args)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"igemm_tall", 0)
+    assert float((y_t - y_d).abs().max()) <= 2e-5 * max(1.0, float(y_o.abs().max()))
