@@ -46,6 +46,7 @@ int g_tune_conv_big = 0;     // 1: the 512 x 128 big-tile implicit GEMM (conv3d_
                              // these layers need is activations split ONCE by their producer, not a bigger tile.
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
+int g_tune_halo_2d = 1;      // 3x3 layers of sgc_conv2d_nhwc_bf16x3: 1 the 2-D form of the halo kernel, 0 the tile kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4x8x8, 2: force 8x8x4, 3: the round-2 rule (4x4x16 at depth >= 16).
                                   // Round 3, interleaved A/B of the three shapes on the 40x40x16 and 80x80x32 layers (bit-identical
                                   // results): 8x8x4 is 1.5 - 2.5 % faster than 4x4x16 (236 vs 241 us, 129.5 vs 133, 534 vs 546;
@@ -843,8 +844,12 @@ unsigned long long *g_halo_stamp_buf = nullptr;
 // read after the barrier that publishes them.  3 (round 3, where the LDS holds it: the 8x8x4 brick): weights are staged TWO
 // taps ahead, so the buffer of tap t + 1 is complete while tap t is multiplied and its first-k-half B fragments are read
 // BEFORE the barrier, next to the A fragments -- no LDS round trip at the head of a tap.  Same k order: bit-identical.
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2>
+// TD: 2-D form (sgc_conv2d_nhwc_bf16x3: the FPN's 3 x 3 output convolutions) -- the grid is (image, row, column),
+// a brick is BX images x BY x BZ pixels, there is no halo and no tap along x: 9 taps, (BY + 2)(BZ + 2) halo rows per image.
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2, bool TD = false>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
+  static_assert(!TD || (!RING && NB == 2), "the 2-D form uses the staged weights");
+  constexpr int NTAP = TD ? 9 : 27, XO = TD ? 0 : 1;    // taps; halo width along x
   static_assert(NP == 3 || !RING, "the single-product mode uses the staged form");
   static_assert(NB == 2 || !RING, "three / no weight buffers belong to the staged form");
   static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   static_assert(!DB || (BNV == 128 && !RING), "the direct-B form is built for 128-column tiles of the staged form");
   constexpr int RT = DB ? 4 : 2;                        // 32-row tiles per wave
   constexpr int TN = DB ? 1 : BNV / 64, WCOL = DB ? 32 : BNV / 2;   // 32-column tiles per wave, columns per wave
-  constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
+  constexpr int HX = BX + 2 * XO, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int NT = 512;
   constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     for (int j = 0; j < 32; ++j) {
       const int r = t * 32 + j;
       const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
-      const int hr = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
+      const int hr = ((x + XO) * HY + (y + 1)) * HZP + (z + 1);
       if ((hr & 15) == (l & 15)) {
         if (seen == (l >> 4)) pick = r;
         ++seen;
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   for (int i = 0; i < RT; ++i) {
     const int r = vox_tab[(wm * RT + i) * 32 + fr];
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
-    arow[i] = ((x + 1) * HY + (y + 1)) * HZP + (z + 1);
+    arow[i] = ((x + XO) * HY + (y + 1)) * HZP + (z + 1);
   }
   // output mask: does this wave's 64-voxel tile / this brick hold a row the caller needs?
   bool wave_live = true;
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         const int idx = i * NT + tid;
         const int row = idx >> 3, c4 = idx & 7;
         const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-        const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+        const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
         const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
         const int off = (((gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4) * 4;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in ? off : 0x7fffffff, 0, 0);
@@ -1078,8 +1083,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           issue_next();
         }
         if (prefetchA) load_A(cc + 1);             // NA loads, younger than the DMA just issued
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
         const __bf16 *bh_ = Bring + st * (HALO_BSTAGE / 2);
         const __bf16 *bl_ = bh_ + HALO_BSTAGE / 4;
         if (wave_live) {
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     constexpr unsigned OOB = 0xfffffff0u;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
-    const int w_bytes = (int)(unsigned)((int64_t)27 * p.Cout * p.Cin * 2);
+    const int w_bytes = (int)(unsigned)((int64_t)NTAP * p.Cout * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
     unsigned aoff[NA];
@@ -1154,7 +1159,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       const int idx = i * NT + tid;
       const int row = idx >> 3, c4 = idx & 7;
       const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-      const int gx = X0 + hx - 1, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+      const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
       const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
       aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
       alds[i] = row < HROWS ? ((row / HZ) * HZP + row % HZ) * LDKH + c4 * 4 : -1;
@@ -1227,8 +1232,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       };
       bf16x8 ah_n[RT] = {}, al_n[RT] = {};
       auto read_A0 = [&](int tap) {
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           const int o = (arow[i] + toff) * LDKH + fh * 8;
@@ -1247,8 +1252,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           const bool more = !last_tap || cc + 1 < c_hi;
           if (more) load_Bf(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc, bh_x, bl_x);
           if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);          // next slice's halo rides under the last taps
-          const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-          const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+          const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+          const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
           if (wave_live) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -1286,9 +1291,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       }
     } else {
       int g = 0;                       // global step counter -> B buffer
-      const int steps_total = (c_hi - c_lo) * 27;
-      auto step_tap = [&](int st) { return st % 27; };
-      auto step_cc = [&](int st) { return c_lo + st / 27; };
+      const int steps_total = (c_hi - c_lo) * NTAP;
+      auto step_tap = [&](int st) { return st % NTAP; };
+      auto step_cc = [&](int st) { return c_lo + st / NTAP; };
       load_A(c_lo);
       load_B(0, c_lo);
       store_A();
@@ -1304,8 +1309,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       bf16x8 ah_n[2] = {}, al_n[2] = {};
       bf16x8 bh_n[TN] = {}, bl_n[TN] = {};          // NB == 3: first-k-half B fragments of the next tap
       auto read_A0 = [&](int tap) {
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
   #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int o = (arow[i] + toff) * LDKH + fh * 8;
@@ -1325,15 +1330,15 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       if constexpr (NB == 3) read_B0(0);
       int bcur = 0;                    // buffer of the tap being multiplied (NB == 3: g % 3 without the division)
       for (int cc = c_lo; cc < c_hi; ++cc) {
-        for (int tap = 0; tap < 27; ++tap, ++g) {
-          const bool last_tap = tap == 26;
+        for (int tap = 0; tap < NTAP; ++tap, ++g) {
+          const bool last_tap = tap == NTAP - 1;
           const bool more = !last_tap || cc + 1 < c_hi;
           const int ahead = NB == 3 ? 2 : 1;                       // taps the weight staging runs ahead
           const bool more_b = g + ahead < steps_total;
           if (more_b) load_B(step_tap(g + ahead), step_cc(g + ahead));
-          if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
-          const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-          const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
+          if (tap == NTAP - 3 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+          const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+          const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
           const int bsel = NB == 3 ? bcur : (g & 1);
           const __bf16 *bh_ = Bbase + bsel * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
           const __bf16 *bl_ = bh_ + B_PLANE;
@@ -1515,7 +1520,7 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2>
+template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2, bool TD = false>
 static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st);
 
 template <int BX, int BY, int BZ, bool RING, int BNV = 128>
@@ -1538,19 +1543,21 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   return launch_halo_np<BX, BY, BZ, RING, BNV, 3>(p, OV, st);
 }
 
-template <int BX, int BY, int BZ, bool RING, int BNV, int NP, int NB>
+template <int BX, int BY, int BZ, bool RING, int BNV, int NP, int NB, bool TD>
 static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
 #if defined(SGC_HALO_STAMPS)
   p.stamps = g_halo_stamp_buf;
 #endif
-  constexpr int LROWS = (BX + 2) * (BY + 2) * halo_pitch(BZ);
+  constexpr int LROWS = (TD ? BX : BX + 2) * (BY + 2) * halo_pitch(BZ);
   const size_t smem = halo_tab_offset(LROWS, RING, NB) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB, TD>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
-  const int splitk = halo_splitk(bricks, nb, nchunks);
+  int splitk = halo_splitk(bricks, nb, nchunks);
+  // the 2-D entry point carries no workspace: one split rather than float atomics (the result must not depend on the run)
+  if (TD && !(p.ws && p.ws_floats >= (int64_t)splitk * OV * p.Cout)) splitk = 1;
   p.splitk = splitk;
   if (splitk > 1) {
     if (p.Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
@@ -1562,7 +1569,7 @@ static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB, TD>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
@@ -1772,6 +1779,17 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
       rc = narrow_n ? launch_halo<4, 8, 8, false, 64>(p, OV, st) : ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
     else
       rc = narrow_n ? launch_halo<8, 8, 4, false, 64>(p, OV, st) : ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
+    if (rc) return rc;
+    return conv_finish(p, OV, st);
+  }
+  // 3 x 3 layers over a stack of images (the FPN's output convolutions): the 2-D form of the halo kernel, bricks of 16 x 16 pixels
+  if (g_tune_conv_halo && g_tune_halo_2d && p.two_d && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout &&
+      p.M >= g_tune_halo_min_m && p.gy >= 8 && p.gz >= 8) {
+    const bool narrow_n = g_tune_halo_narrow && Cout <= 64;
+    if (g_conv_products == 1)
+      rc = narrow_n ? launch_halo_np<1, 16, 16, false, 64, 1, 2, true>(p, OV, st) : launch_halo_np<1, 16, 16, false, 128, 1, 2, true>(p, OV, st);
+    else
+      rc = narrow_n ? launch_halo_np<1, 16, 16, false, 64, 3, 2, true>(p, OV, st) : launch_halo_np<1, 16, 16, false, 128, 3, 2, true>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }

@@ -253,10 +253,14 @@ def test_channels_last_conv_transpose_function_matches_torch_autograd(gpu_ops):
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,k,relu,res", [(3, 15, 20, 64, 96, 3, 1, True), (2, 8, 10, 256, 32, 1, 0, False),
-                                                        (4, 30, 40, 32, 256, 3, 0, False), (1, 7, 5, 96, 28, 3, 2, True)])
+                                                        (4, 30, 40, 32, 256, 3, 0, False), (1, 7, 5, 96, 28, 3, 2, True),
+                                                        (5, 37, 45, 64, 28, 3, 1, True), (2, 64, 80, 256, 256, 3, 2, True),
+                                                        (7, 16, 20, 96, 160, 3, 0, False)])
 def test_conv2d_nhwc_matches_oracle_and_torch(N, H, W, cin, cout, k, relu, res, oracle_ops, gpu_ops):
     """sgc_conv2d_nhwc_bf16x3 (row f-1: the FPN's convolutions on channels-last image rows): against the oracle loop and
-    against F.conv2d on the NCHW view; images must not leak into each other (the taps are confined to one image)."""
+    against F.conv2d on the NCHW view; images must not leak into each other (the taps are confined to one image).  The 3 x 3
+    cases with >= 2048 pixels run the 2-D form of the halo kernel (16 x 16-pixel bricks: ragged rows / columns, 28 and 160
+    output channels, several images per launch), the others the tile kernel; the two agree to fp32 summation noise."""
     g = torch.Generator().manual_seed(N * H + cin + cout)
     x = torch.randn(N * H * W, cin, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) * 0.05
@@ -273,6 +277,17 @@ def test_conv2d_nhwc_matches_oracle_and_torch(N, H, W, cin, cout, k, relu, res, 
                                        None, 1, k // 2)
         y = y.permute(0, 2, 3, 1).reshape(-1, cout) * sc + sh
         assert float((got - y).abs().max()) < 1e-4 * max(1.0, float(y.abs().max()))
+    if k == 3 and N * H * W >= 2048:
+        try:
+            gpu_ops.lib.call("sgc_set_tuning", b"halo_2d", 0)
+            tile = gpu_ops.conv2d_nhwc_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), (N, H, W), k, sc.cuda(), sh.cuda(),
+                                              r.cuda() if res else None, relu).cpu()
+        finally:
+            gpu_ops.lib.call("sgc_set_tuning", b"halo_2d", 1)
+        assert float((got - tile).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+        again = gpu_ops.conv2d_nhwc_bf16x3(x.cuda(), hi.cuda(), lo.cuda(), (N, H, W), k, sc.cuda(), sh.cuda(),
+                                           r.cuda() if res else None, relu).cpu()
+        assert torch.equal(again, got)                              # one split, no atomics: the same bits every run
 
 
 @pytest.mark.parametrize("rows,cin,cout,bias", [(5000, 256, 256, True), (1237, 128, 96, True), (777, 64, 33, False)])
