@@ -398,7 +398,9 @@ int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const
  * fp32 accumulation (the dropped lo*lo term is 2^-16 relative).  w_hi / w_lo [taps][Cout][Cin] are the
  * host-side split of the fp32 weights (raw bf16 bit patterns): w_hi = bf16_rne(w), w_lo = bf16_rne(w - w_hi).
  * Activations are fp32 in memory and split while staged into LDS.  Agreement with sgc_conv3d_cl_f32:
- * ~1e-5 of the tensor scale (tests: 1e-4).                                                      */
+ * ~1e-5 of the tensor scale (tests: 1e-4).  The kernels address x and the weights through 32-bit
+ * buffer offsets: x must stay below 4 GiB and the weight tensor below 2 GiB (SGC_EUNSUP otherwise;
+ * also sgc_conv2d_nhwc_bf16x3, sgc_linear_rows_*_bf16x3, sgc_conv3d_wgrad_bf16x3 for x and dy).   */
 int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,

@@ -1703,8 +1703,8 @@ extern "C" int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *s
 
 // the tile kernel addresses its input and its weights with 32-bit byte offsets into buffer descriptors
 static bool igemm_fits_32bit(const ConvParamsB &p) {
-  const int64_t lim = 0xfffffff0ll - 65536;
-  return (int64_t)p.ix * p.iy * p.iz * p.Cin * 4 < lim && (int64_t)(p.transposed ? 8 : p.taps) * p.Cout * p.Cin * 2 < lim;
+  const int64_t lim = 0xfffffff0ll - 65536;       // input: unsigned byte offsets; weights: the per-step offset is a signed scalar
+  return (int64_t)p.ix * p.iy * p.iz * p.Cin * 4 < lim && (int64_t)(p.transposed ? 8 : p.taps) * p.Cout * p.Cin * 2 < 0x7fffffffll;
 }
 
 // one launch of the tile-per-workgroup implicit-GEMM kernel in the arithmetic mode of g_conv_products
@@ -1760,7 +1760,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.scale = scale; p.shift = shift; p.residual = residual_or_null;
   p.ws = workspace_or_null; p.ws_floats = workspace_or_null ? workspace_floats : 0;
-  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_bf16x3: input and weight tensors must stay below 4 GiB each");
+  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_conv3d_cl_bf16x3: the input must stay below 4 GiB and the weights below 2 GiB");
   const int64_t OV = (int64_t)ox * oy * oz;
   hipStream_t st = (hipStream_t)stream;
   // 1x1x1 stride-1 layers are row GEMMs (the FFN of a level, TU/encoder.py:311-338): persistent weight-stationary kernel
@@ -2254,7 +2254,7 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
   const dim3 grid(ceil_div(rows_cap, BM), ceil_div(Cout, bn), 1);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   hipStream_t st = (hipStream_t)stream;
-  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: input and weight tensors must stay below 4 GiB each");
+  if (!igemm_fits_32bit(p)) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: the input must stay below 4 GiB and the weights below 2 GiB");
   launch_igemm(p, narrow, grid, smem, st);
   return check_launch("conv3d_igemm_bf16x3_kernel (linear rows)");
 }
