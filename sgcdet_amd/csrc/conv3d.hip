@@ -1173,20 +1173,31 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
       }
     };
-    auto store_A = [&]() {
+    // the split of a loaded halo chunk, in place: ra[i] = (hi.xy, hi.zw, lo.xy, lo.zw) as packed bf16 pairs.  Called under the
+    // last tap of a slice (the loads went out three taps earlier), so that between the slice's last barrier and the next
+    // slice's first tap only the ds_writes remain -- the vector work of the split overlaps the other wave's MFMAs instead of
+    // sitting between two barriers.
+    auto split_A = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 hb = (__bf16)v[e];
+          h[e] = hb;
+          l[e] = (__bf16)(v[e] - (float)hb);
+        }
+        const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
+        ra[i] = make_float4(__uint_as_float(hu.x), __uint_as_float(hu.y), __uint_as_float(lu.x), __uint_as_float(lu.y));
+      }
+    };
+    auto store_A = [&]() {               // ra[] holds split chunks (split_A)
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         if (alds[i] >= 0) {
-          const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-          bf16x4 h, l;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const __bf16 hb = (__bf16)v[e];
-            h[e] = hb;
-            l[e] = (__bf16)(v[e] - (float)hb);
-          }
-          *reinterpret_cast<bf16x4 *>(A_hi + alds[i]) = h;
-          if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(A_lo + alds[i]) = l;
+          *reinterpret_cast<uint2 *>(A_hi + alds[i]) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+          if constexpr (NP == 3) *reinterpret_cast<uint2 *>(A_lo + alds[i]) = make_uint2(__float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
         }
       }
     };
@@ -1243,6 +1254,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       };
       load_A(c_lo);
       load_Bf(0, c_lo, bh_c, bl_c);
+      split_A();
       store_A();
       __syncthreads();
       if (wave_live) read_A0(0);
@@ -1279,6 +1291,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
             }
             if (!last_tap) read_A0(tap + 1);
           }
+          if (last_tap && cc + 1 < c_hi) split_A();
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) { bh_c[kk] = bh_x[kk]; bl_c[kk] = bl_x[kk]; }
         }
@@ -1296,6 +1309,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       auto step_cc = [&](int st) { return c_lo + st / NTAP; };
       load_A(c_lo);
       load_B(0, c_lo);
+      split_A();
       store_A();
       store_B(0);
       if constexpr (NB == 3) {
@@ -1381,6 +1395,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           if constexpr (NB == 3) { if (more) read_B0(bnext); }     // published by the barrier that ended the previous tap
           }
           if (more_b) store_B(NB == 3 ? (bnext == 2 ? 0 : bnext + 1) : ((g + 1) & 1));
+          if (last_tap && cc + 1 < c_hi) split_A();
           bcur = bnext;
   #if !defined(SGC_DIAG_HALO_NO_TAPBARRIER)
           __syncthreads();
