@@ -43,8 +43,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed scenes (default 400 = 0.8 s at config 2: the clocks need about a second of load to settle)")
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg2_scannet")
     ap.add_argument("--views", type=int, default=None, help="override the number of views")
     ap.add_argument("--img", default=None,
