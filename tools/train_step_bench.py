@@ -13,6 +13,7 @@ ap.add_argument("--workload", default="cfg2_scannet")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-neck", action="store_true", help="stop at the volume (view transform only)")
 ap.add_argument("--profile", action="store_true", help="print the 25 kernels with the most GPU time (torch.profiler)")
+ap.add_argument("--glue", action="store_true", help="attribute the torch glue ops (copy / add / fill / sum / mul ...) to source lines of this package")
 args = ap.parse_args()
 w = workload(args.workload)
 torch.manual_seed(0)
@@ -52,5 +53,24 @@ if args.profile:
     rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
     for e in rows:
         print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
+if args.glue:
+    import collections
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for ev in prof.events():
+        if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children and any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children):
+            continue                                    # leaf aten ops that own device time
+        if any(k in ev.name for k in ("convolution", "mm", "native_batch_norm")):
+            continue
+        site = next((f for f in (ev.stack or []) if "/sgcdet_amd/" in f or "/tools/" in f), "(autograd engine / no python frame)")
+        key = (ev.name, site.split("/repo/")[-1][:90])
+        agg[key][0] += ev.device_time_total; agg[key][1] += 1
+    tot = sum(v[0] for v in agg.values())
+    print(f"torch glue ops with device time: {tot / 1e3:.2f} ms per step", file=sys.stderr)
+    for (name, site), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+        print(f"{t / 1e3:8.3f} ms  x{n:<4d} {name:28s} {site}", file=sys.stderr)
 print(json.dumps(dict(workload=args.workload, ms_per_step=ms_step, loss=l,
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck)))
