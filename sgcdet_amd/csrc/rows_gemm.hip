@@ -36,6 +36,7 @@ namespace sgc {
 int g_tune_rows_gemm = 1;        // 0: every row GEMM on the tile-per-workgroup implicit-GEMM kernel (round-2 path)
 int g_tune_rows_diag = 0;        // TIMING EXPERIMENTS ONLY, honoured only with SGC_DIAG=1 in the environment (results are then
                                  // invalid): bit 0 = stores dropped by the range check, bit 1 = loads dropped (zeros), bit 2 = no MFMA
+int g_tune_rows_cu_pct = 100;   // persistent row GEMM: share of the CUs it occupies (it is memory-bound: with scenes in flight the rest serve MFMA kernels)
 int g_tune_rows_depth = 1;       // 8-wave form: 1 / 2 = lockstep with that many tiles in flight ahead of the one being multiplied,
                                  // 0 = staggered halves (waves 4-7 half a period behind waves 0-3); the 4-wave form (two workgroups
                                  // per CU) is lockstep, 1 ahead.  Interleaved A/B on the 204,800 x 256 -> 256 Linear (3 rounds x 40
@@ -440,6 +441,7 @@ int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const ui
   // one 8-wave workgroup or two 4-wave workgroups per CU; stripes are a multiple of 8 (the XCD-aware deal of the kernel)
   const int per_cu = nw == 8 ? 1 : 2;
   int stripes = device_cus() * per_cu / p.ncg;
+  if (g_tune_rows_cu_pct > 0 && g_tune_rows_cu_pct < 100) stripes = stripes * g_tune_rows_cu_pct / 100;   // leave CUs to the other streams
   if (stripes > cap_tiles) stripes = cap_tiles;
   stripes = (stripes + 7) / 8 * 8;
   const int grid = stripes * p.ncg;

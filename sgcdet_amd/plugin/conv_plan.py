@@ -80,6 +80,22 @@ class ConvSpec:
 TRAIN_CONV = os.environ.get("SGC_TRAIN_CONV", "hip")
 
 
+def set_throughput_mode(on):
+    """Launch geometry for several scenes in flight (one hipGraph per scene on its own stream, bench.py): with four scenes
+    overlapping the chip is CU-time bound -- the sum of workgroup-residency of all kernels, not any kernel's latency, sets the
+    throughput -- so the persistent row GEMM is put on HALF the CUs with two tiles in flight per workgroup.  Alone it runs 46 %
+    longer that way (92 -> 136 us on the 204 800-row Linear) but holds 27 % less CU-time, which the other scenes' MFMA kernels
+    use: +1.4 % scenes/s (alternated runs).  Same kernel, same bits (a row's result does not depend on the
+    tiling of the call).  Off = the latency-optimal geometry (one scene at a time)."""
+    from .. import ext
+    lib = ext.ops().lib
+    explicit = os.environ.get("SGC_TUNE", "")
+    if "rows_cu_pct" not in explicit:
+        lib.call("sgc_set_tuning", b"rows_cu_pct", 50 if on else 100)
+    if "rows_depth" not in explicit:
+        lib.call("sgc_set_tuning", b"rows_depth", 2 if on else 1)
+
+
 def set_train_conv(mode):
     global TRAIN_CONV
     if mode not in ("hip", "library"):
