@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=400,
                     help="timed scenes (default 400 = 0.8 s at config 2: the clocks need about a second of load to settle)")
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--prewarm", type=float, default=1.0,
+                    help="seconds of untimed scenes during setup, before the --warmup steps (clock settle; 0 = none)")
     ap.add_argument("--workload", default="cfg2_scannet")
     ap.add_argument("--views", type=int, default=None, help="override the number of views")
     ap.add_argument("--img", default=None,
@@ -321,6 +323,14 @@ def main():
         for i in range(n_combo):
             step(i)
         torch.cuda.synchronize()
+    if args.prewarm > 0:                 # setup, like the captures above: the clocks settle within about a second of load
+        tp = time.perf_counter()
+        i = 0
+        while time.perf_counter() - tp < args.prewarm:
+            for _ in range(8):
+                step(i)
+                i += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -579,7 +589,7 @@ def main():
                                    f"{'/'.join(f'{f.shape[-2]}x{f.shape[-1]}' for f in scenes[0][0][:3])}, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
-                       "input_layout": args.input_layout, "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams,
+                       "input_layout": args.input_layout, "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
                        "launch_geometry": ("throughput (row GEMMs on half the CUs, two tiles in flight; conv_plan.set_throughput_mode)"
                                            if args.streams > 1 else "latency"),
                        "launch": {"scene": "one hipGraph replay per scene (device-side pair counts, no host read-back)",
