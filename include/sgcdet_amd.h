@@ -502,6 +502,22 @@ int64_t sgc_topk_select_workspace_bytes(int n);
 int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
                         const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream);
 
+/* Training-mode BatchNorm over channels-last rows x [rows, C]: nn.BatchNorm3d over [1, C, X, Y, Z] is the
+ * per-channel statistics of the X*Y*Z rows (necks/imvoxelnet.py:36-64,146-173).
+ *   forward : mean_out / invstd_out [C] = batch mean and 1 / sqrt(biased variance + eps); y = (x - mean) * invstd * weight + bias;
+ *             running_mean / running_var (optional) are updated as nn.BatchNorm does (momentum, UNBIASED variance).
+ *   backward: dbias = sum dy, dweight = sum dy * xhat, dx = weight * invstd * (dy - dbias / rows - xhat * dweight / rows).
+ * Reductions run over slabs of rows whose partial results are merged in a fixed order (same bits every run); workspace:
+ * sgc_bn_rows_workspace_floats(rows, C) floats for either call.  C % 4 == 0; 16-byte aligned pointers.                   */
+int64_t sgc_bn_rows_workspace_floats(int rows, int C);
+int sgc_bn_rows_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                        float *running_var_or_null, float momentum, float eps, float *y, float *mean_out,
+                        float *invstd_out, float *workspace, int64_t workspace_floats, int rows, int C,
+                        sgc_stream_t stream);
+int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, const float *invstd, const float *weight,
+                         float *dx, float *dweight, float *dbias, float *workspace, int64_t workspace_floats, int rows,
+                         int C, sgc_stream_t stream);
+
 /* The tail of a VoxFormer level in one launch: for every voxel q of the level
  *     x0 = out_proj(ctx[row_of[q]]) if row_of[q] >= 0 else 0      (nn.MultiheadAttention.out_proj + the slot scatter,
  *                                                                  TU/deformable_cross_attention.py:826-837)

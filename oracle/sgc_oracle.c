@@ -1184,6 +1184,58 @@ int sgc_topk_select_ws(const float *score, int n, int k, int64_t *idx_out, int64
   return sgc_topk_select(score, n, k, idx_out, valid_or_null, mask_or_null, stream);
 }
 
+/* Training-mode BatchNorm over rows (test infrastructure; product: csrc/batch_norm.hip).  Statistics in double precision:
+ * this is the checker of the product's fp32 Welford / Chan reductions, not a restatement of their order. */
+int64_t sgc_bn_rows_workspace_floats(int rows, int C) { return rows > 0 && C > 0 ? 4 : 0; }
+
+int sgc_bn_rows_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                        float *running_var_or_null, float momentum, float eps, float *y, float *mean_out,
+                        float *invstd_out, float *workspace, int64_t workspace_floats, int rows, int C,
+                        sgc_stream_t stream) {
+  (void)workspace; (void)workspace_floats; (void)stream;
+  if (!x || !weight || !bias || !y || !mean_out || !invstd_out) return fail(SGC_EINVAL, "sgc_bn_rows_forward: null pointer");
+  if (rows <= 0 || C <= 0) return fail(SGC_EINVAL, "sgc_bn_rows_forward: bad size");
+  if (C % 4) return fail(SGC_EUNSUP, "sgc_bn_rows_forward: needs C % 4 == 0");
+  for (int c = 0; c < C; ++c) {
+    double m = 0.0, v = 0.0;
+    for (int r = 0; r < rows; ++r) m += x[(int64_t)r * C + c];
+    m /= rows;
+    for (int r = 0; r < rows; ++r) { const double d = x[(int64_t)r * C + c] - m; v += d * d; }
+    const double var = v / rows, is = 1.0 / sqrt(var + (double)eps);
+    mean_out[c] = (float)m;
+    invstd_out[c] = (float)is;
+    if (running_mean_or_null) running_mean_or_null[c] = (float)((1.0 - momentum) * running_mean_or_null[c] + momentum * m);
+    if (running_var_or_null)
+      running_var_or_null[c] = (float)((1.0 - momentum) * running_var_or_null[c] + momentum * (rows > 1 ? v / (rows - 1) : var));
+    for (int r = 0; r < rows; ++r)
+      y[(int64_t)r * C + c] = (float)((x[(int64_t)r * C + c] - m) * is * weight[c] + bias[c]);
+  }
+  return SGC_OK;
+}
+
+int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, const float *invstd, const float *weight,
+                         float *dx, float *dweight, float *dbias, float *workspace, int64_t workspace_floats, int rows,
+                         int C, sgc_stream_t stream) {
+  (void)workspace; (void)workspace_floats; (void)stream;
+  if (!x || !dy || !mean || !invstd || !weight || !dx || !dweight || !dbias) return fail(SGC_EINVAL, "sgc_bn_rows_backward: null pointer");
+  if (rows <= 0 || C <= 0) return fail(SGC_EINVAL, "sgc_bn_rows_backward: bad size");
+  if (C % 4) return fail(SGC_EUNSUP, "sgc_bn_rows_backward: needs C % 4 == 0");
+  for (int c = 0; c < C; ++c) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      const double g = dy[(int64_t)r * C + c], xh = ((double)x[(int64_t)r * C + c] - mean[c]) * invstd[c];
+      s1 += g; s2 += g * xh;
+    }
+    dbias[c] = (float)s1;
+    dweight[c] = (float)s2;
+    for (int r = 0; r < rows; ++r) {
+      const double g = dy[(int64_t)r * C + c], xh = ((double)x[(int64_t)r * C + c] - mean[c]) * invstd[c];
+      dx[(int64_t)r * C + c] = (float)((double)weight[c] * invstd[c] * (g - s1 / rows - xh * s2 / rows));
+    }
+  }
+  return SGC_OK;
+}
+
 int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
                         const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream) {
   (void)stream;

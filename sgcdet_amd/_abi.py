@@ -47,6 +47,8 @@ SIGNATURES = {
     "sgc_topk_select": [_p, _i, _i, _p, _p, _p, _p],
     "sgc_topk_select_ws": [_p, _i, _i, _p, _p, _p, _p, C.c_int64, _p],
     "sgc_layer_norm_rows": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
+    "sgc_bn_rows_forward": [_p] * 5 + [_f, _f] + [_p] * 4 + [C.c_int64, _i, _i, _p],
+    "sgc_bn_rows_backward": [_p] * 9 + [C.c_int64, _i, _i, _p],
     "sgc_aligned_nms3d": [_p] * 3 + [_f] + [_p] * 3 + [_i] + [_p],
     "sgc_nms_rotated_bev": [_p] * 3 + [_f] + [_p] * 3 + [_i, _i] + [_p],
     "sgc_box_iou_rotated": [_p] * 3 + [_i, _i] + [_p],
@@ -67,6 +69,7 @@ INTROSPECTION = {
     "sgc_backend": (C.c_char_p, []),
     "sgc_conv3d_workspace_floats": (C.c_int64, [_i] * 9),
     "sgc_conv3d_wgrad_workspace_floats": (C.c_int64, [_i] * 7),
+    "sgc_bn_rows_workspace_floats": (C.c_int64, [_i] * 2),
     "sgc_topk_select_workspace_bytes": (C.c_int64, [_i]),
     "sgc_level_tail_supported": (C.c_int, [_i] * 2),
     "sgc_get_conv_products": (C.c_int, []),

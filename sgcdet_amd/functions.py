@@ -227,6 +227,28 @@ class ChannelsLastConvTranspose3dFunction(Function):
         return dx, dw, None
 
 
+class BatchNormRowsFunction(Function):
+    """Training-mode ``nn.BatchNorm3d`` on channels-last rows [rows, C] (necks/imvoxelnet.py:36-64: every convolution of the neck
+    is followed by one): statistics, normalisation and the backward reductions on ``sgc_bn_rows_forward / _backward`` (ordered
+    reductions: the same bits every run) instead of torch's channels-last batch-norm kernels.  The running statistics are
+    updated in place by the forward kernel, as ``F.batch_norm(training=True)`` does."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps):
+        ops = ext.ops()
+        x = rows.contiguous()
+        y, mean, invstd = ops.bn_rows_forward(x, weight.detach().contiguous(), bias.detach().contiguous(), running_mean, running_var,
+                                              momentum, eps)
+        ctx.save_for_backward(x, mean, invstd, weight.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, mean, invstd, weight = ctx.saved_tensors
+        dx, dw, db = ext.ops().bn_rows_backward(x, grad_y.contiguous(), mean, invstd, weight.contiguous())
+        return dx, dw, db, None, None, None, None
+
+
 class LinearRowsFunction(Function):
     """``nn.Linear`` over a row list with all three passes on the MFMA kernels (training path of the view transform:
     value_proj / sampling_offsets / attention_weights / output_proj, TU/deformable_cross_attention.py:417-436,826): forward

@@ -78,6 +78,7 @@ class ConvSpec:
 # training / autograd path of the neck and head convolutions: "hip" = forward, input and weight gradients on the MFMA
 # kernels (functions.ChannelsLastConv3dFunction), "library" = torch's convolutions (MIOpen) as in round 1
 TRAIN_CONV = os.environ.get("SGC_TRAIN_CONV", "hip")
+BN_ON_HIP = os.environ.get("SGC_BN_HIP", "1") != "0"      # training-mode BatchNorm of the neck on sgc_bn_rows_* (0: torch's kernels)
 
 
 def set_throughput_mode(on):
@@ -136,6 +137,12 @@ def bn_rows(bn, rows, grid):
             bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
+        if (use_batch and TRAIN_CONV == "hip" and BN_ON_HIP and rows.is_cuda and rows.dtype == torch.float32 and rows.shape[1] % 4 == 0
+                and bn.weight is not None and bn.bias is not None and rows.shape[0] > 1):
+            from ..functions import BatchNormRowsFunction
+            track = bn.training and bn.track_running_stats
+            return BatchNormRowsFunction.apply(rows, bn.weight, bn.bias, bn.running_mean if track else None,
+                                               bn.running_var if track else None, float(momentum), float(bn.eps))
         return torch.nn.functional.batch_norm(rows, bn.running_mean if not bn.training or bn.track_running_stats else None,
                                               bn.running_var if not bn.training or bn.track_running_stats else None,
                                               bn.weight, bn.bias, use_batch, momentum, bn.eps)

@@ -678,6 +678,38 @@ class TensorOps:
         self._call("sgc_topk_select_ws", flat, n, int(k), idx, valid, mask, ws, wsb)
         return idx, valid, mask
 
+    def bn_rows_forward(self, x, weight, bias, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+        """Training-mode BatchNorm over rows x [rows, C] -> (y, mean [C], invstd [C]); the running statistics are updated in
+        place as nn.BatchNorm does."""
+        self._check(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var)
+        self._f32(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var)
+        rows, Cc = x.shape
+        if weight.numel() != Cc or bias.numel() != Cc:
+            raise RuntimeError("bn_rows_forward: inconsistent shapes")
+        y = torch.empty_like(x)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        n = int(self.lib._dll.sgc_bn_rows_workspace_floats(rows, Cc))
+        ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+        self._call("sgc_bn_rows_forward", x, weight, bias, running_mean, running_var, float(momentum), float(eps), y, mean, invstd, ws,
+                   ws.numel(), rows, Cc)
+        return y, mean, invstd
+
+    def bn_rows_backward(self, x, dy, mean, invstd, weight):
+        """-> (dx [rows, C], dweight [C], dbias [C]) of ``bn_rows_forward``."""
+        self._check(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight)
+        self._f32(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight)
+        rows, Cc = x.shape
+        if dy.shape != x.shape or mean.numel() != Cc or invstd.numel() != Cc or weight.numel() != Cc:
+            raise RuntimeError("bn_rows_backward: inconsistent shapes")
+        dx = torch.empty_like(x)
+        dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dw)
+        n = int(self.lib._dll.sgc_bn_rows_workspace_floats(rows, Cc))
+        ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+        self._call("sgc_bn_rows_backward", x, dy, mean, invstd, weight, dx, dw, db, ws, ws.numel(), rows, Cc)
+        return dx, dw, db
+
     def layer_norm_rows(self, x, gamma, beta, eps=1e-5, count=None, out=None):
         """nn.LayerNorm over the last dim of x [rows, C]; ``count``: int32 device tensor with the live row count."""
         self._check(x=x, gamma=gamma, beta=beta, count=count, out=out)

@@ -883,3 +883,44 @@ def test_reference_stress_shape_at_full_size():
             close(a, b, tol=5e-5)
         except AssertionError as e:
             raise AssertionError(f"{name}: {e}")
+
+
+@pytest.mark.parametrize("rows,C", [(25600, 256), (3200, 512), (400, 1024), (1237, 128), (77, 1040), (6, 4)])
+def test_batch_norm_rows_kernels_against_the_oracle_and_torch(rows, C, oracle_ops, gpu_ops):
+    """sgc_bn_rows_forward / _backward (csrc/batch_norm.hip: the BatchNorm of the neck's training path on channels-last rows):
+    output, batch statistics and the running-statistics update against the double-precision oracle, gradients against the
+    oracle and F.batch_norm autograd in float64; ragged row / column counts (C > 1024 takes the column loop), a mean far from
+    zero (Welford / Chan, not sum and sum of squares); two launches give the same bits (ordered merges, no atomics)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 1.5 + 40.0                      # |mean| >> std: a naive E[x^2] - E[x]^2 would lose 3 digits
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_o, rv_o, rm_g, rv_g = rm.clone(), rv.clone(), rm.cuda(), rv.cuda()
+    y_o, mean_o, is_o = oracle_ops.bn_rows_forward(x, w, b, rm_o, rv_o, momentum=0.1, eps=1e-5)
+    y_g, mean_g, is_g = gpu_ops.bn_rows_forward(x.cuda(), w.cuda(), b.cuda(), rm_g, rv_g, momentum=0.1, eps=1e-5)
+    assert float((mean_g.cpu() - mean_o).abs().max()) < 1e-5 * 40
+    assert float(((is_g.cpu() - is_o) / is_o).abs().max()) < 2e-5
+    assert float((y_g.cpu() - y_o).abs().max()) < 2e-4                      # (x - mean) of 40-sized values: 4e-6 absolute per element, times invstd * w
+    assert torch.allclose(rm_g.cpu(), rm_o, atol=1e-5) and torch.allclose(rv_g.cpu(), rv_o, rtol=3e-5)
+    y_2, mean_2, is_2 = gpu_ops.bn_rows_forward(x.cuda(), w.cuda(), b.cuda(), None, None, momentum=0.1, eps=1e-5)
+    assert torch.equal(y_2, y_g) and torch.equal(mean_2, mean_g) and torch.equal(is_2, is_g)
+    dy = torch.randn(rows, C, generator=g)
+    dx_o, dw_o, db_o = oracle_ops.bn_rows_backward(x, dy, mean_o, is_o, w)
+    dx_g, dw_g, db_g = gpu_ops.bn_rows_backward(x.cuda(), dy.cuda(), mean_g, is_g, w.cuda())
+    s = max(1.0, float(dw_o.abs().max()))
+    assert float((dw_g.cpu() - dw_o).abs().max()) < 2e-4 * s and float((db_g.cpu() - db_o).abs().max()) < 2e-4 * max(1.0, float(db_o.abs().max()))
+    assert float((dx_g.cpu() - dx_o).abs().max()) < 2e-4 * max(1.0, float(dx_o.abs().max()))
+    dx_2, dw_2, db_2 = gpu_ops.bn_rows_backward(x.cuda(), dy.cuda(), mean_g, is_g, w.cuda())
+    assert torch.equal(dx_2, dx_g) and torch.equal(dw_2, dw_g) and torch.equal(db_2, db_g)
+    # the autograd Function the training path uses, against F.batch_norm in float64
+    from sgcdet_amd.functions import BatchNormRowsFunction
+    xg = x.cuda().requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = BatchNormRowsFunction.apply(xg, wg, bg, None, None, 0.1, 1e-5)
+    y.backward(dy.cuda())
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    F.batch_norm(xd, None, None, wd, bd, True, 0.1, 1e-5).backward(dy.double())
+    assert float((xg.grad.cpu().double() - xd.grad).abs().max()) < 2e-4 * max(1.0, float(xd.grad.abs().max()))
+    assert float((wg.grad.cpu().double() - wd.grad).abs().max()) < 2e-4 * max(1.0, float(wd.grad.abs().max()))
+    assert float((bg.grad.cpu().double() - bd.grad).abs().max()) < 2e-4 * max(1.0, float(bd.grad.abs().max()))

@@ -74,3 +74,30 @@ def test_oracle_weight_gradient_is_what_torch_autograd_returns(oracle_ops):
     wt = w.detach().float().permute(2, 3, 4, 0, 1).reshape(8, cin, cout).contiguous()
     dx, og = oracle_ops.conv3d_cl(dy, wt, (6, 8, 4), 2, 2, False, None, None, None, False)
     assert og == grid and (dx - xr.grad[0].permute(1, 2, 3, 0).reshape(24, cin)).abs().max() < 1e-4
+
+
+def test_oracle_batch_norm_rows_is_torch_batch_norm(oracle_ops):
+    """The oracle's sgc_bn_rows_forward / _backward (double-precision loops, the checker of csrc/batch_norm.hip) against
+    F.batch_norm in float64: output, batch statistics, the running-statistics update (momentum, unbiased variance) and the three
+    gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    for rows, C in ((37, 8), (600, 64), (5, 4)):
+        x = torch.randn(rows, C, generator=g) * 2 + 0.5
+        w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+        rm_o, rv_o = rm.clone(), rv.clone()
+        y, mean, invstd = oracle_ops.bn_rows_forward(x, w, b, rm_o, rv_o, momentum=0.3, eps=1e-5)
+        xd = x.double().requires_grad_(True)
+        wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        rm_r, rv_r = rm.double(), rv.double()
+        y_ref = F.batch_norm(xd, rm_r, rv_r, wd, bd, True, 0.3, 1e-5)
+        assert torch.allclose(y.double(), y_ref, atol=1e-5)
+        assert torch.allclose(mean.double(), xd.mean(0), atol=1e-6)
+        assert torch.allclose(invstd.double(), 1 / (xd.var(0, unbiased=False) + 1e-5).sqrt(), rtol=1e-5)
+        assert torch.allclose(rm_o.double(), rm_r, atol=1e-6) and torch.allclose(rv_o.double(), rv_r, rtol=1e-5)
+        dy = torch.randn(rows, C, generator=g)
+        dx, dw, db = oracle_ops.bn_rows_backward(x, dy, mean, invstd, w)
+        y_ref.backward(dy.double())
+        assert torch.allclose(dx.double(), xd.grad, atol=2e-5)
+        assert torch.allclose(dw.double(), wd.grad, atol=2e-4) and torch.allclose(db.double(), bd.grad, atol=2e-4)
