@@ -26,6 +26,15 @@ class _TrilinearUp2x(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] == 1:
+            # the inference path's kernel (sgc_upsample2x_occ without the occupancy head) on channels-last rows; the result is
+            # returned as the channels-last [1, C, 2X, 2Y, 2Z] view, so that the occupancy Linear that follows reads it in place
+            # (torch's trilinear kernel took 250 us for the 26 MB output of the finest level, and its NCDHW result cost the
+            # Linear a permuting copy)
+            _, C, X, Y, Z = x.shape
+            rows = x[0].permute(1, 2, 3, 0).reshape(X * Y * Z, C).contiguous()
+            up, _, (ox, oy, oz) = ext.ops().upsample2x_occ(rows, (X, Y, Z))
+            return up.view(ox, oy, oz, C).permute(3, 0, 1, 2).unsqueeze(0)
         return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)
 
     @staticmethod
