@@ -13,12 +13,17 @@ ap.add_argument("--workload", default="cfg2_scannet")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-neck", action="store_true", help="stop at the volume (view transform only)")
 ap.add_argument("--profile", action="store_true", help="print the 25 kernels with the most GPU time (torch.profiler)")
+ap.add_argument("--input-layout", default="nchw", choices=["nchw", "nhwc"],
+                help="memory layout of the feature / depth maps handed to the path (nhwc = what plugin/fpn.py produces)")
 ap.add_argument("--glue", action="store_true", help="attribute the torch glue ops (copy / add / fill / sum / mul ...) to source lines of this package")
 args = ap.parse_args()
 w = workload(args.workload)
 torch.manual_seed(0)
 det = build_detector(model_config(w)).cuda().train()
 feats, dpt, meta = make_scene(w["n_views"], w["embed_dims"], kind=w["kind"], seed=1, device="cuda", img_hw=(256, 320))
+if args.input_layout == "nhwc":         # same logical [1, N, C, H, W] tensors, channels-last in memory
+    cl = lambda t: t[0].contiguous(memory_format=torch.channels_last).unsqueeze(0)   # noqa: E731
+    feats, dpt = [cl(f) for f in feats], cl(dpt)
 feats = [f.requires_grad_(True) for f in feats]
 dpt = dpt.requires_grad_(True)
 params = [p for p in det.parameters() if p.requires_grad]
@@ -56,7 +61,7 @@ if args.profile:
 if args.glue:
     import collections
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
     agg = collections.defaultdict(lambda: [0.0, 0])
@@ -66,11 +71,13 @@ if args.glue:
         if any(k in ev.name for k in ("convolution", "mm", "native_batch_norm")):
             continue
         site = next((f for f in (ev.stack or []) if "/sgcdet_amd/" in f or "/tools/" in f), "(autograd engine / no python frame)")
-        key = (ev.name, site.split("/repo/")[-1][:90])
+        shp = str([list(x) for x in (ev.input_shapes or []) if x][:2])
+        key = (ev.name, shp[:70] + " " + site.split("/repo/")[-1][:60])
         agg[key][0] += ev.device_time_total; agg[key][1] += 1
     tot = sum(v[0] for v in agg.values())
     print(f"torch glue ops with device time: {tot / 1e3:.2f} ms per step", file=sys.stderr)
     for (name, site), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
         print(f"{t / 1e3:8.3f} ms  x{n:<4d} {name:28s} {site}", file=sys.stderr)
 print(json.dumps(dict(workload=args.workload, ms_per_step=ms_step, loss=l,
-                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck)))
+                      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck,
+                      input_layout=args.input_layout)))
