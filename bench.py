@@ -303,7 +303,7 @@ def main():
 
     ops = ext.ops()                 # honours the development knobs of SGC_TUNE="tile_nw=8,tile_hg=2" (variant selection only)
     from sgcdet_amd.plugin.conv_plan import set_throughput_mode
-    set_throughput_mode(args.streams > 1)      # launch geometry for scenes in flight (bit-identical results)
+    set_throughput_mode(args.streams > 1)      # launch geometry for scenes in flight (conv_plan.set_throughput_mode)
 
     streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
 
@@ -590,7 +590,8 @@ def main():
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
                        "input_layout": args.input_layout, "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
-                       "launch_geometry": ("throughput (row GEMMs on half the CUs, two tiles in flight; conv_plan.set_throughput_mode)"
+                       "launch_geometry": ("throughput (row GEMMs on half the CUs; fewer reduction splits in the layers with few voxels; "
+                                            "conv_plan.set_throughput_mode)"
                                            if args.streams > 1 else "latency"),
                        "launch": {"scene": "one hipGraph replay per scene (device-side pair counts, no host read-back)",
                                   "tail": "eager view transform (one host read-back per level) + hipGraph replay of neck/head",

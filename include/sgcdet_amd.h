@@ -56,8 +56,10 @@ extern "C" {
 typedef void *sgc_stream_t; /* hipStream_t */
 
 int sgc_abi_version(void);
-/* Development knob (A/B of kernel variants in one process); keys: "fwd_variant" (0 block-barrier,
- * 1 wave-private gather).  Results never depend on it.                                        */
+/* Development knobs (A/B of kernel variants and launch geometries in one process; keys in csrc/dfa3d_fwd.hip).  Results do not
+ * depend on them, with one stated exception: "split_target" / "halo_split_target" choose over how many workgroups a layer with
+ * few voxels splits its reduction -- a different split adds the same partial sums in another order (fp32 rounding, <= 1e-5 of
+ * the tensor scale; deterministic for a given value).                                                                      */
 int sgc_set_tuning(const char *key, int value);
 /* Arithmetic mode of every bf16 MFMA kernel of the library (sgc_conv3d_cl_bf16x3 and its 2-D / masked forms,
  * sgc_linear_rows_*_bf16x3, sgc_level_tail):

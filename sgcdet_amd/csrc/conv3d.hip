@@ -46,6 +46,7 @@ int g_tune_conv_big = 0;     // 1: the 512 x 128 big-tile implicit GEMM (conv3d_
                              // these layers need is activations split ONCE by their producer, not a bigger tile.
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
+int g_tune_halo_split_target = 192;   // halo kernel: channel slices are split over workgroups until a launch has this many
 int g_tune_halo_2d = 1;      // 3x3 layers of sgc_conv2d_nhwc_bf16x3: 1 the 2-D form of the halo kernel, 0 the tile kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4x8x8, 2: force 8x8x4, 3: the round-2 rule (4x4x16 at depth >= 16).
                                   // Round 3, interleaved A/B of the three shapes on the 40x40x16 and 80x80x32 layers (bit-identical
@@ -1530,7 +1531,7 @@ static int halo_brick_shape(int gx, int gy, int gz) {
 
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
-  while (splitk < nchunks && (int64_t)bricks * nb * splitk < 192) splitk *= 2;
+  while (splitk < nchunks && (int64_t)bricks * nb * splitk < g_tune_halo_split_target) splitk *= 2;
   const int per = (nchunks + splitk - 1) / splitk;
   return (nchunks + per - 1) / per;
 }

@@ -417,7 +417,7 @@ extern int g_tune_view_group;
 extern int g_tune_halo_narrow;
 extern int g_tune_split_target;
 extern int g_tune_wgrad_waves;
-extern int g_tune_rows_gemm, g_tune_rows_depth, g_tune_rows_diag, g_tune_conv_big, g_tune_igemm_xcd, g_tune_igemm_tall, g_tune_halo_2d, g_tune_rows_cu_pct;
+extern int g_tune_rows_gemm, g_tune_rows_depth, g_tune_rows_diag, g_tune_conv_big, g_tune_igemm_xcd, g_tune_igemm_tall, g_tune_halo_2d, g_tune_rows_cu_pct, g_tune_halo_split_target;
 extern int g_tune_topk_multi_min;
 extern int g_tune_tile_nw;          // dfa3d_tile.hip
 extern int g_tune_tile_depth_lds;
@@ -609,6 +609,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_tall")) { g_tune_igemm_tall = value; return SGC_OK; }
   if (!strcmp(key, "halo_2d")) { g_tune_halo_2d = value; return SGC_OK; }
   if (!strcmp(key, "rows_cu_pct")) { g_tune_rows_cu_pct = value; return SGC_OK; }
+  if (!strcmp(key, "halo_split_target")) { g_tune_halo_split_target = value; return SGC_OK; }
   if (!strcmp(key, "rows_depth")) { g_tune_rows_depth = value; return SGC_OK; }
   if (!strcmp(key, "rows_diag")) { g_tune_rows_diag = value; return SGC_OK; }      // inert without SGC_DIAG=1 (rows_gemm.hip)
   if (!strcmp(key, "topk_multi_min")) { g_tune_topk_multi_min = value; return SGC_OK; }

@@ -82,19 +82,24 @@ BN_ON_HIP = os.environ.get("SGC_BN_HIP", "1") != "0"      # training-mode BatchN
 
 
 def set_throughput_mode(on):
-    """Launch geometry for several scenes in flight (one hipGraph per scene on its own stream, bench.py): with four scenes
-    overlapping the chip is CU-time bound -- the sum of workgroup-residency of all kernels, not any kernel's latency, sets the
-    throughput -- so the persistent row GEMM is put on HALF the CUs with two tiles in flight per workgroup.  Alone it runs 46 %
-    longer that way (92 -> 136 us on the 204 800-row Linear) but holds 27 % less CU-time, which the other scenes' MFMA kernels
-    use: +1.4 % scenes/s (alternated runs).  Same kernel, same bits (a row's result does not depend on the
-    tiling of the call).  Off = the latency-optimal geometry (one scene at a time)."""
+    """Launch geometry for several scenes in flight (one hipGraph per scene on its own stream, bench.py).  With four scenes
+    overlapping the chip is CU-time bound -- the sum of workgroup residency of all kernels, not any kernel's latency, sets the
+    throughput -- so kernels are sized for work per CU-second instead of for their own latency:
+      * the persistent row GEMM runs on HALF the CUs with two tiles in flight per workgroup (alone: 92 -> 136 us on the
+        204 800-row Linear, but 27 % less CU-time; same bits -- a row's result does not depend on the tiling of the call);
+      * the layers with few voxels split their reductions over FEWER workgroups (tile kernel: until 256 instead of 512 workgroups,
+        halo kernel: 96 instead of 192): less prologue / epilogue and workspace traffic per unit of work, 20 - 30 % more latency
+        per layer.  A different split adds the same partial sums in a different order: seven convolution layers of the neck
+        differ from the latency geometry by fp32 summation order (<= 1e-5 of the tensor scale, tested); each mode is
+        deterministic and bit-identical between graph replays and eager launches.
+    Together +3.5 % scenes/s (alternated runs).  Off = the latency-optimal geometry (one scene at a time, the default of the
+    library).  Call it before the first scene: captured graphs keep the geometry they were captured with."""
     from .. import ext
     lib = ext.ops().lib
     explicit = os.environ.get("SGC_TUNE", "")
-    if "rows_cu_pct" not in explicit:
-        lib.call("sgc_set_tuning", b"rows_cu_pct", 50 if on else 100)
-    if "rows_depth" not in explicit:
-        lib.call("sgc_set_tuning", b"rows_depth", 2 if on else 1)
+    for key, hot, cold in (("rows_cu_pct", 50, 100), ("rows_depth", 2, 1), ("split_target", 256, 512), ("halo_split_target", 96, 192)):
+        if key + "=" not in explicit:
+            lib.call("sgc_set_tuning", key.encode(), hot if on else cold)
 
 
 def set_train_conv(mode):

@@ -142,6 +142,56 @@ def test_hot_path_against_oracle(name, n_views):
             assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
 
 
+def test_throughput_launch_geometry_keeps_parity():
+    """conv_plan.set_throughput_mode (what bench.py selects for scenes in flight): the row GEMM on half the CUs is bit-identical;
+    the coarser reduction splits of seven neck layers move the head tensors by fp32 summation order only (<= 1e-5 of their
+    scale) -- and the path under that geometry passes the same oracle comparison as the default one."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin.conv_plan import set_throughput_mode
+    from sgcdet_amd.scene import make_scene, model_config, workload
+    from oracle.ref_path import RefPath
+    from oracle.compare import check_sparse_head
+    w = workload("cfg2_scannet")
+    torch.manual_seed(7)
+    det = build_detector(model_config(w)).eval()
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in det.voxel_head.named_parameters():
+            p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+    feats, dpt, meta = make_scene(6, w["embed_dims"], kind=w["kind"], seed=5)
+    rp = RefPath(det.voxel_head.state_dict(), dict(embed_dims=w["embed_dims"], n_voxels_list=w["n_voxels_list"],
+                                                   voxel_size_list=w["voxel_size_list"], topk_list=w["topk_list"],
+                                                   dbound=(0.2, 5.0), num_heads=8, num_points=4))
+    vol_c, valid_c, occ_c = rp.adaptive_sparse_head(feats, meta, depth_pyramid(dpt))
+    det = det.cuda()
+    det.use_graph = det.scene_graph = False            # a captured graph keeps the geometry it was captured with
+    gf, gd = [f.cuda() for f in feats], dpt.cuda()
+    with torch.no_grad():
+        lat = det.forward_features(gf, [meta], gd)
+        lat = {k: [t.clone() for t in v] if isinstance(v, (list, tuple)) else v.clone() for k, v in lat.items() if k != "feats"}
+        try:
+            set_throughput_mode(True)
+            thr = det.forward_features(gf, [meta], gd)
+            thr2 = det.forward_features(gf, [meta], gd)
+            n_fin = w["n_voxels_list"][-1][0] * w["n_voxels_list"][-1][1] * w["n_voxels_list"][-1][2]
+            res = check_sparse_head(thr["volume"], thr["valid"], thr["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"])
+            assert res["tie_flips"] <= 4
+            rp2 = RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},
+                           **{"head." + k: v for k, v in det.bbox_head.state_dict().items()}},
+                          dict(head="scannet", n_classes=w["n_classes"], nms_pre=1000))
+            _check_neck_head_on(det, vol_c, rp2)                   # the neck / head under the throughput geometry vs the oracle
+        finally:
+            set_throughput_mode(False)
+    assert torch.equal(thr["volume"], lat["volume"]) and torch.equal(thr["occ"], lat["occ"])      # view transform: same bits
+    moved = 0.0
+    for k in ("centerness", "bbox_pred", "cls_score"):
+        for a, b, c in zip(thr[k], lat[k], thr2[k]):
+            assert torch.equal(a, c)                                   # deterministic within the mode
+            moved = max(moved, float((a - b).abs().max() / b.abs().max().clamp(min=1.0)))
+    assert 0.0 < moved < 1e-5, moved                                   # a different summation order, nothing more
+
+
 @pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 2), ("cfg2_scannet", 6)])
 def test_hot_path_in_strict_fp32_mode(name, n_views):
     """The same scenes with --conv-mode f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every Linear and
