@@ -473,7 +473,8 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
 
 /* value_proj (TU/deformable_cross_attention.py:417) with the result stored HEAD-MAJOR for the tiled gather:
  *   x [N*S][Cin] camera-major pixel rows -> y [N][M][S][Cm], y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j].
- *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128.
+ *   Same arithmetic per element as sgc_linear_rows_bf16x3; Cin % 32 == 0, Cm % 4 == 0 and Cm | 128 (Cm | 64 when M * Cm <= 64): a head
+ *   stays inside one column tile; other head sizes return SGC_EUNSUP (store row-major and permute instead).
  *   y_bf16 != 0: y is bfloat16 (round-to-nearest-even of the fp32 result) -- the opt-in bf16 storage mode.     */
 int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                      void *y, int y_bf16, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);

@@ -62,6 +62,28 @@ __device__ __forceinline__ float lane_xor(float v, int o) {
   return __shfl_xor(v, o);
 }
 
+// Sample coordinate `loc * size - 0.5` with the REFERENCE's two roundings: `loc_h * spatial_h` is a float product
+// (int promoted to float) and `- 0.5` a double subtraction rounded back to float on assignment
+// (ms_depth_score_sample_cuda_kernel.cuh:133-135, wms_deform_attn_cuda_kernel.cuh:286-287) -- nvcc cannot contract
+// that into an fma, so neither may hipcc: floor() of the result picks the pixel, a one-rounding fma flips it for
+// ~1 sample in 1e7.  (float product exact in double, one rounding of the exact difference == float subtraction.)
+__device__ __forceinline__ float sample_coord(float loc, float size) {
+#pragma clang fp contract(off)
+  const float prod = loc * size;
+  return prod - 0.5f;
+}
+
+// a / size, correctly rounded (== the IEEE division of the reference's `sampling_offsets / offset_normalizer`,
+// TU/deformable_cross_attention.py:428-455), for a wave-uniform size and rcp = RN(1 / size): one Newton correction of
+// the reciprocal product (Markstein): q0 = a * rcp is within 1.5 ulp, r = a - q0 * size is exact in an fma, RN(q0 + r * rcp)
+// is the correctly rounded quotient (checked against `/` on 3e8 random operands for every map size in use; a * rcp alone
+// differs from the quotient in the last bit for 20 % of the operands at size 80).  3 instructions instead of ~10.
+__device__ __forceinline__ float div_by_size(float a, float size, float rcp) {
+  const float q0 = a * rcp;
+  const float r = __builtin_fmaf(-q0, size, a);
+  return __builtin_fmaf(r, rcp, q0);
+}
+
 // One trilinear sample of the DFA3D operator, reduced to what the gather needs:
 // 4 corner weights (bilinear * depth score * attention weight) and 4 pixel indices
 // (-1 = corner outside the map).  Semantics: ms_depth_score_sample_cuda_kernel.cuh:24-148
@@ -81,9 +103,9 @@ struct Sample {
 __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict__ dist_px0,
                                             int64_t pix_stride, int H, int W, int D,
                                             float x, float y, float z, float aw) {
-  const float h_im = y * (float)H - 0.5f;
-  const float w_im = x * (float)W - 0.5f;
-  const float d_im = z * (float)D - 0.5f;
+  const float h_im = sample_coord(y, (float)H);
+  const float w_im = sample_coord(x, (float)W);
+  const float d_im = sample_coord(z, (float)D);
   sm.in2 = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
   sm.in3 = sm.in2 && d_im > -1.f && d_im < (float)D;
   const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);
@@ -143,9 +165,9 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(8)));
 
 __device__ __forceinline__ void make_sample_dp(Sample &sm, const float *__restrict__ dp_cam, int H, int W, int D,
                                                float x, float y, float z, float aw) {
-  const float h_im = y * (float)H - 0.5f;
-  const float w_im = x * (float)W - 0.5f;
-  const float d_im = z * (float)D - 0.5f;
+  const float h_im = sample_coord(y, (float)H);
+  const float w_im = sample_coord(x, (float)W);
+  const float d_im = sample_coord(z, (float)D);
   sm.in2 = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
   sm.in3 = sm.in2 && d_im > -1.f && d_im < (float)D;
   const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void dfa3d_bwd_kernel(const BwdParams p) {
       make_sample(sm, dpx, (int64_t)p.dist_heads * p.D, H, W, D, x, y, z, 1.f);
     } else {
       // geometry only (no depth), scores come from the caller
-      const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+      const float h_im = sample_coord(y, (float)H), w_im = sample_coord(x, (float)W);
       sm.in2 = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
       const float hf = floorf(h_im), wf = floorf(w_im);
       const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void dfa3d_bwd_kernel(const BwdParams p) {
     if (p.grad_attn) p.grad_attn[g] = R.res[2];
     float gz = 0.f;
     if (p.fused) {
-      const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f, d_im = z * (float)D - 0.5f;
+      const float h_im = sample_coord(y, (float)H), w_im = sample_coord(x, (float)W), d_im = sample_coord(z, (float)D);
       const bool in3 = h_im > -1.f && w_im > -1.f && d_im > -1.f && h_im < (float)H && w_im < (float)W && d_im < (float)D;
       if (in3) {
         const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);
@@ -316,7 +316,7 @@ __global__ void depth_score_bwd_kernel(const float *__restrict__ dist, const int
     const int b = (int)(g / ((int64_t)P * L * M) / Q);
     const int H = (int)shapes3[l * 3], W = (int)shapes3[l * 3 + 1], Dl = (int)shapes3[l * 3 + 2];
     const float x = loc3[g * 3], y = loc3[g * 3 + 1], z = loc3[g * 3 + 2];
-    const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f, d_im = z * (float)Dl - 0.5f;
+    const float h_im = sample_coord(y, (float)H), w_im = sample_coord(x, (float)W), d_im = sample_coord(z, (float)Dl);
     float gz = 0.f;
     if (h_im > -1.f && w_im > -1.f && d_im > -1.f && h_im < (float)H && w_im < (float)W && d_im < (float)Dl) {
       const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);

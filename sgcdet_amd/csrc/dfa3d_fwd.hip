@@ -267,19 +267,18 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {          // stage B: locations, softmax over the P adjacent lanes
       if (MODE == kPairsDeform) {
-        // offset / (W,H,D) as a multiply by the (wave-uniform) reciprocal and exp / division through the
-        // hardware v_exp / v_rcp: <= 2 ulp from the reference's IEEE forms
-        x[j] = x[j] + uv[j].x * rW;
-        y[j] = y[j] + uv[j].y * rH;
-        z[j] = z[j] + dzv[j] * rD;
+        // the reference's forms: offset / (W,H,D) with IEEE rounding (div_by_size), expf, a true division (see dfa3d_tile.hip)
+        x[j] = x[j] + div_by_size(uv[j].x, (float)p.W, rW);
+        y[j] = y[j] + div_by_size(uv[j].y, (float)p.H, rH);
+        z[j] = z[j] + div_by_size(dzv[j], (float)p.D, rD);
         float mx = lgv[j];
 #pragma unroll
         for (int o = 1; o < P; o <<= 1) mx = fmaxf(mx, lane_xor(mx, o));
-        const float e = __expf(lgv[j] - mx);
+        const float e = expf(lgv[j] - mx);
         float sum = e;
 #pragma unroll
         for (int o = 1; o < P; o <<= 1) sum += lane_xor(sum, o);
-        aw[j] = e * __frcp_rn(sum);
+        aw[j] = e / sum;
       }
     }
 #pragma unroll
@@ -525,7 +524,7 @@ __global__ __launch_bounds__(256) void wms_fwd_kernel(const float *__restrict__ 
       const float *vb = value + ((int64_t)b * S + lsi[l]) * MC + m * Cm + c0;
       for (int pt = 0; pt < P; ++pt) {
         const int64_t s = (sidx * L + l) * P + pt;
-        const float h_im = loc2[s * 2 + 1] * (float)H - 0.5f, w_im = loc2[s * 2] * (float)W - 0.5f;
+        const float h_im = sample_coord(loc2[s * 2 + 1], (float)H), w_im = sample_coord(loc2[s * 2], (float)W);
         if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;
         const float hf = floorf(h_im), wf = floorf(w_im);
         const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;

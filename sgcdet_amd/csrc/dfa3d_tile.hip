@@ -336,15 +336,17 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
     if (p.diag != 1) {
     for (; g0 < cnt; g0 += NW * UPW) {
       // ---------------- phase 1: lane = (unit, point), branch-free ----------------
-      // offset / (W,H,D) as a multiply by the wave-uniform reciprocal, exp / division through v_exp / v_rcp:
-      // <= 2 ulp from the reference's IEEE forms (TU/deformable_cross_attention.py:428-455), as the wave kernel
-      const float x = rec.x + r4.x * rW, y = rec.y + r4.y * rH, z = rec.z + r4.z * rD;
+      // the reference's forms (TU/deformable_cross_attention.py:428-455): offset / (W, H, D) with IEEE rounding (div_by_size),
+      // then the addition; softmax over the 4 points with expf and a true division.  (Round 3 multiplied by the reciprocal and
+      // used v_exp / v_rcp, <= 2 ulp off: same kernel time -- 109.4 vs 109.2 us config 2, 374 vs 365 us config 4, alternated
+      // rounds, profiles/r04_gather_ieee.txt -- so there is no reason to differ from the reference in the last bit.)
+      const float x = rec.x + div_by_size(r4.x, fW, rW), y = rec.y + div_by_size(r4.y, fH, rH), z = rec.z + div_by_size(r4.z, fD, rD);
       float mx = fmaxf(r4.w, lane_xor(r4.w, 1));
       mx = fmaxf(mx, lane_xor(mx, 2));
-      const float e = __expf(r4.w - mx);
+      const float e = expf(r4.w - mx);
       float sum = e + lane_xor(e, 1);
       sum += lane_xor(sum, 2);
-      const float aw = e * __frcp_rn(sum);
+      const float aw = e / sum;
       // next step's operands (one step ahead)
       const int gn = g0 + NW * UPW;
       float4 rec_n = rec, r4_n = r4;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
         r4_n = p.raw[((int64_t)iun * p.M + m) * P + pt];
       }
 
-      const float h_im = y * fH - 0.5f, w_im = x * fW - 0.5f, d_im = z * fD - 0.5f;
+      const float h_im = sample_coord(y, fH), w_im = sample_coord(x, fW), d_im = sample_coord(z, fD);
       const bool in2 = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
       const bool in3 = in2 && d_im > -1.f && d_im < fD;
       const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);

@@ -144,7 +144,7 @@ def rotated_iou_3d(pred, target):
 
 
 def rotated_iou_3d_loss(pred, target, weight=None, avg_factor=None, loss_weight=1.0, reduction="mean"):
-    if weight is not None and not torch.any(weight > 0):
+    if weight is not None and not torch.any(weight > 0) and reduction != "none":
         return pred.sum() * 0
     return _reduce(1 - rotated_iou_3d(pred, target), weight, avg_factor, loss_weight, reduction)
 

@@ -69,6 +69,20 @@ class DenseHead(nn.Module):
         vox_coords, ref_3d = self.get_voxel_indices()
         self.register_buffer("vox_coords", vox_coords)
         self.register_buffer("ref_3d", ref_3d)
+        self._tag_flat_coords()
+
+    def _tag_flat_coords(self):
+        """Declare ``vox_coords[:, 3] == arange`` (true by construction in get_voxel_indices) on the tensor OBJECT, keyed by
+        its version counter: the transformer then never needs the host read-back of ``_coords_are_flat`` -- also not when the
+        first use of a moved buffer falls into a graph capture.  An in-place overwrite (``load_state_dict``) bumps the version
+        and voids the tag; the content is then checked once on the host."""
+        vc = self.vox_coords
+        vc._sgc_flat = (vc._version, True)
+
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() build a new tensor object: tag it again
+        out = super()._apply(fn, *args, **kwargs)
+        self._tag_flat_coords()
+        return out
 
     def get_voxel_indices(self):
         """vox_coords [Nvox,4] = (x,y,z,flat) with flat = (x*ny + y)*nz + z; ref_3d [Nvox,3] =

@@ -648,7 +648,8 @@ class VoxFormerLayer(MyCustomBaseTransformerLayer):
     def _fused_tail(self, query, key, value, query_pos, key_pos, ref_3d, reference_points_cam, mask, key_padding_mask,
                     spatial_shapes, level_start_index, kwargs):
         from .conv_plan import CONV_MODE
-        if (not self.fuse_tail or torch.is_grad_enabled() or self.operation_order != ("cross_attn", "norm", "ffn", "norm")
+        # (module in training mode under no_grad: the six-launch path applies the attention / FFN dropouts, this one cannot)
+        if (not self.fuse_tail or torch.is_grad_enabled() or self.training or self.operation_order != ("cross_attn", "norm", "ffn", "norm")
                 or self.pre_norm or not kwargs.get("zero_query") or CONV_MODE != "bf16x3" or not query.is_cuda
                 or query_pos is not None):
             return None

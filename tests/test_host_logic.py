@@ -80,6 +80,8 @@ def test_losses_registry_builds_what_the_configs_name():
     w7 = torch.rand(16, 7, generator=g)                              # per-coordinate weights are averaged (rotated_iou_loss.py:75)
     assert torch.allclose(rot(p7, t7, weight=w7, avg_factor=4.0), losses.rotated_iou_3d_loss(p7, t7, w7.mean(-1), 4.0))
     assert float(rot(p7, t7, weight=torch.zeros(16), avg_factor=1.0)) == 0.0
+    none0 = rot(p7, t7, weight=torch.zeros(16), reduction_override="none")       # all-zero weights keep the [n] shape
+    assert none0.shape == (16,) and float(none0.abs().max()) == 0.0
     foc = LOSSES.build(dict(type="FocalLoss", use_sigmoid=True, gamma=1.5, alpha=0.3, loss_weight=0.5))
     x, y = torch.randn(30, 5, generator=g), torch.randint(-1, 5, (30,), generator=g)
     assert torch.equal(foc(x, y, avg_factor=7.0), losses.sigmoid_focal_loss(x, y, 1.5, 0.3, None, 7.0, 0.5))
