@@ -27,6 +27,7 @@
 //               block), mode 2: relu(y) + residual (decoder skip add); scale/shift carry the
 //               folded eval-mode BatchNorm (or the conv bias).
 #include "common.hpp"
+#include "diag.hpp"
 
 namespace sgc {
 int g_conv_products = 3;     // NOT a tuning knob (it changes results; sgc_set_conv_products): 3 = fp32-faithful 3-way bf16 split
@@ -56,17 +57,6 @@ int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 12
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_narrow = 1;       // halo kernel: 64-column tiles for layers with <= 64 output channels
-int g_tune_halo_nb = 2;           // halo kernel: weight buffers of the staged form (3 = staged two taps ahead; 8x8x4 brick only, see the kernel;
-                                  // 0 = direct-B form: weights straight into registers, no barrier per tap -- bit-identical, measured equal
-                                  // on the 90-GF layer (236 vs 229-240 us warm) and 2-7 % slower on the others, tools/halo_nb_ab.py).
-                                  // Round 3, interleaved A/B on the 8x8x4 brick, bit-identical: 3 buffers 246 - 249 vs 236 - 239 us (2 buffers);
-                                  // with the fragment reads pinned by scheduling barriers (second k-half before the first half's MFMAs, next
-                                  // tap's first half before the second half's) 252 - 254 us with 2 buffers, 254 - 255 with 3: the compiler's own
-                                  // schedule of the plain loop is the fastest of the four -> 2 stays
-int g_tune_halo_ring = 0;         // halo kernel: 0 weights staged through registers (default), 1 LDS-DMA ring on the 256 -> 256 layers,
-                                  // 2 ring everywhere.  Interleaved A/B, 8 rounds x 40 launches of the 90-GF layer on two boxes:
-                                  // staged 229.7 / 231.3 us, ring 237.2 / 238.1 us once the clocks have settled (the ring only wins the
-                                  // first, cold round: 264 vs 278 us) -- bit-identical, not faster under sustained load
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -820,66 +810,44 @@ static bool use_big_tile(const ConvParams &p, int Cout) {
 // of the brick holds each halo-row residue mod 16 exactly twice (checked offline for the three brick shapes:
 // 18 for BZ = 16, 12 for BZ = 8, 6 for BZ = 4) -- the precondition of the conflict-free lane assignment.
 __host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ + 2; }
-constexpr int HALO_AP = 32;              // ring form: bf16 per LDS row (64 B, no padding; 16-byte chunks XOR-swizzled by the row)
-constexpr int HALO_NST = 4;              // ring form: weight stages in LDS = 2 groups of 2 taps (one barrier per group)
-constexpr int HALO_BSTAGE = 2 * 128 * HALO_AP * 2;   // bytes of one weight stage: hi|lo planes of [128][32] bf16 = 16 KB
-__host__ __device__ constexpr size_t halo_tab_offset(int lrows, bool ring, int nb = 2) {
-  const size_t planes = ring ? (size_t)2 * lrows * HALO_AP * sizeof(uint16_t) + (size_t)HALO_NST * HALO_BSTAGE
-                             : (size_t)(2 * lrows + 2 * nb * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + nb x B hi|lo
-  const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                    // epilogue tile [256][BNV + 8]
+__host__ __device__ constexpr size_t halo_tab_offset(int lrows) {
+  const size_t planes = (size_t)(2 * lrows + 2 * 2 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
+  const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                        // epilogue tile [256][BNV + 8]
   return planes > stage ? planes : stage;
 }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 // BNV: output columns per workgroup, 128 (wave tile 64 x 64) or 64 (wave tile 64 x 32: the head's 28 / 32-column layers, which
 // otherwise spend three quarters of their matrix work on padding columns).
-// Diagnostic builds only (tools/diag_build.sh halostamps conv3d.hip -DSGC_HALO_STAMPS): shader-clock and real-time stamps
-// around the tap loop of every workgroup -> the clock the chip holds while this kernel runs (MI355X_MICROARCH.md, DVFS
-// give-back item 6).  The stamps go to a buffer of their own; no output value depends on them.
-#if defined(SGC_HALO_STAMPS)
-unsigned long long *g_halo_stamp_buf = nullptr;
-#endif
-
-// NB: weight buffers of the staged form.  2: a tap's weights are written while the previous tap is multiplied and can only be
-// read after the barrier that publishes them.  3 (round 3, where the LDS holds it: the 8x8x4 brick): weights are staged TWO
-// taps ahead, so the buffer of tap t + 1 is complete while tap t is multiplied and its first-k-half B fragments are read
-// BEFORE the barrier, next to the A fragments -- no LDS round trip at the head of a tap.  Same k order: bit-identical.
 // TD: 2-D form (sgc_conv2d_nhwc_bf16x3: the FPN's 3 x 3 output convolutions) -- the grid is (image, row, column),
 // a brick is BX images x BY x BZ pixels, there is no halo and no tap along x: 9 taps, (BY + 2)(BZ + 2) halo rows per image.
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2, bool TD = false>
+// STG: software-pipelined schedule with the barrier in the MIDDLE of a tap (round 4; the body explains the hazards).  The
+// lockstep form (STG = false) put the barrier at the end of a tap: behind it every wave first had to fetch the freshly published
+// weight fragments from LDS (MFMA pipe idle for an LDS round trip with 96 reads queued), and in front of it every wave waited
+// for its two weight ds_write_b128 to drain.  Timing builds (tools/halo_skip.py, 90-GF layer, warm): 232 us as shipped, 195
+// without the weight ds_writes, 215 without the barrier, 183 without the weight loads and writes, 179 with nothing but the MFMAs
+// and the loop -- the weight path cost a fifth of the kernel although it moves 16 KB per tap.  With the barrier at mid-tap the
+// operands of BOTH k-halves are in registers before the MFMAs that use them are reached, the weight tile is written a
+// half-tap before the barrier that publishes it, and nothing but wave skew is left at the barrier.  Every accumulator still
+// sees (tap, k-half, product) in the same order: bit-identical to the lockstep form.
+template <int BX, int BY, int BZ, int BNV = 128, int NP = 3, bool TD = false, bool STG = true>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
-  static_assert(!TD || (!RING && NB == 2), "the 2-D form uses the staged weights");
   constexpr int NTAP = TD ? 9 : 27, XO = TD ? 0 : 1;    // taps; halo width along x
-  static_assert(NP == 3 || !RING, "the single-product mode uses the staged form");
-  static_assert(NB == 2 || !RING, "three / no weight buffers belong to the staged form");
-  static_assert(BNV == 128 || (BNV == 64 && !RING), "the ring form is built for 128-column tiles");
-  // NB == 0: DIRECT-B form.  The weights never pass through LDS: the 8 waves are laid out 2 (voxels) x 4 (columns), a wave
-  // owns 128 voxels x 32 columns and loads the B fragments of its own 32 columns straight from global memory into registers,
-  // one tap ahead (each fragment is fetched by the two voxel-waves only, 32 KB per tap and CU through the L1).  No weight
-  // ds_write, no barrier per tap: the halo image is read-only within a channel slice, so waves run free for 27 taps.
-  // (Ablations of the staged form, warm, 90-GF layer: 236 us; without the weight loads 215, without the weight ds_writes 210,
-  //  without the barrier per tap 225, without all three 187 -- tools/halo_ablate.py.)
-  constexpr bool DB = NB == 0;
-  static_assert(!DB || (BNV == 128 && !RING), "the direct-B form is built for 128-column tiles of the staged form");
-  constexpr int RT = DB ? 4 : 2;                        // 32-row tiles per wave
-  constexpr int TN = DB ? 1 : BNV / 64, WCOL = DB ? 32 : BNV / 2;   // 32-column tiles per wave, columns per wave
+  constexpr int RT = 2;                                 // 32-row tiles per wave
+  constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2 * XO, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int NT = 512;
   constexpr int NA = (HROWS * 8 + NT - 1) / NT;     // float4 halo chunks per thread
-  constexpr int AP = RING ? HALO_AP : LDKH;          // bf16 per LDS row of the halo image
-  constexpr int A_PLANE = LROWS * AP, B_PLANE = BNV * LDKH;
+  constexpr int A_PLANE = LROWS * LDKH, B_PLANE = BNV * LDKH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
   // [8 tiles][32 lanes], behind both the staging planes and the epilogue's output tile that later overlays them
-  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, RING, NB));
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = DB ? wid >> 2 : wid >> 1, wn = DB ? wid & 3 : wid & 1;
-  const int nbx = (p.gx + BX - 1) / BX, nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
-  (void)nbx;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
   int bid = blockIdx.x;
   const int bk = bid % nbz; bid /= nbz;
   const int bj = bid % nby; const int bi = bid / nby;
@@ -967,459 +935,230 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-#if defined(SGC_HALO_STAMPS)
-  unsigned long long *stamp = p.stamps ? p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4) : nullptr;
-  if (stamp && tid == 0) { stamp[0] = __builtin_readcyclecounter(); stamp[1] = __builtin_amdgcn_s_memrealtime(); }
-#endif
+  SGC_HALO_STAMP(0);
 
-  if constexpr (RING) {
-    // ---- ring form: weights by LDS-DMA into a 3-stage ring, no registers and no ds_write on the weight path ----
-    // (The staged form below moves every weight tile global -> VGPR -> ds_write_b128 -> LDS between two barriers; with
-    //  that path removed in a timing build the 90-GF layer ran 222 instead of 294 us.)  One global_load_lds_dwordx4 writes
-    //  1 KiB = 16 rows x 64 B contiguously, so the LDS rows carry no padding; bank conflicts are avoided by XOR-ing the
-    //  16-byte chunk index with (row >> 2) & 3 -- applied on the SOURCE address of the DMA for the weights, on the
-    //  ds_write address for the halo rows, and on every fragment read.  With the lane -> voxel assignment above (halo
-    //  rows distinct mod 16 inside every 16-lane group of a ds_read_b128) both images are conflict-free.
-    //  Wave w fills rows 16 w .. 16 w + 15 of both planes of a stage: 2 DMA instructions per wave per tap, issued two
-    //  taps ahead; the step-end wait leaves the youngest tap in flight (counted vmcnt) and a raw s_barrier publishes the
-    //  stage every wave reads next.  Same accumulation order as the staged form: bit-identical results.
-    __bf16 *Bring = A_lo + A_PLANE;
-    float4 ra[NA];
-    // halo rows through BUFFER loads: rows outside the volume (and the padding slots past HROWS) get an out-of-range
-    // offset and come back as zeros, so every wave issues exactly NA load instructions -- the counted waits below rely
-    // on it (with plain loads the compiler branches around a load whose lanes are all outside the volume)
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.x), 0, (int)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
-    auto load_A = [&](int cc) {
+  float4 ra[NA];
+  uint4 rbh, rbl;
+  // Addressing is fixed per thread for the whole kernel (the halo rows a thread stages and its weight row do not depend on the
+  // channel slice or the tap): one 32-bit byte offset per chunk, 0xfffffff0 = "outside the volume / padding slot", computed once;
+  // a slice / a tap then only moves a uniform offset.  Buffer loads return zeros past the tensor, so the loads carry no branch.
+  constexpr unsigned OOB = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+  const int w_bytes = (int)(unsigned)((int64_t)NTAP * p.Cout * p.Cin * 2);
+  const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
+  unsigned aoff[NA];
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int idx = i * NT + tid;
-        const int row = idx >> 3, c4 = idx & 7;
-        const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-        const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
-        const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
-        const int off = (((gx * p.iy + gy) * p.iz + gz) * p.Cin + cc * BK + c4 * 4) * 4;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in ? off : 0x7fffffff, 0, 0);
-        ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  for (int i = 0; i < NA; ++i) {
+    const int idx = i * NT + tid;
+    const int row = idx >> 3, c4 = idx & 7;
+    const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
+    const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
+    const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
+    aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+  }
+  const unsigned boff = bn_ok ? (unsigned)((n0 + bn) * p.Cin + bc * 8) * 2u : OOB;
+  auto load_A = [&](int cc) {
+    const int soff = __builtin_amdgcn_readfirstlane(cc * (BK * 4));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff, 0);
+      ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    }
+  };
+  // the split of a loaded halo chunk, in place: ra[i] = (hi.xy, hi.zw, lo.xy, lo.zw) as packed bf16 pairs.  Called under the
+  // last tap of a slice (the loads went out three taps earlier), so that between the slice's last barrier and the next
+  // slice's first tap only the ds_writes remain -- the vector work of the split overlaps the other wave's MFMAs instead of
+  // sitting between two barriers.
+  auto split_A = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = (__bf16)v[e];
+        h[e] = hb;
+        l[e] = (__bf16)(v[e] - (float)hb);
       }
-    };
-    auto store_A = [&]() {
+      const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
+      ra[i] = make_float4(__uint_as_float(hu.x), __uint_as_float(hu.y), __uint_as_float(lu.x), __uint_as_float(lu.y));
+    }
+  };
+  auto store_A = [&]() {               // ra[] holds split chunks (split_A)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int idx = i * NT + tid;
-        const int row = idx >> 3, c4 = idx & 7;
-        if (row < HROWS) {
-          const int lrow = (row / HZ) * HZP + row % HZ;
-          const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-          bf16x4 h, l;
+    for (int i = 0; i < NA; ++i) {
+      // LDS slot of the chunk, recomputed once per slice (two constant divisions) rather than held in NA registers
+      const int idx = i * NT + tid;
+      const int row = idx >> 3, c4 = idx & 7;
+      if (row < HROWS) {
+        const int o = ((row / HZ) * HZP + row % HZ) * LDKH + c4 * 4;
+        *reinterpret_cast<uint2 *>(A_hi + o) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+        if constexpr (NP == 3) *reinterpret_cast<uint2 *>(A_lo + o) = make_uint2(__float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
+      }
+    }
+  };
+  auto load_B = [&](int tap, int cc) {
+    const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
+    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff, soff, 0);
+    rbh = make_uint4(h[0], h[1], h[2], h[3]);
+    if constexpr (NP == 3) {
+      const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(wlr, boff, soff, 0);
+      rbl = make_uint4(l[0], l[1], l[2], l[3]);
+    } else {
+      rbl = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_B = [&](int buf) {
+    if (tid >= BNV * 4) return;
+    __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
+    *reinterpret_cast<uint4 *>(b) = rbh;
+    if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
+  };
+  auto tap_off = [&](int tap) {
+    const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    return ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
+  };
+  // one k-half (16 channels) of a tap: A fragments of the wave's two row tiles, B fragments of its TN column tiles
+  struct Frag { bf16x8 ah[RT], al[RT], bh[TN], bl[TN]; };
+  auto read_A = [&](Frag &f, int toff, int kk) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const __bf16 hb = (__bf16)v[e];
-            h[e] = hb;
-            l[e] = (__bf16)(v[e] - (float)hb);
-          }
-          const int o = lrow * AP + (((c4 >> 1) ^ ((lrow >> 2) & 3)) << 3) + (c4 & 1) * 4;
-          *reinterpret_cast<bf16x4 *>(A_hi + o) = h;
-          *reinterpret_cast<bf16x4 *>(A_lo + o) = l;
+    for (int i = 0; i < RT; ++i) {
+      const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
+      f.ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
+      if constexpr (NP == 3) f.al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
+    }
+  };
+  auto read_B = [&](Frag &f, int buf, int kk) {
+    const __bf16 *b = Bbase + buf * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8 + kk * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * LDKH);
+      if constexpr (NP == 3) f.bl[j] = *reinterpret_cast<const bf16x8 *>(b + B_PLANE + j * 32 * LDKH);
+    }
+  };
+  auto mfma_half = [&](const Frag &f) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
       }
-    };
-    // weight DMA: lane -> (row 16 wid + (lane >> 2), LDS chunk lane & 3) of its wave's 1-KiB block; the chunk it FETCHES is
-    // the swizzled one
-    const int brow = min(n0 + 16 * wid + (lane >> 2), p.Cout - 1);            // columns past Cout: any finite row (never stored)
-    const int64_t bsrc = (int64_t)brow * p.Cin + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
-    const int64_t wtap = (int64_t)p.Cout * p.Cin;
-    const int bdst = __builtin_amdgcn_readfirstlane(wid) * 1024;              // byte offset of the wave's block in a plane
-    auto issue_B = [&](int tap, int cc, int stage) {
-      const int64_t off = tap * wtap + cc * BK + bsrc;
-      unsigned char *d = reinterpret_cast<unsigned char *>(Bring) + stage * HALO_BSTAGE + bdst;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.w_hi + off),
-                                       (__attribute__((address_space(3))) void *)d, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.w_lo + off),
-                                       (__attribute__((address_space(3))) void *)(d + HALO_BSTAGE / 2), 16, 0, 0);
-    };
-    const int S = (c_hi - c_lo) * 27;
-    // issue pointer: runs one GROUP (two taps, stages 2 g & 1 .. + 1) ahead of the compute pointer
-    int itap = 0, icc = c_lo, ist = 0, issued = 0;
-    auto issue_next = [&]() {
-      if (issued < S) {
-        issue_B(itap, icc, ist);
-        ++issued;
-        if (++itap == 27) { itap = 0; ++icc; }
-      }
-      ist = (ist + 1) & (HALO_NST - 1);
-    };
+  };
+  const int steps_total = (c_hi - c_lo) * NTAP;
+  auto step_tap = [&](int st) { return st % NTAP; };
+  auto step_cc = [&](int st) { return c_lo + st / NTAP; };
+
+  if constexpr (STG) {
+    // P: operands of a tap's first k-half, Q: of its second k-half (32 registers each).  Tap g, every wave:
+    //   first half   issue the reads of Q(g); write the weight tile of tap g + 1 (registers loaded during tap g - 1) and
+    //                start the load of tap g + 2; multiply P(g) -- in registers since the second half of tap g - 1
+    //   BARRIER      publishes tile g + 1; its own waits (Q(g) reads, the tile's ds_writes) ended long before
+    //   second half  issue the reads of P(g + 1); multiply Q(g)
+    // Hazards: tile g + 1 overwrites tile g - 1, whose last reads (Q(g - 1)) completed before barrier g - 1; P(g + 1) is read
+    // behind barrier g, which follows every wave's ds_writes of tile g + 1.  At a slice's last tap the second half reads
+    // nothing from the halo image (P of the next slice needs the new image), so barrier g also ends the slice's halo reads:
+    // the next slice's image is written under the MFMAs of that second half, one more barrier publishes it.
+    // (Weight tiles by LDS-DMA instead of registers + ds_write_b128 -- unpadded swizzled rows, issued a whole tap ahead of the
+    //  barrier that publishes them -- were built into this schedule and measured: 0.90 of the lockstep form's time against 0.83
+    //  for the register-staged tiles, same box, bit-identical.  Two DMA pieces per wave cost more issue time than two ds_writes.)
     load_A(c_lo);
-    issue_next();
-    issue_next();
+    load_B(0, c_lo);
+    split_A();
     store_A();
-    wait_vmcnt<0>();
+    store_B(0);
+    if (steps_total > 1) load_B(step_tap(1), step_cc(1));      // stays in registers until tap 0 publishes it
     __syncthreads();
-    // fragment addressing: A row = arow[i] + toff(tap), chunk (2 kk + fh) ^ ((row >> 2) & 3); B row = wn*64 + j*32 + fr,
-    // whose (row >> 2) & 3 = (fr >> 2) & 3 is a lane constant
-    int bo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) bo[kk] = (wn * 64 + fr) * AP + (((2 * kk + fh) ^ ((fr >> 2) & 3)) << 3);
-    bf16x8 ah_n[2] = {}, al_n[2] = {};
-    auto read_A0 = [&](int tap) {
-      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-      const int toff = ((dx - 1) * HY + (dy - 1)) * HZP + (dz - 1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = arow[i] + toff;
-        const int o = row * AP + ((fh ^ ((row >> 2) & 3)) << 3);
-        ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-        al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-      }
-    };
-    if (wave_live) read_A0(0);
-    constexpr int TA = 18;                         // tap at which the next slice's halo loads are issued
-    int s = 0, st = 0;
+    Frag P = {}, Q = {};
+    constexpr int SKIP = SGC_HALO_SKIP;      // timing builds only (diag.hpp); 0 in the product
+    if (wave_live) { read_A(P, tap_off(0), 0); read_B(P, 0, 0); }
+    int g = 0;
     for (int cc = c_lo; cc < c_hi; ++cc) {
-      for (int tap = 0; tap < 27; ++tap, ++s) {
-        const bool last_tap = tap == 26;
-        const bool prefetchA = tap == TA && cc + 1 < c_hi;
-        if ((s & 1) == 0) {                        // group start: weights of the NEXT group (steps s + 2, s + 3); their stages were
-          issue_next();                            // last read in the previous group, which every wave has left
-          issue_next();
-        }
-        if (prefetchA) load_A(cc + 1);             // NA loads, younger than the DMA just issued
-        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
-        const __bf16 *bh_ = Bring + st * (HALO_BSTAGE / 2);
-        const __bf16 *bl_ = bh_ + HALO_BSTAGE / 4;
+      // the taps are unrolled: a tap's halo offset, its place in the slice and (with the slice's parity) its weight buffer are
+      // compile-time constants, so the fragment addresses are one register + an immediate and the tap decode -- ~50 scalar and
+      // ~12 vector instructions per tap in the rolled loop (SQ_INSTS_SALU > SQ_INSTS_VALU in round 3's counters) -- is gone
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap, ++g) {
+        const bool last_tap = tap == NTAP - 1;
+        const bool more = g + 1 < steps_total;
         if (wave_live) {
-#pragma unroll
-          for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              if (kk == 0) {
-                ah[i] = ah_n[i]; al[i] = al_n[i];
-              } else {
-                const int row = arow[i] + toff;
-                const int o = row * AP + (((2 + fh) ^ ((row >> 2) & 3)) << 3);
-                ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-                al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + bo[kk] + j * 32 * AP);
-              bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + bo[kk] + j * 32 * AP);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-              }
-          }
-          if (!last_tap) read_A0(tap + 1);
+          if (!(SKIP & 16) || g == 0) read_A(Q, tap_off(tap), 1);
+          if (!(SKIP & 8) || g == 0) read_B(Q, g & 1, 1);
         }
-        // group end: the weights of the next group (issued at this group's start) must have landed for THIS wave before
-        // the barrier; only halo loads issued since may stay in flight
-        const bool gend = (s & 1) || s + 1 == S;
-        if (gend) {
-          if (cc + 1 < c_hi && (tap == TA || tap == TA + 1)) wait_vmcnt<NA>(); else wait_vmcnt<0>();
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
+        if (!(SKIP & 2) && more) store_B((g + 1) & 1);
+        if (!(SKIP & 4) && g + 2 < steps_total) load_B(step_tap(g + 2), step_cc(g + 2));
+        if (tap == NTAP - 3 && cc + 1 < c_hi) load_A(cc + 1);    // next slice's halo rides under the last taps
+        if (wave_live) mfma_half(P);
+        if (last_tap && cc + 1 < c_hi) split_A();
+        if (!(SKIP & 1)) __syncthreads();
+        // the fence keeps the refill of P behind the MFMAs that consumed it (hoisted above them it needs a second set of
+        // registers) and behind the barrier that publishes the tile it reads
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave_live && !last_tap) {
+          if (!(SKIP & 16)) read_A(P, tap_off(tap + 1), 0);
+          if (!(SKIP & 8)) read_B(P, (g + 1) & 1, 0);
         }
-        if (++st == HALO_NST) st = 0;
-        if (last_tap && cc + 1 < c_hi && !gend) {  // slice end in the middle of a group: every wave must be past the last tap
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
+        if (last_tap && cc + 1 < c_hi) store_A();                // every wave's halo reads of this slice are complete
+        if (wave_live) mfma_half(Q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (cc + 1 < c_hi) {
+        __syncthreads();                                          // the new halo image is published
+        if (wave_live) { read_A(P, tap_off(0), 0); read_B(P, g & 1, 0); }
+      }
+    }
+  } else {
+    // lockstep form.  SGC_HALO_SKIP (diag.hpp; 0 in the product) removes parts of the tap loop in timing builds
+    constexpr int SKIP = SGC_HALO_SKIP;
+    int g = 0;                       // global step counter -> B buffer
+    load_A(c_lo);
+    load_B(0, c_lo);
+    split_A();
+    store_A();
+    store_B(0);
+    __syncthreads();
+    // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
+    // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
+    Frag P = {}, Q = {};
+    read_A(P, tap_off(0), 0);
+    for (int cc = c_lo; cc < c_hi; ++cc) {
+      for (int tap = 0; tap < NTAP; ++tap, ++g) {
+        const bool last_tap = tap == NTAP - 1;
+        if (!(SKIP & 4) && g + 1 < steps_total) load_B(step_tap(g + 1), step_cc(g + 1));
+        if (tap == NTAP - 3 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
+        const int toff = tap_off(tap);
+        if (wave_live) {
+          if (!(SKIP & 8) || g == 0) read_B(P, g & 1, 0);
+          if (!(SKIP & 16) || g == 0) read_A(Q, toff, 1);
+          if (!(SKIP & 8) || g == 0) read_B(Q, g & 1, 1);
+          mfma_half(P);
+          mfma_half(Q);
+          if (!last_tap && (!(SKIP & 16) || g == 0)) read_A(P, tap_off(tap + 1), 0);
         }
+        if (!(SKIP & 2) && g + 1 < steps_total) store_B((g + 1) & 1);
+        if (last_tap && cc + 1 < c_hi) split_A();
+        if (!(SKIP & 1)) __syncthreads();
       }
       if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
         store_A();
         __syncthreads();
-        if (wave_live) read_A0(0);
-      }
-    }
-  } else {
-    float4 ra[NA];
-    uint4 rbh, rbl;
-    // Addressing is fixed per thread for the whole kernel (the halo rows a thread stages and its weight row do not depend on the
-    // channel slice or the tap): one 32-bit byte offset per chunk, 0xfffffff0 = "outside the volume / padding slot", computed once;
-    // a slice / a tap then only moves a uniform offset.  Buffer loads return zeros past the tensor, so the loads carry no branch.
-    // (It used to redo the row decode, the bounds test and a 64-bit address per chunk in every slice: ~500 vector instructions per
-    //  wave and slice injected into the last taps' MFMA stream.)
-    constexpr unsigned OOB = 0xfffffff0u;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
-    const int w_bytes = (int)(unsigned)((int64_t)NTAP * p.Cout * p.Cin * 2);
-    const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
-    unsigned aoff[NA];
-    int alds[NA];                                   // LDS element offset of the chunk, -1 = padding slot past HROWS
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int idx = i * NT + tid;
-      const int row = idx >> 3, c4 = idx & 7;
-      const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
-      const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
-      const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
-      aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
-      alds[i] = row < HROWS ? ((row / HZ) * HZP + row % HZ) * LDKH + c4 * 4 : -1;
-    }
-    const unsigned boff = bn_ok ? (unsigned)((n0 + bn) * p.Cin + bc * 8) * 2u : OOB;
-    auto load_A = [&](int cc) {
-      const int soff = __builtin_amdgcn_readfirstlane(cc * (BK * 4));
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff, 0);
-        ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-      }
-    };
-    // the split of a loaded halo chunk, in place: ra[i] = (hi.xy, hi.zw, lo.xy, lo.zw) as packed bf16 pairs.  Called under the
-    // last tap of a slice (the loads went out three taps earlier), so that between the slice's last barrier and the next
-    // slice's first tap only the ds_writes remain -- the vector work of the split overlaps the other wave's MFMAs instead of
-    // sitting between two barriers.
-    auto split_A = [&]() {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-        bf16x4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const __bf16 hb = (__bf16)v[e];
-          h[e] = hb;
-          l[e] = (__bf16)(v[e] - (float)hb);
-        }
-        const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
-        ra[i] = make_float4(__uint_as_float(hu.x), __uint_as_float(hu.y), __uint_as_float(lu.x), __uint_as_float(lu.y));
-      }
-    };
-    auto store_A = [&]() {               // ra[] holds split chunks (split_A)
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        if (alds[i] >= 0) {
-          *reinterpret_cast<uint2 *>(A_hi + alds[i]) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
-          if constexpr (NP == 3) *reinterpret_cast<uint2 *>(A_lo + alds[i]) = make_uint2(__float_as_uint(ra[i].z), __float_as_uint(ra[i].w));
-        }
-      }
-    };
-    auto load_B = [&](int tap, int cc) {
-#if defined(SGC_DIAG_HALO_NO_BLOAD)
-      rbh = make_uint4(tap, cc, 0, 0); rbl = rbh;
-      return;
-#endif
-      const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
-      const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff, soff, 0);
-      rbh = make_uint4(h[0], h[1], h[2], h[3]);
-      if constexpr (NP == 3) {
-        const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(wlr, boff, soff, 0);
-        rbl = make_uint4(l[0], l[1], l[2], l[3]);
-      } else {
-        rbl = make_uint4(0, 0, 0, 0);
-      }
-    };
-    auto store_B = [&](int buf) {
-      if (tid >= BNV * 4) return;
-#if defined(SGC_DIAG_HALO_NO_BWRITE)
-      if (rbh.x == 0x12345678u)
-#endif
-      {
-      __bf16 *b = Bbase + buf * 2 * B_PLANE + bn * LDKH + bc * 8;
-      *reinterpret_cast<uint4 *>(b) = rbh;
-      if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b + B_PLANE) = rbl;
-      }
-    };
-
-    if constexpr (DB) {
-      // ---- direct-B form ----
-      const int bcol = n0 + wn * 32 + fr;                                  // this lane's weight row (MFMA B operand: column fr of the tile)
-      const unsigned bfoff = bcol < p.Cout ? (unsigned)(bcol * p.Cin + fh * 8) * 2u : OOB;
-      bf16x8 bh_c[2], bl_c[2], bh_x[2], bl_x[2];                           // fragments of the tap being multiplied / of the next one
-      auto load_Bf = [&](int tap, int cc, bf16x8 (&h)[2], bf16x8 (&l)[2]) {
-        const int soff = __builtin_amdgcn_readfirstlane((tap * p.Cout * p.Cin + cc * BK) * 2);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          h[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(whr, bfoff, soff + kk * 32, 0));
-          if constexpr (NP == 3) l[kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wlr, bfoff, soff + kk * 32, 0));
-        }
-      };
-      bf16x8 ah_n[RT] = {}, al_n[RT] = {};
-      auto read_A0 = [&](int tap) {
-        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const int o = (arow[i] + toff) * LDKH + fh * 8;
-          ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-          if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-        }
-      };
-      load_A(c_lo);
-      load_Bf(0, c_lo, bh_c, bl_c);
-      split_A();
-      store_A();
-      __syncthreads();
-      if (wave_live) read_A0(0);
-      for (int cc = c_lo; cc < c_hi; ++cc) {
-        for (int tap = 0; tap < 27; ++tap) {
-          const bool last_tap = tap == 26;
-          const bool more = !last_tap || cc + 1 < c_hi;
-          if (more) load_Bf(last_tap ? 0 : tap + 1, last_tap ? cc + 1 : cc, bh_x, bl_x);
-          if (tap == 24 && cc + 1 < c_hi) load_A(cc + 1);          // next slice's halo rides under the last taps
-          const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-          const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
-          if (wave_live) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-              bf16x8 ah[RT], al[RT];
-#pragma unroll
-              for (int i = 0; i < RT; ++i) {
-                if (kk == 0) {
-                  ah[i] = ah_n[i]; al[i] = al_n[i];
-                } else {
-                  const int o = (arow[i] + toff) * LDKH + fh * 8 + 16;
-                  ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-                  if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-                }
-              }
-#pragma unroll
-              for (int i = 0; i < RT; ++i) {
-                if constexpr (NP == 3) {
-                  acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh_c[kk], acc[i][0], 0, 0, 0);
-                  acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl_c[kk], acc[i][0], 0, 0, 0);
-                }
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh_c[kk], acc[i][0], 0, 0, 0);
-              }
-            }
-            if (!last_tap) read_A0(tap + 1);
-          }
-          if (last_tap && cc + 1 < c_hi) split_A();
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) { bh_c[kk] = bh_x[kk]; bl_c[kk] = bl_x[kk]; }
-        }
-        if (cc + 1 < c_hi) {
-          __syncthreads();              // every wave is past the last tap of this slice: the halo can be replaced
-          store_A();
-          __syncthreads();
-          if (wave_live) read_A0(0);
-        }
-      }
-    } else {
-      int g = 0;                       // global step counter -> B buffer
-      const int steps_total = (c_hi - c_lo) * NTAP;
-      auto step_tap = [&](int st) { return st % NTAP; };
-      auto step_cc = [&](int st) { return c_lo + st / NTAP; };
-      load_A(c_lo);
-      load_B(0, c_lo);
-      split_A();
-      store_A();
-      store_B(0);
-      if constexpr (NB == 3) {
-        if (steps_total > 1) { load_B(step_tap(1), step_cc(1)); store_B(1); }
-      }
-      __syncthreads();
-      // A fragments of the NEXT tap's first k-half are read before the barrier (the halo is static within a
-      // channel slice), so after the barrier only the freshly written B tile has to come out of LDS
-      // (reading BOTH k-halves of the next tap's A fragments before the barrier: 248 VGPRs, 262 vs 249 us -- no;
-      //  s_setprio(1) around the MFMA block: 274 vs 250 us -- no)
-      bf16x8 ah_n[2] = {}, al_n[2] = {};
-      bf16x8 bh_n[TN] = {}, bl_n[TN] = {};          // NB == 3: first-k-half B fragments of the next tap
-      auto read_A0 = [&](int tap) {
-        const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
-  #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int o = (arow[i] + toff) * LDKH + fh * 8;
-          ah_n[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-          if constexpr (NP == 3) al_n[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-        }
-      };
-      auto read_B0 = [&](int buf) {
-        const __bf16 *b = Bbase + buf * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
-  #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh_n[j] = *reinterpret_cast<const bf16x8 *>(b + j * 32 * LDKH);
-          if constexpr (NP == 3) bl_n[j] = *reinterpret_cast<const bf16x8 *>(b + B_PLANE + j * 32 * LDKH);
-        }
-      };
-      read_A0(0);
-      if constexpr (NB == 3) read_B0(0);
-      int bcur = 0;                    // buffer of the tap being multiplied (NB == 3: g % 3 without the division)
-      for (int cc = c_lo; cc < c_hi; ++cc) {
-        for (int tap = 0; tap < NTAP; ++tap, ++g) {
-          const bool last_tap = tap == NTAP - 1;
-          const bool more = !last_tap || cc + 1 < c_hi;
-          const int ahead = NB == 3 ? 2 : 1;                       // taps the weight staging runs ahead
-          const bool more_b = g + ahead < steps_total;
-          if (more_b) load_B(step_tap(g + ahead), step_cc(g + ahead));
-          if (tap == NTAP - 3 && cc + 1 < c_hi) load_A(cc + 1);      // next slice's halo rides under the last taps
-          const int dx = TD ? XO : tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-          const int toff = ((dx - XO) * HY + (dy - 1)) * HZP + (dz - 1);
-          const int bsel = NB == 3 ? bcur : (g & 1);
-          const __bf16 *bh_ = Bbase + bsel * 2 * B_PLANE + (wn * WCOL + fr) * LDKH + fh * 8;
-          const __bf16 *bl_ = bh_ + B_PLANE;
-          const int bnext = NB == 3 ? (bcur == 2 ? 0 : bcur + 1) : 0;
-          if (wave_live) {
-  #pragma unroll
-          for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 ah[2], al[2], bh[TN], bl[TN];
-  #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              if (kk == 0) {
-                ah[i] = ah_n[i]; al[i] = al_n[i];
-              } else {
-                const int o = (arow[i] + toff) * LDKH + fh * 8 + kk * 16;
-                ah[i] = *reinterpret_cast<const bf16x8 *>(A_hi + o);
-                if constexpr (NP == 3) al[i] = *reinterpret_cast<const bf16x8 *>(A_lo + o);
-              }
-            }
-  #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              if (NB == 3 && kk == 0) {
-                bh[j] = bh_n[j]; bl[j] = bl_n[j];
-              } else {
-                bh[j] = *reinterpret_cast<const bf16x8 *>(bh_ + j * 32 * LDKH + kk * 16);
-                if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(bl_ + j * 32 * LDKH + kk * 16);
-              }
-            }
-  #pragma unroll
-            for (int i = 0; i < 2; ++i)
-  #pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                if constexpr (NP == 3) {
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-              }
-          }
-          if (!last_tap) read_A0(tap + 1);
-          if constexpr (NB == 3) { if (more) read_B0(bnext); }     // published by the barrier that ended the previous tap
-          }
-          if (more_b) store_B(NB == 3 ? (bnext == 2 ? 0 : bnext + 1) : ((g + 1) & 1));
-          if (last_tap && cc + 1 < c_hi) split_A();
-          bcur = bnext;
-  #if !defined(SGC_DIAG_HALO_NO_TAPBARRIER)
-          __syncthreads();
-  #endif
-        }
-        if (cc + 1 < c_hi) {            // every wave is past the last tap: the halo can be replaced
-          store_A();
-          __syncthreads();
-          if (wave_live) read_A0(0);
-        }
+        if (wave_live && (!(SKIP & 16))) read_A(P, tap_off(0), 0);
       }
     }
   }
+  SGC_HALO_STAMP(2);
 
-#if defined(SGC_HALO_STAMPS)
-  if (stamp && tid == 0) { stamp[2] = __builtin_readcyclecounter(); stamp[3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
   // Epilogue through LDS (as in the implicit-GEMM kernel): the halo / weight buffers are free, the 256 x 128 tile
   // leaves as 16-byte row-contiguous stores instead of 64 four-byte stores per lane.
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
     constexpr int LDC = BNV + 8;
     float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 139 KB (launch_halo sizes LDS for it)
-    if constexpr (DB) __syncthreads();                       // free-running waves: the tile overlays the halo image others may still read
+    if constexpr (STG) __syncthreads();                      // the second half of the last tap ran after the loop's last barrier
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -1489,11 +1228,11 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     }
 }
 
-// (A one-wave-per-SIMD form of this kernel -- 4 waves of 64 x 128 outputs, up to 512 registers, the fragments of
-//  the next k-half and of the next tap read ahead of the MFMAs that precede them in program order -- was built,
-//  bit-identical, and measured: 309 us against 251 us on the 256 -> 256 layer at 40x40x16 (427 VGPRs, no spills).
-//  With the compiler's schedule a single wave exposes every s_waitcnt it takes; two waves per SIMD hide more than the
-//  read-ahead buys.  A hand-scheduled loop body is what that design needs; not adopted in this form.)
+// Forms of this kernel that were built, bit-identical, and measured slower or equal (the code is in the
+// history up to round 3): weights by LDS-DMA into a four-stage ring with swizzled unpadded rows (237 vs 230 us warm on the 90-GF
+// layer); weights straight from L2 into registers, no barrier per tap (236 vs 229-240, 2-7 % slower elsewhere); three weight
+// buffers staged two taps ahead (236 vs 232); v_mfma_f32_16x16x32_bf16 (234 vs 230); a one-wave-per-SIMD form with 512
+// registers (309 vs 251).
 
 // Zero-fill of a split-K accumulation target as a KERNEL, not hipMemsetAsync: a memset captured into a large
 // hipGraph (the whole-scene graph) is not ordered with the kernel nodes around it on ROCm 7.2 -- from the second
@@ -1536,38 +1275,17 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   return (nchunks + per - 1) / per;
 }
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128, int NP = 3, int NB = 2, bool TD = false>
-static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st);
+int g_tune_halo_stagger = 1;   // halo kernel: 1 software-pipelined schedule with the barrier at mid-tap (see the kernel), 0 lockstep form
 
-template <int BX, int BY, int BZ, bool RING, int BNV = 128>
-static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
-  // three weight buffers where the LDS holds them: the 8x8x4 brick (157.9 KB); never with the LDS-DMA ring
-  constexpr bool nb3_fits = halo_tab_offset((BX + 2) * (BY + 2) * halo_pitch(BZ), false, 3) + 512 <= 160 * 1024;
-  if constexpr (BNV == 128 && !RING) {
-    if (g_tune_halo_nb == 0) {                                 // direct-B form (no weight buffers in LDS)
-      if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1, 0>(p, OV, st);
-      return launch_halo_np<BX, BY, BZ, false, BNV, 3, 0>(p, OV, st);
-    }
-  }
-  if constexpr (nb3_fits && !RING) {
-    if (g_tune_halo_nb == 3) {
-      if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1, 3>(p, OV, st);
-      return launch_halo_np<BX, BY, BZ, false, BNV, 3, 3>(p, OV, st);
-    }
-  }
-  if (g_conv_products == 1) return launch_halo_np<BX, BY, BZ, false, BNV, 1>(p, OV, st);
-  return launch_halo_np<BX, BY, BZ, RING, BNV, 3>(p, OV, st);
-}
-
-template <int BX, int BY, int BZ, bool RING, int BNV, int NP, int NB, bool TD>
-static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
+template <int BX, int BY, int BZ, int BNV, int NP, bool TD, bool STG>
+static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
 #if defined(SGC_HALO_STAMPS)
   p.stamps = g_halo_stamp_buf;
 #endif
   constexpr int LROWS = (TD ? BX : BX + 2) * (BY + 2) * halo_pitch(BZ);
-  const size_t smem = halo_tab_offset(LROWS, RING, NB) + 256 * sizeof(uint16_t);
+  const size_t smem = halo_tab_offset(LROWS) + 256 * sizeof(uint16_t);
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB, TD>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
@@ -1585,8 +1303,18 @@ static int launch_halo_np(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, RING, BNV, NP, NB, TD>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
+}
+
+template <int BX, int BY, int BZ, int BNV = 128, bool TD = false>
+static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
+  if (g_tune_halo_stagger) {
+    if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true>(p, OV, st);
+    return launch_halo_k<BX, BY, BZ, BNV, 3, TD, true>(p, OV, st);
+  }
+  if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, false>(p, OV, st);
+  return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
 }
 
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
@@ -1784,17 +1512,14 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     return rows_gemm_launch(x, Cin, w_hi, w_lo, scale, shift, residual_or_null, y, nullptr, (int)OV, Cin, Cout, relu, 0, 0, 0, st);
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
-    // ring form: an option (see g_tune_halo_ring); 1 = the 256 -> 256 layers on the 4x4x16 brick, 2 = everywhere
-    const bool ring = (g_tune_halo_ring == 2 || (g_tune_halo_ring == 1 && halo_brick_shape(p.gx, p.gy, p.gz) == 0 && Cout >= 256 && Cin <= 256)) &&
-                      (int64_t)ix * iy * iz * Cin * 4 < 0x7fffffff;   // 32-bit buffer offsets
     const bool narrow_n = g_tune_halo_narrow && Cout <= 64;          // 64-column tiles for the head's 28 / 32-column layers
     const int brick = halo_brick_shape(p.gx, p.gy, p.gz);
     if (brick == 0)
-      rc = narrow_n ? launch_halo<4, 4, 16, false, 64>(p, OV, st) : ring ? launch_halo<4, 4, 16, true>(p, OV, st) : launch_halo<4, 4, 16, false>(p, OV, st);
+      rc = narrow_n ? launch_halo<4, 4, 16, 64>(p, OV, st) : launch_halo<4, 4, 16>(p, OV, st);
     else if (brick == 1)
-      rc = narrow_n ? launch_halo<4, 8, 8, false, 64>(p, OV, st) : ring ? launch_halo<4, 8, 8, true>(p, OV, st) : launch_halo<4, 8, 8, false>(p, OV, st);
+      rc = narrow_n ? launch_halo<4, 8, 8, 64>(p, OV, st) : launch_halo<4, 8, 8>(p, OV, st);
     else
-      rc = narrow_n ? launch_halo<8, 8, 4, false, 64>(p, OV, st) : ring ? launch_halo<8, 8, 4, true>(p, OV, st) : launch_halo<8, 8, 4, false>(p, OV, st);
+      rc = narrow_n ? launch_halo<8, 8, 4, 64>(p, OV, st) : launch_halo<8, 8, 4>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
@@ -1802,10 +1527,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   if (g_tune_conv_halo && g_tune_halo_2d && p.two_d && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout &&
       p.M >= g_tune_halo_min_m && p.gy >= 8 && p.gz >= 8) {
     const bool narrow_n = g_tune_halo_narrow && Cout <= 64;
-    if (g_conv_products == 1)
-      rc = narrow_n ? launch_halo_np<1, 16, 16, false, 64, 1, 2, true>(p, OV, st) : launch_halo_np<1, 16, 16, false, 128, 1, 2, true>(p, OV, st);
-    else
-      rc = narrow_n ? launch_halo_np<1, 16, 16, false, 64, 3, 2, true>(p, OV, st) : launch_halo_np<1, 16, 16, false, 128, 3, 2, true>(p, OV, st);
+    rc = narrow_n ? launch_halo<1, 16, 16, 64, true>(p, OV, st) : launch_halo<1, 16, 16, 128, true>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }

@@ -410,8 +410,7 @@ extern int g_tune_conv_waves;   // conv3d.hip: 4 or 8 waves per 128x128 tile
 extern int g_tune_halo_min_cout;
 extern int g_tune_halo_min_m;
 extern int g_tune_halo_brick;
-extern int g_tune_halo_ring;
-extern int g_tune_halo_nb;
+extern int g_tune_halo_stagger;
 extern int g_tune_view_group;
 extern int g_tune_halo_narrow;
 extern int g_tune_split_target;
@@ -596,8 +595,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "halo_min_cout")) { g_tune_halo_min_cout = value; return SGC_OK; }
   if (!strcmp(key, "halo_min_m")) { g_tune_halo_min_m = value; return SGC_OK; }
   if (!strcmp(key, "halo_brick")) { g_tune_halo_brick = value; return SGC_OK; }
-  if (!strcmp(key, "halo_ring")) { g_tune_halo_ring = value; return SGC_OK; }
-  if (!strcmp(key, "halo_nb")) { g_tune_halo_nb = value; return SGC_OK; }
+  if (!strcmp(key, "halo_stagger")) { g_tune_halo_stagger = value; return SGC_OK; }
   if (!strcmp(key, "view_group")) { g_tune_view_group = value; return SGC_OK; }
   if (!strcmp(key, "halo_narrow")) { g_tune_halo_narrow = value; return SGC_OK; }
   if (!strcmp(key, "split_target")) { g_tune_split_target = value; return SGC_OK; }

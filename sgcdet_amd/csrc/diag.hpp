@@ -1,0 +1,30 @@
+// Diagnostic switches of the library, in ONE place so that the product loops read clean.  Nothing here is compiled into the
+// shipped library: the macros expand to nothing unless a diagnostic build defines them (tools/diag_build.sh <name> <file>
+// -D<MACRO> builds a side library under tools/diag/ that the A/B tools load through SGC_DIAG_LIB).
+//
+//   SGC_HALO_STAMPS   shader-clock (s_memtime) and real-time (s_memrealtime) stamps around the tap loop of every workgroup of
+//                     the halo convolution -> the clock the chip holds while the kernel runs (MI355X_MICROARCH.md, DVFS
+//                     give-back item 6; tools/halo_clock.py).  The stamps go to a buffer of their own
+//                     (sgc_diag_halo_stamp_buffer); no output value depends on them.
+//   SGC_HALO_SKIP     bit mask, lockstep form of the halo convolution (halo_stagger 0), TIMING ONLY (results are garbage): 1 no
+//                     barrier per tap, 2 no weight ds_write, 4 no weight global load, 8 weight fragments read from LDS once
+//                     instead of every tap, 16 halo fragments read once -- what each part of the tap loop costs (tools/halo_skip.py)
+#pragma once
+
+#if !defined(SGC_HALO_SKIP)
+#define SGC_HALO_SKIP 0
+#endif
+
+#if defined(SGC_HALO_STAMPS)
+namespace sgc { inline unsigned long long *g_halo_stamp_buf = nullptr; }
+#define SGC_HALO_STAMP(slot)                                                                                     \
+  do {                                                                                                           \
+    if (p.stamps && threadIdx.x == 0) {                                                                          \
+      unsigned long long *s_ = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4);                   \
+      s_[slot] = __builtin_readcyclecounter();                                                                   \
+      s_[(slot) + 1] = __builtin_amdgcn_s_memrealtime();                                                         \
+    }                                                                                                            \
+  } while (0)
+#else
+#define SGC_HALO_STAMP(slot) do {} while (0)
+#endif

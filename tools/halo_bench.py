@@ -1,5 +1,5 @@
-"""3x3x3 stride-1 layers on the halo kernel: staged weights (halo_ring 0) vs weights straight from L2 into registers
-(halo_ring 1): time, TF-equivalent, and bit-identity of the two."""
+"""3x3x3 stride-1 layers on the halo kernel: lockstep (halo_stagger 0) vs staggered waves (1): time, TF-equivalent, and
+bit-identity of the two (SGC_HALO_VARIANTS="1" times the default only; tools/halo_knob_ab.py alternates the values)."""
 import os
 import sys
 import time
@@ -29,7 +29,7 @@ for name, Cin, Cout, g in layers:
     wh, wl = ops.split_bf16(wt)
     res = {}
     for bd in variants:
-        ops.lib.call("sgc_set_tuning", b"halo_ring", bd)
+        ops.lib.call("sgc_set_tuning", b"halo_stagger", bd)
         f = lambda: ops.conv3d_cl_bf16x3(x, wh, wl, g, 3, 1, False, sc, sh, None, True)
         for _ in range(3):
             y, og = f()

@@ -18,12 +18,12 @@ for name, Cin, Cout, g in [("256->256 @40x40x16", 256, 256, (40, 40, 16)), ("256
     ref = None
     for rnd in range(5):
         line = []
-        for b, nb in ((3, 2), (1, 2), (2, 2), (2, 3)):
+        for b, nb in ((3, 1), (1, 1), (2, 1), (2, 0)):
             ops.lib.call("sgc_set_tuning", b"halo_brick", b)
-            ops.lib.call("sgc_set_tuning", b"halo_nb", nb)
+            ops.lib.call("sgc_set_tuning", b"halo_stagger", nb)
             y, _ = f()
             if ref is None: ref = y.clone()
-            line.append(f"brick{b}/nb{nb} {timed(f):6.1f} us same={bool(torch.equal(y, ref))}")
+            line.append(f"brick{b}/stagger{nb} {timed(f):6.1f} us same={bool(torch.equal(y, ref))}")
         print(name, "round", rnd, " | ".join(line), flush=True)
 ops.lib.call("sgc_set_tuning", b"halo_brick", 0)
-ops.lib.call("sgc_set_tuning", b"halo_nb", 2)
+ops.lib.call("sgc_set_tuning", b"halo_stagger", 1)
