@@ -244,7 +244,6 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   constexpr int NCH = CM / 16;          // 16-byte chunks of a row per lane in phase 2 (a unit's 4 lanes cover the row)
   constexpr int CV = CM / 4;            // 16-byte chunks per row
   constexpr int UPW = 64 / P;           // units per wave step (16)
-  constexpr int R16 = CM / 4;           // a value row in 4-channel chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ngrp = p.M / p.HG;
@@ -279,8 +278,12 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   unsigned char *val0 = tile_smem;
   float *dep = reinterpret_cast<float *>(tile_smem + ((NBUF * buf_bytes + 15) & ~15));   // [dh][dw][D]
   const float *dcam = p.dist + (int64_t)n * p.S * p.D;
-  const int xd0 = max(0, min(bx * p.bw - p.hx - p.smx, p.W - p.dw));
-  const int yd0 = max(0, min(by * p.bh - p.hy - p.smy, p.H - p.dh));
+  int xd0 = max(0, min(bx * p.bw - p.hx - p.smx, p.W - p.dw));
+  int yd0 = max(0, min(by * p.bh - p.hy - p.smy, p.H - p.dh));
+  if (p.HG == 1 && p.dw == p.tw && p.dh == p.th) {   // one head per workgroup: the depth window is the head's own value window
+    xd0 = max(0, min(bx * p.bw - p.hx + sx_first, p.W - p.tw));
+    yd0 = max(0, min(by * p.bh - p.hy + sy_first, p.H - p.th));
+  }
 
   auto window_origin = [&](int m, int &x0, int &y0) {
     int sx = sx_first, sy = sy_first;
@@ -357,8 +360,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       }
 
       const float h_im = sample_coord(y, fH), w_im = sample_coord(x, fW), d_im = sample_coord(z, fD);
-      const bool in2 = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
-      const bool in3 = in2 && d_im > -1.f && d_im < fD;
+      // bitwise & on purpose: with && the compiler evaluates the later comparisons under an exec mask (an s_and_saveexec /
+      // s_or pair per chain -- 13 of them per step); every operand here is cheap and side-effect free
+      const bool in2 = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
+      const bool in3 = in2 & (d_im > -1.f) & (d_im < fD);
       const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);
       // (int) of a huge float is undefined: clamp the floats first (in2 / in3 already hold the decision)
       const int h0 = (int)fminf(fmaxf(hf, -2.f), fH), w0 = (int)fminf(fmaxf(wf, -2.f), fW);
@@ -375,18 +380,20 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
 #pragma unroll
       for (int k = 0; k < 4; ++k) {               // corner order (h0,w0) (h0,w1) (h1,w0) (h1,w1)
         const int hk = h0 + (k >> 1), wk = w0 + (k & 1);
-        ok[k] = in2 && hk >= 0 && hk <= p.H - 1 && wk >= 0 && wk <= p.W - 1;
+        ok[k] = in2 & (hk >= 0) & (hk <= p.H - 1) & (wk >= 0) & (wk <= p.W - 1);
         const int ch = min(max(hk, 0), p.H - 1), cw = min(max(wk, 0), p.W - 1);
         pix[k] = __mul24(ch, p.W) + cw;
         const int tx = cw - x0, ty = ch - y0;
-        inside[k] = (unsigned)tx < (unsigned)p.tw && (unsigned)ty < (unsigned)p.th;
-        trow[k] = inside[k] ? __mul24(ty, p.tw) + tx : npx;
+        inside[k] = ((unsigned)tx < (unsigned)p.tw) & ((unsigned)ty < (unsigned)p.th);
+        const int trow_in = __mul24(ty, p.tw) + tx;
+        trow[k] = inside[k] ? trow_in : npx;
         if (DL) {
           const int dx = cw - xd0, dy = ch - yd0;
-          const bool din = (unsigned)dx < (unsigned)p.dw && (unsigned)dy < (unsigned)p.dh;
-          const float *dp = dep + (__mul24(din ? __mul24(dy, p.dw) + dx : 0, p.D) + dbase);
+          const bool din = ((unsigned)dx < (unsigned)p.dw) & ((unsigned)dy < (unsigned)p.dh);
+          const int drow = __mul24(dy, p.dw) + dx;
+          const float *dp = dep + (__mul24(din ? drow : 0, p.D) + dbase);
           ta[k] = dp[0]; tb[k] = dp[1];
-          need_g |= in3 && ok[k] && !din;
+          need_g |= in3 & ok[k] & !din;
         } else {
           const float2_u pr = *reinterpret_cast<const float2_u *>(dcam + (unsigned)(__mul24(pix[k], p.D) + dbase));
           ta[k] = pr.x; tb[k] = pr.y;
@@ -405,21 +412,20 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
         }
       }
       float wgt[4];
-      unsigned r16[4], fbs[4];
+      unsigned rowb[4], fbs[4];                      // byte offset of the corner's row in the staged window
       bool any_fb = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float va = d0ok ? (dlo ? ta[k] : tb[k]) : 0.f;
         const float vb = d1ok ? (dlo ? tb[k] : ta[k]) : 0.f;
-        const float sc = (in3 && ok[k]) ? va * hd + vb * ld : 0.f;
+        const float sc = (in3 & ok[k]) ? va * hd + vb * ld : 0.f;
         const float bil = (k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw);
         wgt[k] = in2 ? bil * sc * aw : 0.f;
-        const bool fb = ok[k] && !inside[k];
-        r16[k] = (unsigned)(ok[k] ? trow[k] : npx) * (unsigned)R16;        // outside the map / outside the window -> zero row
+        const bool fb = ok[k] & !inside[k];
+        rowb[k] = (unsigned)__mul24(ok[k] ? trow[k] : npx, CM * VB);       // outside the map / outside the window -> zero row
         fbs[k] = fb ? (kFallbackBit | (unsigned)pix[k]) : 0u;
         any_fb |= fb;
       }
-      const unsigned s01 = r16[0] | (r16[1] << 16), s23 = r16[2] | (r16[3] << 16);
       const unsigned long long fbm = __ballot(any_fb);
 
       // ---------------- phase 2: the unit's own quad; lane c owns channels 4c .. 4c+3 (+16 j for Cm = 32) ----------------
@@ -431,14 +437,22 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
         float4 acc[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto sample = [&](const float w0, const float w1, const float w2, const float w3, const unsigned q01, const unsigned q23) {
+        // every broadcast has ONE consumer (the address add, or -- per corner weight -- the four multiply-adds of its chunk), so
+        // the row offsets travel as four plain byte offsets rather than two packed pairs: no unpacking, and the compiler can fold
+        // the quad broadcast into the add (v_add_u32_dpp)
+        // The row offsets travel as four plain byte offsets, each with ONE consumer (the address add), so the compiler folds the quad
+        // broadcast into it (v_add_u32_dpp) and nothing is unpacked.  (The weights keep their v_mov_b32_dpp broadcasts: reading them
+        // through the DPP operand of every multiply-add instead -- inline-asm v_fmac_f32_dpp, 16 instructions per step less -- changed
+        // nothing measurable: 0.379 vs 0.374 / 0.383 vs 0.391 / 0.446 vs 0.457 of 8 TB/s at configs 4 / 5 / 2.)
+        auto sample = [&](const float w0, const float w1, const float w2, const float w3, const unsigned b0, const unsigned b1,
+                          const unsigned b2, const unsigned b3) {
           const float w[4] = {w0, w1, w2, w3};
-          const unsigned r[4] = {q01 & 0xffffu, q01 >> 16, q23 & 0xffffu, q23 >> 16};
+          const unsigned r[4] = {b0, b1, b2, b3};
           float4 v[4][NCH];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) v[k][j] = load_chunk<VB>(vrow + (r[k] + 4 * j) * CHB);
+            for (int j = 0; j < NCH; ++j) v[k][j] = load_chunk<VB>(vrow + r[k] + 4 * j * CHB);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -447,10 +461,14 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
               acc[j].z += w[k] * v[k][j].z; acc[j].w += w[k] * v[k][j].w;
             }
         };
-        sample(quad_bcast<0>(wgt[0]), quad_bcast<0>(wgt[1]), quad_bcast<0>(wgt[2]), quad_bcast<0>(wgt[3]), quad_bcast_u<0>(s01), quad_bcast_u<0>(s23));
-        sample(quad_bcast<1>(wgt[0]), quad_bcast<1>(wgt[1]), quad_bcast<1>(wgt[2]), quad_bcast<1>(wgt[3]), quad_bcast_u<1>(s01), quad_bcast_u<1>(s23));
-        sample(quad_bcast<2>(wgt[0]), quad_bcast<2>(wgt[1]), quad_bcast<2>(wgt[2]), quad_bcast<2>(wgt[3]), quad_bcast_u<2>(s01), quad_bcast_u<2>(s23));
-        sample(quad_bcast<3>(wgt[0]), quad_bcast<3>(wgt[1]), quad_bcast<3>(wgt[2]), quad_bcast<3>(wgt[3]), quad_bcast_u<3>(s01), quad_bcast_u<3>(s23));
+        sample(quad_bcast<0>(wgt[0]), quad_bcast<0>(wgt[1]), quad_bcast<0>(wgt[2]), quad_bcast<0>(wgt[3]),
+               quad_bcast_u<0>(rowb[0]), quad_bcast_u<0>(rowb[1]), quad_bcast_u<0>(rowb[2]), quad_bcast_u<0>(rowb[3]));
+        sample(quad_bcast<1>(wgt[0]), quad_bcast<1>(wgt[1]), quad_bcast<1>(wgt[2]), quad_bcast<1>(wgt[3]),
+               quad_bcast_u<1>(rowb[0]), quad_bcast_u<1>(rowb[1]), quad_bcast_u<1>(rowb[2]), quad_bcast_u<1>(rowb[3]));
+        sample(quad_bcast<2>(wgt[0]), quad_bcast<2>(wgt[1]), quad_bcast<2>(wgt[2]), quad_bcast<2>(wgt[3]),
+               quad_bcast_u<2>(rowb[0]), quad_bcast_u<2>(rowb[1]), quad_bcast_u<2>(rowb[2]), quad_bcast_u<2>(rowb[3]));
+        sample(quad_bcast<3>(wgt[0]), quad_bcast<3>(wgt[1]), quad_bcast<3>(wgt[2]), quad_bcast<3>(wgt[3]),
+               quad_bcast_u<3>(rowb[0]), quad_bcast_u<3>(rowb[1]), quad_bcast_u<3>(rowb[2]), quad_bcast_u<3>(rowb[3]));
         if (fbm) {            // rare, wave-uniform: some corner of some unit lies outside the staged window
           const int src = lane & ~(P - 1);
 #pragma unroll
@@ -558,8 +576,11 @@ static TileGeom tile_geometry(int H, int W, int Cm, int D, int bin_w, int bin_h,
   g.tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W;
   g.th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
   g.smx = smx; g.smy = smy;
-  g.dw = bin_w + 2 * (halo_x + smx) < W ? bin_w + 2 * (halo_x + smx) : W;
-  g.dh = bin_h + 2 * (halo_y + smy) < H ? bin_h + 2 * (halo_y + smy) : H;
+  // depth window: with one head per workgroup it is that head's own (shifted) value window; a workgroup that walks several
+  // heads stages the union of their windows once
+  const bool one_head = !(g_tune_tile_hg > 1);
+  g.dw = one_head ? g.tw : (bin_w + 2 * (halo_x + smx) < W ? bin_w + 2 * (halo_x + smx) : W);
+  g.dh = one_head ? g.th : (bin_h + 2 * (halo_y + smy) < H ? bin_h + 2 * (halo_y + smy) : H);
   g.dl = (g_tune_tile_depth_lds >= 0 ? g_tune_tile_depth_lds : depth_in_lds) != 0 && D % 4 == 0 && D >= 2;
   const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * vb, dbuf = (size_t)g.dw * g.dh * D * 4;
   g.nbuf = g_tune_tile_nbuf == 2 ? 2 : 1;

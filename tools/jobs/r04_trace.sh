@@ -1,0 +1,32 @@
+#!/bin/bash
+# kernel-trace of the default bench command: per-kernel shares (gpurun_out/r04_kernels_from_trace.json, r04_bench_cfg2_kernel_stats.csv)
+mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+TAG=${1:-r04}
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$TAG
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-strict-fp32 --sustain 0 > $R/gpurun_out/${TAG}_bench_cfg2_under_rocprof.json 2> /dev/null; echo rocprof rc $?
+f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
+t=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1)
+if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_bench_cfg2_kernel_stats.csv; fi
+if [ -n "$t" ]; then
+python3 - "$t" > $R/gpurun_out/${TAG}_kernels_from_trace.json <<'PY'
+import csv, json, sys
+csv.field_size_limit(1 << 30)
+rows = list(csv.DictReader(open(sys.argv[1])))
+out = {}
+tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+import re, collections
+by = collections.defaultdict(list)
+for r in rows:
+    by[re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for key, d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+    if sum(d) * 1e3 / tot >= 0.004:
+        d.sort()
+        out[key] = dict(launches=len(d), avg_us=round(sum(d) / len(d), 2), median_us=round(d[len(d) // 2], 2), max_us=round(d[-1], 2),
+                        share_of_gpu_time=round(sum(d) * 1e3 / tot, 4))
+out["_all"] = dict(launches=len(rows), total_ms=round(tot / 1e6, 2))
+print(json.dumps(out, indent=1))
+PY
+fi
+cat $R/gpurun_out/${TAG}_kernels_from_trace.json

@@ -23,6 +23,10 @@ if which == "cfg2":
 else:
     N, C, grid, vox, topk = 50, 128, (80, 80, 32), (.08, .08, .1), 51200
 ops = ext.ops()
+if os.environ.get("SGC_DIAG_LIB"):      # another build of the library (A/B of two builds on one box)
+    from sgcdet_amd._abi import Library
+    from sgcdet_amd.tensor_api import TensorOps
+    ops = TensorOps(Library(os.environ["SGC_DIAG_LIB"]), "cuda")
 dev = "cuda"
 meta = make_img_meta(N, "scannet", 0)
 proj = compute_projection(meta).float().to(dev).contiguous()
