@@ -54,11 +54,11 @@ def parse():
                     help="HxW of the resized input images.  Default: 256x320 for cfg2_scannet (the size BASELINE.json's "
                          "north star quotes); `config` = the reference config's own 239x320 (ScanNet) / 240x320 (ARKit), "
                          "which is also the default of the other workloads")
-    ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32", "bf16"],
+    ap.add_argument("--conv-mode", default="bf16x3", choices=["bf16x3", "f32", "bf16", "fp16"],
                     help="convolution / Linear arithmetic: 3-way bf16 split on the bf16 MFMA (fp32-faithful to ~1e-5, "
                          "default, the headline), exact fp32 products on the fp32 MFMA, or -- opt-in reduced precision of "
-                         "BASELINE.json configs #2 / #5, its own line, never the headline -- plain bf16 products (operands "
-                         "rounded to bfloat16, fp32 accumulate: 1/3 of the matrix work)")
+                         "BASELINE.json configs #2 / #5, their own lines, never the headline -- plain bf16 or fp16 products "
+                         "(operands rounded to bfloat16 / IEEE half, fp32 accumulate: 1/3 of the matrix work)")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU: consecutive steps alternate over this many HIP streams so the host "
                          "syncs / launch gaps of one scene overlap the kernels of the other")
@@ -338,13 +338,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     lib_calls_per_scene = None
-    eager_events = not det.scene_graph      # kernels inside a replayed scene graph cannot carry host-side events
-    if eager_events:
-        ops.event_log = []
-        # the neck / head convolutions live in the tail hipGraph when there is one (a capture cannot carry host-side events)
-        gather_names = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled"}
-        ops.event_names = (gather_names if det.use_graph else None if args.breakdown
-                           else gather_names | {"sgc_conv3d_cl_bf16x3", "sgc_conv3d_cl_f32"})
+    # Kernel times for the `roofline` objects never come from the timed region: inside a replayed graph a kernel cannot carry
+    # host-side events, and with several scenes in flight an event bracket on one stream also holds the time the kernel waits
+    # for CUs the other scenes occupy (round 3's strict-fp32 line read 855 us for a 92-us gather that way).  They are taken in a
+    # separate eager pass, one scene at a time, right after the timed region.
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -372,27 +369,25 @@ def main():
         el_s = sgc_dist.max_over_ranks(time.perf_counter() - ts, device=device)
         sustained = dict(value=round(world * n_sus / el_s, 3), unit="scenes/sec", steps=n_sus, seconds=round(el_s, 2),
                          ms_per_step=round(el_s / n_sus * 1e3, 3))
-    roofline_pass = "HIP events on the launch stream over the timed region"
-    if not eager_events:
-        # same scenes, same streams, same kernels launched eagerly right after the timed region: the deformable
-        # gather is bracketed by HIP events on its launch stream (its pair count comes back to the host here)
-        det.scene_graph = False
-        tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
-        ops.event_log = []
-        ops.event_names = None if args.breakdown else PATH_KERNELS
-        calls0 = ops.n_calls
-        with torch.no_grad():
-            for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
-                feats, dpt, metas = scenes[i % n_scenes]
-                det.forward_features(feats, metas, dpt)
-                torch.cuda.synchronize()
-        log, ops.event_log = ops.event_log, None
-        lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
-        det.scene_graph, det.use_graph = True, tail_graph
-        roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
-                         "after the timed region (the timed region replays one hipGraph per scene, which cannot carry "
-                         "events; inside it the kernel shares the chip with the other scenes in flight and runs 0-3 % longer, see "
-                         "profiles/r02_kernels_from_trace.json)")
+    # same scenes, same kernels launched eagerly right after the timed region, one scene at a time: the deformable
+    # gather is bracketed by HIP events on its launch stream (its pair count comes back to the host here)
+    scene_graph_was, det.scene_graph = det.scene_graph, False
+    tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
+    ops.event_log = []
+    ops.event_names = None if args.breakdown else PATH_KERNELS
+    calls0 = ops.n_calls
+    with torch.no_grad():
+        for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
+            feats, dpt, metas = scenes[i % n_scenes]
+            det.forward_features(feats, metas, dpt)
+            torch.cuda.synchronize()
+    log, ops.event_log = ops.event_log, None
+    lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
+    det.scene_graph, det.use_graph = scene_graph_was, tail_graph
+    roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
+                     "after the timed region (the timed region replays hipGraphs, which cannot carry events, with several "
+                     "scenes in flight; inside it the kernel shares the chip with the other scenes and runs 0-3 % longer, see "
+                     "profiles/r02_kernels_from_trace.json)")
 
     # ---- self check (untimed): the scenes-in-flight configuration reproduces the serial, graph-free results ----
     self_check = None
@@ -468,10 +463,6 @@ def main():
                                 "sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8> (finest level)"),
                         measured=roofline_pass,
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
-        if args.conv_mode == "f32" and args.streams > 1:
-            roofline["note"] = ("HIP events over-read this kernel in strict-fp32 mode with more than one stream (the bracket also holds "
-                                "the fp32 Linear in front of it): the kernel trace of this command shows 90 - 96 us per launch "
-                                "(profiles/r03_f32_gather_trace.txt), `--streams 1` reads 94 us = 0.44 with events too")
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
     roofline_mfma = None
     cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode != "f32" else "sgc_conv3d_cl_f32", [])
@@ -495,12 +486,12 @@ def main():
                              avg_launch_us=round(t_c * 1e6, 1), launches=len(big_c),
                              note=("achieved = MFMA work actually issued (three bf16 products per fp32 multiply-add: lo*hi + "
                                    "hi*lo + hi*hi); fp32_equivalent_tflops = algorithmic FLOPs of the fp32 convolution / time")
-                             if nprod == 3 else "one bf16 product per multiply-add (opt-in bf16 mode)" if bf
+                             if nprod == 3 else f"one {'fp16' if args.conv_mode == 'fp16' else 'bf16'} product per multiply-add (opt-in mode)" if bf
                              else "exact fp32 products on v_mfma_f32_32x32x2_f32")
     # ---- the whole path against its own roofline (north star: "as a fraction of the HBM roofline"): compulsory gather bytes at
     #      8 TB/s + the matrix work actually issued at the dense MFMA peak, per scene, over the measured time per scene ----
     path_roofline = None
-    if not eager_events and per_kernel:
+    if per_kernel:
         n_e = max(6, min(args.steps, 20))
         gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"])
                    for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
@@ -533,7 +524,7 @@ def main():
                     a = shapes.setdefault(key, [0, 0.0])
                     a[0] += 1
                     a[1] += t
-            n_eager = max(6, min(args.steps, 20)) if not eager_events else args.steps
+            n_eager = max(6, min(args.steps, 20))
             for key, (cnt, tt) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                 V, Cin, Cout, taps, OV = key
                 gf = 2.0 * (taps or 1) * Cin * Cout * (OV or V) / 1e9
@@ -580,6 +571,10 @@ def main():
             "dtype": ("bf16 (opt-in reduced precision: every convolution / Linear with operands rounded to bfloat16, one MFMA product, "
                       "fp32 accumulate" + ("; value map of the gather stored in bfloat16" if args.storage == "bf16" else "") +
                       "; NOT parity-exact, not the headline)" if args.conv_mode == "bf16" else
+                      "fp16 (opt-in reduced precision: every convolution / Linear with operands rounded to IEEE half -- saturated at "
+                      "+-65504 --, one v_mfma_f32_32x32x16_f16 product, fp32 accumulate"
+                      + ("; value map of the gather stored in bfloat16" if args.storage == "bf16" else "") +
+                      "; NOT parity-exact, not the headline)" if args.conv_mode == "fp16" else
                       "bf16 storage (value map of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
                       if args.storage == "bf16" else
                       "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)"),

@@ -51,7 +51,7 @@ extern "C" {
 /* Bumped whenever the argument list of an EXISTING entry point changes (a stale prebuilt .so is then rejected at load
  * instead of being called with shifted arguments).  1 -> 2: sgc_project_points gained `sel`, sgc_nchw_to_nhwc_crop gained
  * `step` (round 2).  New entry points do not bump it: a missing symbol already fails the load. */
-#define SGC_ABI_VERSION 2
+#define SGC_ABI_VERSION 3
 
 typedef void *sgc_stream_t; /* hipStream_t */
 
@@ -66,10 +66,14 @@ int sgc_set_tuning(const char *key, int value);
  *   3 (default) = fp32-faithful: operands split a = a_hi + a_lo in bf16, products a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32
  *       accumulate -- agrees with exact fp32 products to ~1e-5 of the tensor scale (the parity mode, the headline);
  *   1 = plain bf16: a_hi*b_hi only, i.e. both operands ROUNDED to bfloat16 (RNE), fp32 accumulate -- the opt-in
- *       reduced-precision mode of BASELINE.json configs #2 ("bf16") / #5 ("fp16"; the reference's fp16 twin of the operator:
- *       TU/multi_scale_3ddeformable_attn_function.py:353-428); 1/3 of the matrix work, ~2^-8 relative per operand.
+ *       reduced-precision mode of BASELINE.json config #2 ("bf16"); 1/3 of the matrix work, ~2^-8 relative per operand;
+ *   2 = plain fp16 (ABI version 3): ONE product on v_mfma_f32_32x32x16_f16 -- activations rounded to IEEE half (RNE) and
+ *       SATURATED at +-65504 (a NaN stays a NaN), fp32 accumulate; the w_hi planes then hold IEEE-half bit patterns of the
+ *       weights (TensorOps.split_f16), not bfloat16.  BASELINE.json config #5 ("fp16"; the reference's fp16 twin of the
+ *       operator: TU/multi_scale_3ddeformable_attn_function.py:353-428); the rate of mode 1, ~2^-11 relative per operand.
  * It changes results (that is its purpose) and is therefore NOT a sgc_set_tuning key.  Process-wide; returns SGC_EINVAL for
- * any other value.  The w_lo arguments are ignored in mode 1. */
+ * any other value.  The w_lo arguments are ignored in modes 1 and 2.  The training entry points (weight / input gradients)
+ * always compute in mode 3. */
 int sgc_set_conv_products(int products);
 int sgc_get_conv_products(void);
 const char *sgc_last_error(void);

@@ -67,11 +67,11 @@ static int fail(int code, const char *msg) {
 
 int sgc_abi_version(void) { return SGC_ABI_VERSION; }
 
-/* arithmetic mode of the bf16 MFMA entry points (include/sgcdet_amd.h): 3 = fp32 truth of the 3-way split, 1 = both
- * operands rounded to bfloat16 (RNE), products and sums in fp32 */
+/* arithmetic mode of the MFMA entry points (include/sgcdet_amd.h): 3 = fp32 truth of the 3-way split, 1 = both operands
+ * rounded to bfloat16 (RNE), 2 = both operands rounded to IEEE half (RNE, saturated at +-65504); products and sums in fp32 */
 static int g_conv_products = 3;
 int sgc_set_conv_products(int products) {
-  if (products != 1 && products != 3) return fail(SGC_EINVAL, "1 (bf16) or 3 (bf16x3)");
+  if (products != 1 && products != 2 && products != 3) return fail(SGC_EINVAL, "3 (bf16x3), 1 (bf16) or 2 (fp16)");
   g_conv_products = products;
   return SGC_OK;
 }
@@ -954,6 +954,38 @@ int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, i
 
 static uint16_t f32_to_bf16_rne(float f);
 
+/* IEEE binary16 <-> binary32 in integer arithmetic (gcc 11 has no _Float16 on x86-64): round to nearest even, values
+ * beyond the half range SATURATE at +-65504 (csrc/mma.hpp op_hi), NaN stays NaN, subnormal halves are kept */
+static uint16_t f32_to_f16_sat(float f) {
+  union { float f; uint32_t u; } c; c.f = f;
+  const uint32_t sign = (c.u >> 16) & 0x8000u, a = c.u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                    /* NaN */
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);                   /* >= 65520 rounds past the largest half: saturate */
+  if (a < 0x33000001u) return (uint16_t)sign;                                /* < 2^-25 (ties to even at 2^-25): zero */
+  const int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                                  /* 24-bit significand */
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                                /* bits dropped; subnormal halves drop more */
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  uint32_t h = e >= -14 ? ((uint32_t)(e + 15) << 10) + (q - 0x400u) : q;     /* a carry out of the significand bumps the exponent */
+  return (uint16_t)(sign | h);
+}
+static float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  union { float f; uint32_t u; } c;
+  if (e == 0) { c.f = (float)m * 5.9604644775390625e-8f; c.u |= sign; return c.f; }   /* subnormal: m * 2^-24 */
+  if (e == 31) { c.u = sign | 0x7f800000u | (m << 13); return c.f; }
+  c.u = sign | ((e + 112u) << 23) | (m << 13);
+  return c.f;
+}
+/* an activation / a weight as the mode's MFMA sees it */
+static float mode_x(float x) {
+  return g_conv_products == 1 ? bf16_to_f32(f32_to_bf16_rne(x)) : g_conv_products == 2 ? f16_to_f32(f32_to_f16_sat(x)) : x;
+}
+static float mode_w(uint16_t hi, uint16_t lo) {
+  return g_conv_products == 3 ? bf16_to_f32(hi) + bf16_to_f32(lo) : g_conv_products == 1 ? bf16_to_f32(hi) : f16_to_f32(hi);
+}
+
 int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
@@ -965,13 +997,13 @@ int sgc_conv3d_cl_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const size_t n = (size_t)taps * Cout * Cin;
   float *w = (float *)malloc(n * sizeof(float));
   if (!w) return fail(SGC_EINVAL, "out of memory");
-  for (size_t i = 0; i < n; ++i) w[i] = bf16_to_f32(w_hi[i]) + (g_conv_products == 3 ? bf16_to_f32(w_lo[i]) : 0.f);
+  for (size_t i = 0; i < n; ++i) w[i] = mode_w(w_hi[i], w_lo[i]);
   float *xr = NULL;
-  if (g_conv_products == 1) {                     /* plain bf16 mode: the activations are rounded to bfloat16 as well */
+  if (g_conv_products != 3) {                     /* one-product modes: the activations are rounded to the operand format as well */
     const size_t nx = (size_t)ix * iy * iz * Cin;
     xr = (float *)malloc(nx * sizeof(float));
     if (!xr) { free(w); return fail(SGC_EINVAL, "out of memory"); }
-    for (size_t i = 0; i < nx; ++i) xr[i] = bf16_to_f32(f32_to_bf16_rne(x[i]));
+    for (size_t i = 0; i < nx; ++i) xr[i] = mode_x(x[i]);
   }
   const int rc = sgc_conv3d_cl_f32(xr ? xr : x, w, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, ksize, stride,
                                    transposed, relu, NULL, 0, stream);
@@ -1001,8 +1033,7 @@ int sgc_conv2d_nhwc_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
               const float *xi = x + (((int64_t)n * H + hh) * W + ww) * Cin;
               const int64_t wo = ((int64_t)(ky * ksize + kx) * Cout + co) * Cin;
               for (int ci = 0; ci < Cin; ++ci)
-                acc += (g_conv_products == 1 ? bf16_to_f32(f32_to_bf16_rne(xi[ci])) : xi[ci]) *
-                       (bf16_to_f32(w_hi[wo + ci]) + (g_conv_products == 3 ? bf16_to_f32(w_lo[wo + ci]) : 0.f));
+                acc += mode_x(xi[ci]) * mode_w(w_hi[wo + ci], w_lo[wo + ci]);
             }
           float v = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
           if (relu == 2 && v < 0.f) v = 0.f;

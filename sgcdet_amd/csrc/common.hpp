@@ -135,11 +135,7 @@ __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict_
       float va, vb;
       if (D >= 2) {
         const int base = d0 < 0 ? 0 : (d0 > D - 2 ? D - 2 : d0);
-#if defined(SGC_DIAG_NO_DEPTH_LOADS)
-        float2_u pr; pr.x = 0.3f + (float)base; pr.y = 0.2f; (void)p;
-#else
         const float2_u pr = *reinterpret_cast<const float2_u *>(p + base);
-#endif
         va = d0 < 0 ? 0.f : (d0 == base ? pr.x : pr.y);
         vb = d1 > D - 1 ? 0.f : (d0 == base ? pr.y : pr.x);
       } else {

@@ -27,24 +27,15 @@
 //               block), mode 2: relu(y) + residual (decoder skip add); scale/shift carry the
 //               folded eval-mode BatchNorm (or the conv bias).
 #include "common.hpp"
+#include "mma.hpp"
 #include "diag.hpp"
 
 namespace sgc {
-int g_conv_products = 3;     // NOT a tuning knob (it changes results; sgc_set_conv_products): 3 = fp32-faithful 3-way bf16 split
-                             // (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), 1 = plain bf16 (a_hi*b_hi only: operands rounded to bf16,
-                             // fp32 accumulate) -- the opt-in reduced-precision mode of BASELINE.json configs #2 / #5
-int g_tune_igemm_tall = 0;   // 1: 256 x 128 workgroup tiles (wave tile 64 x 64, one workgroup per CU) for the strided / transposed /
-                             // small-scale 3x3x3 layers.  Bit-identical; measured 3 - 50 % SLOWER than two resident 128 x 128
-                             // workgroups on every such layer (tools/igemm_tall_ab.py), kept as an option
+int g_conv_products = 3;     // NOT a tuning knob (it changes results; sgc_set_conv_products): the NP of csrc/mma.hpp -- 3 = fp32-faithful
+                             // 3-way bf16 split (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi), 1 = plain bf16 (a_hi*b_hi only: operands rounded
+                             // to bf16, fp32 accumulate), 2 = plain fp16 (operands rounded to IEEE half): the opt-in reduced-precision
+                             // modes of BASELINE.json configs #2 / #5
 int g_tune_igemm_xcd = 0;    // tile implicit GEMM, XCD deal of the split / transposed layers (ConvParams.xcd_deal)
-int g_tune_conv_big = 0;     // 1: the 512 x 128 big-tile implicit GEMM (conv3d_igemm_big_kernel) for the strided / transposed / small-scale
-                             // layers, 0 (default): 128 x 128 tiles.  Built and measured in round 3, bit-compatible (same tests), NOT
-                             // faster: eager config-2 layers, tile -> big: 1024->1024 @10x10x4 150 -> 137 us, 512->1024 s2 89 -> 88, but
-                             // 256->512 s2 124 -> 178, ConvTranspose 512->256 44 -> 101, 1024->512 47 -> 89, 1024->128 57 -> 79.  A step of
-                             // the big tile takes 4.4 us for 48 MFMAs per wave (1.4 us of matrix time): the fp32 -> bf16 hi / lo split of
-                             // the gathered rows (8 float4 per thread and step, ~280 VALU instructions, every wave in lockstep) and
-                             // the extra pass through the split workspace cost what the larger tile saves on weight traffic.  What
-                             // these layers need is activations split ONCE by their producer, not a bigger tile.
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_split_target = 192;   // halo kernel: channel slices are split over workgroups until a launch has this many
@@ -62,7 +53,6 @@ int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo ke
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
 
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // rows_gemm.hip: persistent weight-stationary form of the K <= 256 row GEMMs (every Linear of a level, the 1x1x1 layers)
 bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_t ldx);
@@ -255,8 +245,6 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
 // 3/16 of the fp32-MFMA cycles.  Activations stay fp32 in HBM and are split while they are staged
 // into LDS; weights are split once on the host.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDKH = BK + 8;   // bf16 elements per LDS row (80 B): conflict-free ds_read_b128
 
@@ -365,18 +353,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     const int soff_b = __builtin_amdgcn_readfirstlane((ld_tap * p.Cout * p.Cin + ld_kc * BK) * 2);
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-#if defined(SGC_DIAG_IG_NO_LOADS)
-      ra[i] = make_float4(0.001f * (float)aoff[i], 0.002f, 0.003f, 1.f);
-#else
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff_a, 0);
       ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-#endif
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-#if defined(SGC_DIAG_IG_NO_LOADS)
-      rbh[i] = make_uint4(0, 0, 0, 0); rbl[i] = make_uint4(0, 0, 0, 0);
-#else
       const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff[i], soff_b, 0);
       rbh[i] = make_uint4(h[0], h[1], h[2], h[3]);
       if constexpr (NP == 3) {
@@ -385,7 +366,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       } else {
         rbl[i] = make_uint4(0, 0, 0, 0);
       }
-#endif
     }
     if (++ld_kc == ksteps_c) {                          // next tap: uniform branch, once per Cin / 32 steps
       ld_kc = 0;
@@ -401,14 +381,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#if defined(SGC_DIAG_IG_NO_SPLIT)
-        h[e] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(v[e]) >> 16));
-        l[e] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(v[e]) & 0xffffu));
-#else
-        const __bf16 hb = (__bf16)v[e];
+        const __bf16 hb = op_hi<NP>(v[e]);
         h[e] = hb;
-        l[e] = (__bf16)(v[e] - (float)hb);
-#endif
+        l[e] = op_lo<NP>(v[e], hb);
       }
       const int o = (r0 + AROWS * i) * LDKH + c4 * 4;
       *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
@@ -458,41 +433,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-#if defined(SGC_DIAG_IG_NO_MFMA)
-          acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1] + (float)ah[i][2] * (float)bh[j][2];
-#elif defined(SGC_DIAG_IG_ONE_PRODUCT)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#elif defined(SGC_DIAG_IG_REORDER)
-          (void)0;
-#else
           if constexpr (NP == 3) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#endif
+          acc[i][j] = mma_hh<NP>(ah[i], bh[j], acc[i][j]);
         }
-#if defined(SGC_DIAG_IG_REORDER)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#endif
     }
     if (s + 1 < nsteps) store_step(buf ^ 1);
     __syncthreads();
   }
-#if defined(SGC_DIAG_IG_NO_EPILOGUE)
-  if (acc[0][0][0] != 123.456f) return;
-#endif
 
   // Epilogue through LDS: in the MFMA layout a lane owns ONE column and 16 rows of a tile, i.e. 4-byte stores, 32 per
   // lane -- store-issue bound (PMC on the K = 256 Linears: waves parked 54 % of their cycles, matrix pipe busy 20 %).
@@ -606,194 +556,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Big-tile form of the implicit GEMM for the layers the halo kernel does not take (stride-2 3x3x3, ConvTranspose k2 s2, the
-// 3x3x3 layers of the 10x10x4 scale, necks/imvoxelnet.py:36-64): 512 voxels x 128 channels per 8-wave workgroup
-// (wave tile 128 x 64 = 4 x 2 MFMA tiles), K-step 32, ONE LDS staging buffer.
-// Why: those layers have few voxels (400 / 3,200) and a huge K (6,912 .. 27,648); on 128 x 128 tiles with a tap per split
-// they ran 864 workgroups that each re-stream their weight slab for a quarter of the voxels and pay one global-load latency
-// per 32-deep step for 12 MFMAs per wave (measured 2.7 us per step: 150 us for the 22.6-GF 1024 -> 1024 layer, 885 MB moved
-// for 113 MB of weights).  Here a workgroup covers ALL voxels of the small scales, so the weights are read once per
-// 128 output channels, a step carries 48 MFMAs per wave, and the K range (taps x channel chunks) is split evenly over
-// workgroups regardless of tap boundaries.  Partial tiles always go through the split workspace and the ordered
-// conv_epilogue_kernel (same deterministic reduction as the tile kernel).  Same products, same k order per tap.
-// ---------------------------------------------------------------------------------------------
-constexpr int BMB = 512;
-
-template <int NP>
-__global__ __launch_bounds__(512) void conv3d_igemm_big_kernel(const ConvParamsB p) {
-  constexpr int BN = 128, WN = 2, NT = 512;
-  constexpr int TM = 4, TN = 2;                          // wave tile 128 x 64
-  constexpr int ACH = BMB * 8 / NT;                      // 8 float4 A chunks per thread (rows r0 + 64 i)
-  constexpr int AROWS = NT / 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
-  constexpr int A_PLANE = BMB * LDKH, B_PLANE = BN * LDKH;
-  __bf16 *a_hi = reinterpret_cast<__bf16 *>(smem_g), *a_lo = a_hi + A_PLANE, *b_hi = a_lo + A_PLANE, *b_lo = b_hi + B_PLANE;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  const int m0 = blockIdx.x * BMB, n0 = blockIdx.y * BN;
-  int zid = blockIdx.z;
-  int parity = 0;
-  if (p.transposed) { parity = zid % 8; zid /= 8; }
-  const int ksteps_c = p.Cin / BK;
-  const int total = p.taps * ksteps_c;                   // K-steps of one (parity's) GEMM
-  const int per = (total + p.splitk - 1) / p.splitk;
-  const int g0 = zid * per, nsteps = min(per, total - g0);
-  if (nsteps <= 0) {                                     // a split past the end: its partial tile is zero (the epilogue sums all splits)
-    for (int e = tid; e < BMB * (BN / 4); e += NT) {
-      const int rl = e / (BN / 4), c4 = e - rl * (BN / 4);
-      const int m = m0 + rl, col = n0 + c4 * 4;
-      if (m >= p.M || col >= p.Cout) continue;
-      int64_t orow = m;
-      if (p.transposed) {
-        const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
-        orow = ((int64_t)(2 * x + (parity >> 2)) * (2 * p.gy) + (2 * y + ((parity >> 1) & 1))) * (2 * p.gz) + (2 * z + (parity & 1));
-      }
-      *reinterpret_cast<float4 *>(p.ws + (int64_t)zid * p.ws_stride + orow * p.Cout + col) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return;
-  }
-
-  const int c4 = tid & 7, rs8 = (tid >> 3) & 7;
-  const int r0 = 16 * (wid >> 1) + 2 * (wid & 1) + (rs8 >> 2) + 4 * (rs8 & 3);   // rows r0 + 64 i: the conflict-free staging deal of the tile kernel
-  const int bc = tid & 3, rs16 = (tid >> 2) & 15;
-  const int br0 = 16 * wid + (rs16 >> 2) + 4 * (rs16 & 3);
-  int coord[ACH];                                        // (x << 20) | (y << 10) | z of the GEMM row, -1 past M
-#pragma unroll
-  for (int i = 0; i < ACH; ++i) {
-    const int m = m0 + r0 + AROWS * i;
-    coord[i] = m < p.M ? ((m / (p.gz * p.gy)) << 20) | (((m / p.gz) % p.gy) << 10) | (m % p.gz) : -1;
-  }
-  float4 ra[ACH];
-  uint4 rbh, rbl;
-  auto load_step = [&](int s) {
-    const int g = g0 + s;
-    const int tap = p.transposed ? parity : g / ksteps_c;
-    const int cib = (g % ksteps_c) * BK;
-    int dx = 0, dy = 0, dz = 0;
-    if (!p.transposed && p.ksize > 1) { dx = tap / (p.ksize * p.ksize); dy = (tap / p.ksize) % p.ksize; dz = tap % p.ksize; }
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-      const int xx = (coord[i] >> 20) * p.stride + dx - p.pad, yy = ((coord[i] >> 10) & 1023) * p.stride + dy - p.pad,
-                zz = (coord[i] & 1023) * p.stride + dz - p.pad;
-      const bool ok = coord[i] >= 0 && xx >= 0 && xx < p.ix && yy >= 0 && yy < p.iy && zz >= 0 && zz < p.iz;
-      ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + ((int64_t)(xx * p.iy + yy) * p.iz + zz) * p.Cin + cib + c4 * 4)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int n = n0 + br0;
-    const int64_t off = ((int64_t)tap * p.Cout + n) * p.Cin + cib + bc * 8;
-    if (n < p.Cout) {
-      rbh = *reinterpret_cast<const uint4 *>(p.w_hi + off);
-      if constexpr (NP == 3) rbl = *reinterpret_cast<const uint4 *>(p.w_lo + off);
-    } else {
-      rbh = make_uint4(0, 0, 0, 0);
-      rbl = make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto store_step = [&]() {
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-      bf16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const __bf16 hb = (__bf16)v[e];
-        h[e] = hb;
-        l[e] = (__bf16)(v[e] - (float)hb);
-      }
-      const int o = (r0 + AROWS * i) * LDKH + c4 * 4;
-      *reinterpret_cast<bf16x4 *>(a_hi + o) = h;
-      if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(a_lo + o) = l;
-    }
-    const int o = br0 * LDKH + bc * 8;
-    *reinterpret_cast<uint4 *>(b_hi + o) = rbh;
-    if constexpr (NP == 3) *reinterpret_cast<uint4 *>(b_lo + o) = rbl;
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-
-  // row tiles of this wave that hold a live row (the 10x10x4 scale fills 400 of the 512 rows): dead tiles skip their MFMAs
-  const int live_tiles = min(TM, max(0, (p.M - m0 - wm * (BMB / 4) + 31) / 32));
-  load_step(0);
-  store_step();
-  __syncthreads();
-  const int fr = lane & 31, fh = lane >> 5;
-  const __bf16 *fa_hi = a_hi + (wm * (BMB / 4) + fr) * LDKH + fh * 8, *fa_lo = fa_hi + A_PLANE;
-  const __bf16 *fb_hi = b_hi + (wn * (BN / WN) + fr) * LDKH + fh * 8, *fb_lo = fb_hi + B_PLANE;
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) load_step(s + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 bh[TN], bl[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8 *>(fb_hi + j * 32 * LDKH + kk * 16);
-        if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(fb_lo + j * 32 * LDKH + kk * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (i < live_tiles) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(fa_hi + i * 32 * LDKH + kk * 16);
-          bf16x8 al;
-          if constexpr (NP == 3) al = *reinterpret_cast<const bf16x8 *>(fa_lo + i * 32 * LDKH + kk * 16);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (NP == 3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();                                   // every wave has read the staged step
-    if (s + 1 < nsteps) store_step();
-    __syncthreads();
-  }
-
-  // partial tile -> workspace, straight from the accumulators: a store instruction covers two rows x 32 columns = two whole
-  // 128-byte lines (as in rows_gemm.hip)
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int m = m0 + wm * (BMB / 4) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * fh;
-        if (m >= p.M || col >= p.Cout) continue;
-        int64_t orow = m;
-        if (p.transposed) {
-          const int z = m % p.gz, y = (m / p.gz) % p.gy, x = m / (p.gz * p.gy);
-          orow = ((int64_t)(2 * x + (parity >> 2)) * (2 * p.gy) + (2 * y + ((parity >> 1) & 1))) * (2 * p.gz) + (2 * z + (parity & 1));
-        }
-        p.ws[(int64_t)zid * p.ws_stride + orow * p.Cout + col] = acc[i][j][k];
-      }
-    }
-}
-
-// splits of the big-tile kernel: enough workgroups for the chip, at least 8 K-steps per workgroup
-static int big_splitk(int tiles, int total_steps) {
-  int s = ceil_div(256, tiles);
-  const int smax = total_steps / 8 > 0 ? total_steps / 8 : 1;
-  if (s > smax) s = smax;
-  return s < 1 ? 1 : s;
-}
-// does the big-tile kernel take this layer?  (bf16 MFMA path, not a halo layer; enough K-steps and rows to pay for a 512-row tile)
-static bool use_big_tile(const ConvParams &p, int Cout) {
-  if (!g_tune_conv_big || p.two_d || p.out_mask) return false;
-  const int total_steps = p.taps * (p.Cin / BK);
-  return Cout % 4 == 0 && Cout >= 128 && p.M >= 256 && total_steps >= 16 && p.gx < 1024 && p.gy < 1024 && p.gz < 1024;
-}
 
 // ---------------------------------------------------------------------------------------------
 // v2 for the 3x3x3 stride-1 layers (90 % of the neck's FLOPs): halo-resident A.
@@ -978,9 +740,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const __bf16 hb = (__bf16)v[e];
+        const __bf16 hb = op_hi<NP>(v[e]);
         h[e] = hb;
-        l[e] = (__bf16)(v[e] - (float)hb);
+        l[e] = op_lo<NP>(v[e], hb);
       }
       const uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
       ra[i] = make_float4(__uint_as_float(hu.x), __uint_as_float(hu.y), __uint_as_float(lu.x), __uint_as_float(lu.y));
@@ -1047,7 +809,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = mma_hh<NP>(f.ah[i], f.bh[j], acc[i][j]);
       }
   };
   const int steps_total = (c_hi - c_lo) * NTAP;
@@ -1309,12 +1071,11 @@ static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
 
 template <int BX, int BY, int BZ, int BNV = 128, bool TD = false>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
-  if (g_tune_halo_stagger) {
-    if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true>(p, OV, st);
-    return launch_halo_k<BX, BY, BZ, BNV, 3, TD, true>(p, OV, st);
-  }
-  if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, false>(p, OV, st);
-  return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
+  if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true>(p, OV, st);
+  if (g_conv_products == 2) return launch_halo_k<BX, BY, BZ, BNV, 2, TD, true>(p, OV, st);
+  // the lockstep form is kept for the fp32-faithful mode only: it is the reference of the schedule's bit-identity test
+  if (!g_tune_halo_stagger) return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
+  return launch_halo_k<BX, BY, BZ, BNV, 3, TD, true>(p, OV, st);
 }
 
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
@@ -1452,40 +1213,20 @@ static bool igemm_fits_32bit(const ConvParamsB &p) {
 }
 
 // one launch of the tile-per-workgroup implicit-GEMM kernel in the arithmetic mode of g_conv_products
-static void launch_igemm(const ConvParamsB &p, bool narrow, dim3 grid, size_t smem, hipStream_t st) {
-  static std::atomic<uint64_t> done[6];
-  const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
-  if (g_conv_products == 1) {
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2, 1>, big, done[0]);
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 1>, big, done[1]);
-    if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1, 1>), grid, dim3(256), smem, st, p);
-    else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 1>), grid, dim3(512), smem, st, p);
-    else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2, 1>), grid, dim3(256), smem, st, p);
-    return;
-  }
-  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2>, big, done[2]);
-  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2>, big, done[3]);
-  if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1>), grid, dim3(256), smem, st, p);
-  else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2>), grid, dim3(512), smem, st, p);
-  else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2>), grid, dim3(256), smem, st, p);
-}
-
-// the tall tile: 256 x 128, 8 waves as 4 x 2 (wave tile 64 x 64), one workgroup per CU
-constexpr int BM_TALL = 256;
-constexpr size_t SMEM_TALL = (size_t)BM_TALL * (128 + 8) * sizeof(float) > (size_t)2 * (2 * BM_TALL + 2 * 128) * LDKH * sizeof(uint16_t)
-                                 ? (size_t)BM_TALL * (128 + 8) * sizeof(float) : (size_t)2 * (2 * BM_TALL + 2 * 128) * LDKH * sizeof(uint16_t);
-static bool use_tall_tile(const ConvParams &p, int Cout) {
-  return g_tune_igemm_tall && Cout > 64 && (p.taps > 1 || p.transposed) && !p.two_d && !p.out_mask && p.hm_cm == 0 && p.M > BM;
-}
-static void launch_igemm_tall(const ConvParamsB &p, dim3 grid, hipStream_t st) {
+template <int NP>
+static void launch_igemm_np(const ConvParamsB &p, bool narrow, dim3 grid, size_t smem, hipStream_t st) {
   static std::atomic<uint64_t> done[2];
-  if (g_conv_products == 1) {
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 1, BM_TALL>, (int)SMEM_TALL, done[0]);
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 1, BM_TALL>), grid, dim3(512), SMEM_TALL, st, p);
-  } else {
-    ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, 3, BM_TALL>, (int)SMEM_TALL, done[1]);
-    hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, 3, BM_TALL>), grid, dim3(512), SMEM_TALL, st, p);
-  }
+  const int big = (int)((size_t)2 * (2 * BM + 2 * 128) * LDKH * sizeof(uint16_t));
+  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 2, 2, NP>, big, done[0]);
+  ensure_dynamic_lds((const void *)conv3d_igemm_bf16x3_kernel<128, 4, 2, NP>, big, done[1]);
+  if (narrow) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<64, 4, 1, NP>), grid, dim3(256), smem, st, p);
+  else if (g_tune_conv_waves == 8) hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 4, 2, NP>), grid, dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((conv3d_igemm_bf16x3_kernel<128, 2, 2, NP>), grid, dim3(256), smem, st, p);
+}
+static void launch_igemm(const ConvParamsB &p, bool narrow, dim3 grid, size_t smem, hipStream_t st) {
+  if (g_conv_products == 1) launch_igemm_np<1>(p, narrow, grid, smem, st);
+  else if (g_conv_products == 2) launch_igemm_np<2>(p, narrow, grid, smem, st);
+  else launch_igemm_np<3>(p, narrow, grid, smem, st);
 }
 
 // Same contract with the weights pre-split on the host: w_hi = bf16(w), w_lo = bf16(w - float(w_hi)),
@@ -1531,38 +1272,10 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
-  if (use_big_tile(p, Cout)) {
-    const int mbb = ceil_div(p.M, BMB), nbb = ceil_div(Cout, 128);
-    const int splits = big_splitk(mbb * nbb * (transposed ? 8 : 1), p.taps * (Cin / BK));
-    if (p.ws && p.ws_floats >= (int64_t)splits * OV * Cout) {
-      p.splitk = splits;
-      p.ws_stride = OV * Cout;
-      const dim3 gridb(mbb, nbb, (transposed ? 8 : 1) * splits);
-      const size_t smemb = (size_t)(2 * BMB + 2 * 128) * LDKH * sizeof(uint16_t);
-      static std::atomic<uint64_t> done_b3{0}, done_b1{0};
-      if (g_conv_products == 1) {
-        ensure_dynamic_lds((const void *)conv3d_igemm_big_kernel<1>, (int)smemb, done_b1);
-        hipLaunchKernelGGL(conv3d_igemm_big_kernel<1>, gridb, dim3(512), smemb, st, p);
-      } else {
-        ensure_dynamic_lds((const void *)conv3d_igemm_big_kernel<3>, (int)smemb, done_b3);
-        hipLaunchKernelGGL(conv3d_igemm_big_kernel<3>, gridb, dim3(512), smemb, st, p);
-      }
-      rc = check_launch("conv3d_igemm_big_kernel");
-      if (rc) return rc;
-      // ordered reduction + epilogue (also for one split: the kernel only writes raw tiles)
-      const int64_t total4 = OV * p.Cout / 4;
-      const int ge = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-      hipLaunchKernelGGL(conv_epilogue_kernel, dim3(ge), dim3(256), 0, st, p.y, p.scale, p.shift, p.residual, total4,
-                         p.Cout / 4, p.relu, (const float *)p.ws, p.splitk);
-      return check_launch("conv_epilogue_kernel");
-    }
-    // no (or too small a) workspace: the tile kernel below
-  }
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
-  const bool tall = use_tall_tile(p, Cout);
-  const int mb = ceil_div(p.M, tall ? BM_TALL : BM), nb = ceil_div(Cout, bn);
-  p.splitk = pick_splitk(p, mb, nb, tall ? g_tune_split_target / 2 : g_tune_split_target);   // tall: one workgroup per CU
+  const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
+  p.splitk = pick_splitk(p, mb, nb, g_tune_split_target);
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
     if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
@@ -1576,8 +1289,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const dim3 grid(mb, nb, (transposed ? 8 : 1) * p.splitk);
   const size_t smem = (size_t)2 * (2 * BM + 2 * bn) * LDKH * sizeof(uint16_t);
   p.xcd_deal = (p.taps > 1 || transposed) && !p.two_d ? g_tune_igemm_xcd : 0;
-  if (tall) launch_igemm_tall(p, grid, st);
-  else launch_igemm(p, narrow, grid, smem, st);
+  launch_igemm(p, narrow, grid, smem, st);
   rc = check_launch("conv3d_igemm_bf16x3_kernel");
   if (rc) return rc;
   return conv_finish(p, OV, st);
@@ -1950,14 +1662,9 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     ConvParams p = {};
     p.transposed = transposed; p.taps = transposed ? 1 : ksize * ksize * ksize;
     p.Cin = Cin; p.M = (int)M; p.gx = gx; p.gy = gy; p.gz = gz;
-    if (bf16x3 && Cin % BK == 0 && use_big_tile(p, Cout)) {      // mirrors conv3d_bf16x3: the big-tile kernel always needs a workspace
-      const int tiles = ceil_div((int)M, BMB) * ceil_div(Cout, 128) * (transposed ? 8 : 1);
-      return (int64_t)big_splitk(tiles, p.taps * (Cin / BK)) * OV * Cout;
-    }
     p.taps = transposed ? 8 : ksize * ksize * ksize;
     const int bn = bf16x3 ? (Cout <= 64 ? 64 : 128) : (Cout <= 32 ? 32 : 128);
-    const bool tall = bf16x3 && Cin % BK == 0 && use_tall_tile(p, Cout);               // mirrors conv3d_bf16x3
-    splitk = pick_splitk(p, ceil_div((int)M, tall ? BM_TALL : BM), ceil_div(Cout, bn), tall ? g_tune_split_target / 2 : g_tune_split_target);
+    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target);
   }
   return splitk > 1 ? (int64_t)splitk * OV * Cout : 0;
 }
@@ -2026,7 +1733,8 @@ extern "C" void sgc_diag_halo_stamp_buffer(unsigned long long *buf) { sgc::g_hal
 // Arithmetic mode of every bf16 MFMA kernel of the library (convolutions, Linears, the fused level tail): 3 = the
 // fp32-faithful 3-way split (default), 1 = plain bf16 products.  Changes results (that is its purpose): not a tuning knob.
 extern "C" int sgc_set_conv_products(int products) {
-  if (products != 1 && products != 3) return set_error(SGC_EINVAL, "sgc_set_conv_products: 1 (bf16) or 3 (bf16x3, fp32-faithful)");
+  if (products != 1 && products != 2 && products != 3)
+    return set_error(SGC_EINVAL, "sgc_set_conv_products: 3 (bf16x3, fp32-faithful), 1 (one bf16 product) or 2 (one fp16 product)");
   sgc::g_conv_products = products;
   return SGC_OK;
 }

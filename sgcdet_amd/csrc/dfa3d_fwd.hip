@@ -51,14 +51,7 @@ struct FwdParams {
                             // appended to the map; corners outside the image are pointed at it (no select needed)
   int n_items;              // < 0: read totals[0]
   int TP;                   // items per tile
-#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
-  float *dbg;               // diagnostic build: [2][items][M*P][12] produced / consumed descriptors
-#endif
 };
-#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
-static float *g_dbg = nullptr;
-extern "C" int sgc_debug_buffer(void *ptr) { g_dbg = (float *)ptr; return 0; }
-#endif
 
 template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void dfa3d_fwd_kernel(const FwdParams p) {
@@ -240,28 +233,17 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       const int il = slot / SPI, r = slot - il * SPI;
       int item = item0 + il;
       if (item >= n_items) item = n_items - 1;
-#if defined(SGC_DIAG_NO_PAIR_LOADS)
-      bb[j] = item % 40; x[j] = 0.3f + 1e-6f * item; y[j] = 0.4f; z[j] = 0.5f;
-#elif defined(SGC_DIAG_PAIR_REF)
-      { const float4 pr = reinterpret_cast<const float4 *>(p.dbg)[item];
-        bb[j] = __float_as_int(pr.w); x[j] = pr.x; y[j] = pr.y; z[j] = pr.z; }
-#else
       bb[j] = p.pair_cam[item];
       const int q = p.pair_q[item];
       const float *rc = p.ref_cam + ((int64_t)bb[j] * p.Nq + q) * 3;
       x[j] = rc[0]; y[j] = rc[1]; z[j] = rc[2];
-#endif
       aw[j] = 1.f;
       if (MODE == kPairsDeform) {
         const int MP = M * P;
         const float *rw = p.raw + (int64_t)item * (MP * 4);
-#if defined(SGC_DIAG_NO_RAW_LOADS)
-        (void)rw; uv[j] = make_float2(0.1f * r, -0.2f * r); dzv[j] = 0.01f * r; lgv[j] = 0.3f * r;
-#else
         uv[j] = *reinterpret_cast<const float2 *>(rw + r * 2);
         dzv[j] = rw[MP * 2 + r];
         lgv[j] = rw[MP * 3 + r];
-#endif
       }
     }
 #pragma unroll
@@ -299,28 +281,12 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
         o_[slot] = make_int4(sm.off[0], sm.off[1], sm.off[2], sm.off[3]);
       }
       if (r == 0) b_[il] = bb[j];
-#if defined(SGC_DIAG_DESC)
-      if (p.dbg && item0 + il < n_items) {
-        float *d = p.dbg + ((int64_t)(item0 + il) * SPI + r) * 12;
-        const int4 oo = o_[slot];
-        d[0] = sm.w[0]; d[1] = sm.w[1]; d[2] = sm.w[2]; d[3] = sm.w[3];
-        d[4] = __int_as_float(oo.x); d[5] = __int_as_float(oo.y); d[6] = __int_as_float(oo.z); d[7] = __int_as_float(oo.w);
-        d[8] = x[j]; d[9] = y[j]; d[10] = z[j]; d[11] = aw[j];
-      }
-#endif
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-#if defined(SGC_DIAG_PHASE1_ONLY)
-  {  // diagnostic build only (tools/diag): time phase 1 alone, keep its results live
-    const float4 w = w_[lane];
-    if (item0 * 1 + lane / SPI < n_items) p.out[(int64_t)(item0 + lane / SPI) * MC + (lane % SPI)] = w.x + w.y + w.z + w.w + (float)o_[lane].x;
-    return;
-  }
-#endif
   // ---- phase 2: lane = 4 channels of a head ----
   const int CV = Cm / 4, LPI = M * CV;
   const int LP = P;
@@ -346,29 +312,13 @@ __global__ __launch_bounds__(256) void dfa3d_fwd_wave_kernel(const FwdParams p) 
       float4 v[PT > 0 ? PT : 1][4];
 #pragma unroll
       for (int s = 0; s < PT; ++s) { w[s] = w_[d0 + s]; o[s] = o_[d0 + s]; }
-#if defined(SGC_DIAG_DESC)
-      if (p.dbg && c0 == 0) {
-#pragma unroll
-        for (int s = 0; s < PT; ++s) {
-          float *d = p.dbg + ((int64_t)(n_items + item) * SPI + m * LP + s) * 12;
-          d[0] = w[s].x; d[1] = w[s].y; d[2] = w[s].z; d[3] = w[s].w;
-          d[4] = __int_as_float(o[s].x); d[5] = __int_as_float(o[s].y); d[6] = __int_as_float(o[s].z); d[7] = __int_as_float(o[s].w);
-        }
-      }
-#endif
 #pragma unroll
       for (int s = 0; s < PT; ++s) {
         const int ok[4] = {o[s].x, o[s].y, o[s].z, o[s].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {   // no branch per load: clamped index + select (see Sample::off);
                                         // 32-bit element offset (host checks S*M*Cm < 2^31)
-#if defined(SGC_DIAG_NO_ROW_LOADS)
-          v[s][k] = make_float4((float)ok[k], 1.f, 2.f, 3.f);
-#elif defined(SGC_DIAG_SAME_ROW)
-          v[s][k] = *reinterpret_cast<const float4 *>(vbase + (unsigned)((off_index(ok[k]) & 7) * MC));
-#else
           v[s][k] = *reinterpret_cast<const float4 *>(vbytes + (rowb + (unsigned)(ZR ? ok[k] : off_index(ok[k])) * rstride));
-#endif
           if (!ZR && ok[k] < 0) v[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -415,7 +365,7 @@ extern int g_tune_view_group;
 extern int g_tune_halo_narrow;
 extern int g_tune_split_target;
 extern int g_tune_wgrad_waves;
-extern int g_tune_rows_gemm, g_tune_rows_depth, g_tune_rows_diag, g_tune_conv_big, g_tune_igemm_xcd, g_tune_igemm_tall, g_tune_halo_2d, g_tune_rows_cu_pct, g_tune_halo_split_target;
+extern int g_tune_rows_gemm, g_tune_rows_depth, g_tune_rows_diag, g_tune_igemm_xcd, g_tune_halo_2d, g_tune_rows_cu_pct, g_tune_halo_split_target;
 extern int g_tune_topk_multi_min;
 extern int g_tune_tile_nw;          // dfa3d_tile.hip
 extern int g_tune_tile_depth_lds;
@@ -601,9 +551,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "split_target")) { g_tune_split_target = value; return SGC_OK; }
   if (!strcmp(key, "wgrad_waves")) { g_tune_wgrad_waves = value; return SGC_OK; }
   if (!strcmp(key, "rows_gemm")) { g_tune_rows_gemm = value; return SGC_OK; }
-  if (!strcmp(key, "conv_big")) { g_tune_conv_big = value; return SGC_OK; }
   if (!strcmp(key, "igemm_xcd")) { g_tune_igemm_xcd = value; return SGC_OK; }
-  if (!strcmp(key, "igemm_tall")) { g_tune_igemm_tall = value; return SGC_OK; }
   if (!strcmp(key, "halo_2d")) { g_tune_halo_2d = value; return SGC_OK; }
   if (!strcmp(key, "rows_cu_pct")) { g_tune_rows_cu_pct = value; return SGC_OK; }
   if (!strcmp(key, "halo_split_target")) { g_tune_halo_split_target = value; return SGC_OK; }
@@ -699,9 +647,6 @@ extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, co
   p.M = M; p.Cm = Cm; p.D = D; p.dist_heads = 1; p.L = 1; p.Q = 1; p.P = P; p.Nq = Nq;
   p.value_bytes = ((int64_t)N * p.S + 1) * M * Cm * 4;
   p.zero_row = value_has_zero_row ? N * p.S : -1;
-#if defined(SGC_DIAG_DESC) || defined(SGC_DIAG_PAIR_REF)
-  p.dbg = g_dbg;
-#endif
   p.H = H; p.W = W; p.n_items = n_pairs_or_neg;
   return launch_fwd<kPairsDeform>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }

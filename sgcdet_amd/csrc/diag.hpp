@@ -9,6 +9,8 @@
 //   SGC_HALO_SKIP     bit mask, lockstep form of the halo convolution (halo_stagger 0), TIMING ONLY (results are garbage): 1 no
 //                     barrier per tap, 2 no weight ds_write, 4 no weight global load, 8 weight fragments read from LDS once
 //                     instead of every tap, 16 halo fragments read once -- what each part of the tap loop costs (tools/halo_skip.py)
+//   SGC_RG_STAMPS     s_memtime stamps inside the staggered form of the persistent row GEMM (rows_depth 0; tools/rows_gemm_stamps.py):
+//                     buffer [workgroup < 8][wave parity 2][iteration < 32][8] x uint64 (sgc_diag_rows_stamp_buffer)
 #pragma once
 
 #if !defined(SGC_HALO_SKIP)
@@ -27,4 +29,16 @@ namespace sgc { inline unsigned long long *g_halo_stamp_buf = nullptr; }
   } while (0)
 #else
 #define SGC_HALO_STAMP(slot) do {} while (0)
+#endif
+
+#if defined(SGC_RG_STAMPS)
+namespace sgc { inline unsigned long long *g_rows_stamp_buf = nullptr; }
+#define RG_STAMP_PTR(p, wid, late) \
+  unsigned long long *stamp_ptr = ((p).stamps && blockIdx.x < 8 && ((wid) & 3) == 0) ? (p).stamps + ((blockIdx.x * 2 + (late)) * 32) * 8 : nullptr
+#define RG_STAMP(slot) do { if (stamp_ptr && i < 32 && lane == 0) stamp_ptr[i * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define RG_STAMP_BIND(p) (p).stamps = sgc::g_rows_stamp_buf
+#else
+#define RG_STAMP_PTR(p, wid, late) do {} while (0)
+#define RG_STAMP(slot) do {} while (0)
+#define RG_STAMP_BIND(p) do {} while (0)
 #endif

@@ -18,14 +18,12 @@
 // Every product, sum order and epilogue expression is that of the unfused kernels, so the fused level is
 // BIT-IDENTICAL to the six launches (tests/test_gpu_kernels.py checks it) -- it is a scheduling change, not a numerical one.
 #include "common.hpp"
+#include "mma.hpp"
 
 namespace sgc {
 
 int g_tune_level_tail = 1;       // 0: the six separate launches (round-2 path)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct LevelTailParams {
   const float *ctx;              // [rows, C] compact rows of the voxels some camera sees (view_attend's output)
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
+      acc = mma_hh<NP>(ah[kk % (PD + 1)], bh[kk], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -139,8 +137,8 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
         bf16x4 h4, l4;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-          const __bf16 hb = (__bf16)y[j];
-          const __bf16 lb = (__bf16)(y[j] - (float)hb);
+          const __bf16 hb = op_hi<NP>(y[j]);
+          const __bf16 lb = op_lo<NP>(y[j], hb);
           if constexpr (VPL == 4) {
             h4[j] = hb; l4[j] = lb;
           } else {
@@ -173,9 +171,9 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const __bf16 hb = (__bf16)v[e];
+        const __bf16 hb = op_hi<NP>(v[e]);
         h[e] = hb;
-        l[e] = (__bf16)(v[e] - (float)hb);
+        l[e] = op_lo<NP>(v[e], hb);
       }
       *reinterpret_cast<bf16x4 *>(A_hi + row * PA + ld_c4 * 4) = h;
       *reinterpret_cast<bf16x4 *>(A_lo + row * PA + ld_c4 * 4) = l;
@@ -216,9 +214,9 @@ __global__ __launch_bounds__(C * 2, 2) void level_tail_kernel(const LevelTailPar
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const float v = fmaxf(acc[k] + sh, 0.f);
-        const __bf16 hb = (__bf16)v;
+        const __bf16 hb = op_hi<NP>(v);
         hh[((k & 3) + 8 * (k >> 2)) * PH] = hb;
-        hl[((k & 3) + 8 * (k >> 2)) * PH] = (__bf16)(v - (float)hb);
+        hl[((k & 3) + 8 * (k >> 2)) * PH] = op_lo<NP>(v, hb);
       }
     }
     __syncthreads();
@@ -301,5 +299,7 @@ extern "C" int sgc_level_tail(const float *ctx, const int32_t *row_of, const uin
   p.out = out; p.Nq = Nq;
   if (g_conv_products == 1)
     return C == 256 ? launch_level_tail<256, 1>(p, (hipStream_t)stream) : launch_level_tail<128, 1>(p, (hipStream_t)stream);
+  if (g_conv_products == 2)
+    return C == 256 ? launch_level_tail<256, 2>(p, (hipStream_t)stream) : launch_level_tail<128, 2>(p, (hipStream_t)stream);
   return C == 256 ? launch_level_tail<256, 3>(p, (hipStream_t)stream) : launch_level_tail<128, 3>(p, (hipStream_t)stream);
 }

@@ -30,6 +30,8 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "mma.hpp"
+#include "diag.hpp"
 
 namespace sgc {
 
@@ -45,9 +47,6 @@ int g_tune_rows_depth = 1;       // 8-wave form: 1 / 2 = lockstep with that many
                                  // slows the partner wave's MFMA chain from 1536 to 2000-3000 cycles, so separating the phases in
                                  // time does not pay); the memory-only form of the kernel (no MFMA) takes 80 us = 5.2 TB/s
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct RowsGemmParams {
   const float *x;              // [M, K] rows, row stride ldx floats
@@ -68,14 +67,6 @@ struct RowsGemmParams {
 
 constexpr int RG_ROWS = 32;
 
-// In-kernel cycle stamps of the staggered loop: ONLY in diagnostic builds (tools/diag_build.sh ... -DSGC_RG_STAMPS); the
-// product library has none of this.  stamp buffer: [workgroup < 8][wave parity 2][iteration < 32][8] x uint64 (s_memtime).
-#if defined(SGC_RG_STAMPS)
-unsigned long long *g_rows_stamp_buf = nullptr;
-#define RG_STAMP(slot) do { if (stamp_ptr && i < 32 && lane == 0) stamp_ptr[i * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define RG_STAMP(slot) do { } while (0)
-#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned RG_OOB = 0xfffffff0u;    // a byte offset no buffer of < 4 GiB reaches: the load returns 0, the store is dropped
 
@@ -157,9 +148,9 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const __bf16 hb = (__bf16)v[e];
+        const __bf16 hb = op_hi<NP>(v[e]);
         h[e] = hb;
-        l[e] = (__bf16)(v[e] - (float)hb);
+        l[e] = op_lo<NP>(v[e], hb);
       }
       *reinterpret_cast<bf16x4 *>(a_hi + row * PITCH + c4 * 4) = h;
       if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(a_lo + row * PITCH + c4 * 4) = l;
@@ -191,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
+      acc = mma_hh<NP>(ah[kk % (PD + 1)], bh[kk], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -270,9 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
     // enough: the half of tile i + 1 staged by waves 4-7 during the first half-period lands in the buffer of tile
     // i - 1, whose last reader (their own multiply) finished a barrier earlier.
     float4 r0[CH];
-#if defined(SGC_RG_STAMPS)
-    unsigned long long *stamp_ptr = (p.stamps && blockIdx.x < 8 && (wid & 3) == 0) ? p.stamps + ((blockIdx.x * 2 + late) * 32) * 8 : nullptr;
-#endif
+    RG_STAMP_PTR(p, wid, late);
     load_tile(t, r0);
     split_tile(r0, 0);
     load_tile(t + nstripes, r0);
@@ -381,7 +370,8 @@ static int launch_rows_gemm_np(const RowsGemmParams &p, int grid, hipStream_t st
 
 template <int K, int NW, int DEPTH, int EPI>
 static int launch_rows_gemm_e(const RowsGemmParams &p, int grid, hipStream_t st) {
-  if (g_conv_products == 1) return launch_rows_gemm_np<K, NW, 1, EPI, 1>(p, grid, st);      // single-product mode: the lockstep-1 form
+  if (g_conv_products == 1) return launch_rows_gemm_np<K, NW, 1, EPI, 1>(p, grid, st);      // single-product modes: the lockstep-1 form
+  if (g_conv_products == 2) return launch_rows_gemm_np<K, NW, 1, EPI, 2>(p, grid, st);
   return launch_rows_gemm_np<K, NW, DEPTH, EPI, 3>(p, grid, st);
 }
 
@@ -432,9 +422,7 @@ int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const ui
     static const bool diag_ok = getenv("SGC_DIAG") && atoi(getenv("SGC_DIAG")) == 1;
     p.diag = diag_ok ? g_tune_rows_diag : 0;
   }
-#if defined(SGC_RG_STAMPS)
-  p.stamps = g_rows_stamp_buf;
-#endif
+  RG_STAMP_BIND(p);
   const int nw = (N % 256 == 0) ? 8 : 4;
   p.ncg = N / (nw * 32);
   const int cap_tiles = ceil_div(M, RG_ROWS);

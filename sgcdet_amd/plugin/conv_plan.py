@@ -16,19 +16,21 @@ _PAD = 32
 
 # "bf16x3": fp32 operands split hi/lo onto the bf16 matrix cores (fp32-faithful to ~1e-5, default);
 # "f32": exact fp32 products on the fp32 MFMA (5x slower matrix pipe).  Both are tested against the oracle.
-# "bf16" (opt-in, BASELINE.json configs #2 / #5): the bf16x3 code path with ONE product per multiply-add -- both operands
-# rounded to bfloat16, fp32 accumulate (sgc_set_conv_products(1)); 1/3 of the matrix work, NOT parity-exact: its own bench
-# line, never the headline.  CONV_MODE stays "bf16x3" (same kernels, same launch sequence); CONV_PRODUCTS says which.
+# "bf16" / "fp16" (opt-in, BASELINE.json configs #2 "bf16" / #5 "fp16"): the bf16x3 code path with ONE product per multiply-add
+# -- both operands rounded to bfloat16 (sgc_set_conv_products(1)) or to IEEE half (2; v_mfma_f32_32x32x16_f16: the same rate,
+# 11 instead of 8 significant bits, operands saturated at +-65504), fp32 accumulate; 1/3 of the matrix work, NOT parity-exact:
+# their own bench lines, never the headline.  CONV_MODE stays "bf16x3" (same kernels, same launch sequence); CONV_PRODUCTS says
+# which.  Call set_conv_mode BEFORE the modules prepare their weight plans (the planes hold bf16 or half bits accordingly).
 CONV_MODE = "bf16x3"
 CONV_PRODUCTS = 3
 
 
 def set_conv_mode(mode):
     global CONV_MODE, CONV_PRODUCTS
-    if mode not in ("bf16x3", "f32", "bf16"):
+    if mode not in ("bf16x3", "f32", "bf16", "fp16"):
         raise ValueError(mode)
-    CONV_MODE = "bf16x3" if mode == "bf16" else mode
-    CONV_PRODUCTS = 1 if mode == "bf16" else 3
+    CONV_MODE = "bf16x3" if mode in ("bf16", "fp16") else mode
+    CONV_PRODUCTS = {"bf16": 1, "fp16": 2}.get(mode, 3)
     import torch
     if torch.cuda.is_available():
         ext.ops().lib.call("sgc_set_conv_products", CONV_PRODUCTS)
@@ -62,7 +64,7 @@ class ConvSpec:
         if bias is not None:
             shift[:cout] += bias.detach().float() * scale[:cout]
         self.wt, self.scale, self.shift = wp.contiguous(), scale, shift
-        self.w_hi, self.w_lo = ext.ops().split_bf16(self.wt) if w.is_cuda else (None, None)
+        self.w_hi, self.w_lo = ext.ops().split_operand(self.wt) if w.is_cuda else (None, None)
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.ksize, self.stride, self.transposed = ksize, stride, transposed
 
@@ -163,7 +165,7 @@ def module_fingerprint(module):
         tensors = list(module.parameters()) + list(module.buffers())
         module.__dict__["_fp_tensors"] = tensors
         module.__dict__["_fp_training"] = module.training
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+    return (CONV_PRODUCTS,) + tuple((t.data_ptr(), t._version) for t in tensors)       # a mode switch rebuilds the weight planes
 
 
 def to_channels_last_rows(x):
@@ -196,7 +198,7 @@ class LinearSpec:
         wp = torch.zeros((1, cout_p, cin), dtype=torch.float32, device=w.device)
         wp[0, :cout] = w
         self.wt = wp
-        self.w_hi, self.w_lo = ext.ops().split_bf16(wp)
+        self.w_hi, self.w_lo = ext.ops().split_operand(wp)
         self.shift = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
         if bias is not None:
             self.shift[:cout] = bias.detach().float()

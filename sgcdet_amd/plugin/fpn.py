@@ -84,7 +84,7 @@ class FPN(nn.Module):
         def spec(conv):
             w = conv.weight.detach().float()
             k = w.shape[2]
-            hi, lo = ops.split_bf16(w.permute(2, 3, 0, 1).reshape(k * k, w.shape[0], w.shape[1]).contiguous())
+            hi, lo = ops.split_operand(w.permute(2, 3, 0, 1).reshape(k * k, w.shape[0], w.shape[1]).contiguous())
             return hi, lo, conv.bias.detach().float().contiguous(), k
         plan = ([spec(m.conv) for m in self.lateral_convs], [spec(m.conv) for m in self.fpn_convs])
         self._hip_plan = (fp, plan)

@@ -675,7 +675,7 @@ class VoxFormerLayer(MyCustomBaseTransformerLayer):
         plan = self.__dict__.get("_tail_plan")
         if plan is None or plan[0] != fp:                       # weights split to bf16 hi / lo and fragment-packed once
             def packed(weight):
-                hi, lo = ops.split_bf16(weight.detach().float())
+                hi, lo = ops.split_operand(weight.detach().float())
                 return ops.pack_b_fragments(hi), ops.pack_b_fragments(lo)
             mha = att.attention_pooling
             lin1, lin2 = ffn.layers[0][0], ffn.layers[1]

@@ -489,6 +489,19 @@ class TensorOps:
         lo = (w - hi.float()).to(torch.bfloat16)
         return hi.contiguous(), lo.contiguous()
 
+    @staticmethod
+    def split_f16(w):
+        """fp32 -> the operand planes of the fp16 mode (``sgc_set_conv_products(2)``): hi = the IEEE-half bits of w (rounded to
+        nearest even, saturated at +-65504) in a bfloat16-TYPED container (the planes are 16-bit patterns to the library), lo =
+        zeros (ignored in the one-product modes)."""
+        hi = w.clamp(-65504.0, 65504.0).to(torch.float16).view(torch.bfloat16)
+        return hi.contiguous(), torch.zeros_like(hi)
+
+    def split_operand(self, w):
+        """Weight planes for the library's CURRENT arithmetic mode (``sgc_get_conv_products``): the bf16 hi / lo split for 3 and 1,
+        half bits for 2.  Prepared plans must be rebuilt after a mode switch (plugin/conv_plan.set_conv_mode does not do it)."""
+        return self.split_f16(w) if self.lib._dll.sgc_get_conv_products() == 2 else self.split_bf16(w)
+
     def conv3d_cl_bf16x3(self, x, w_hi, w_lo, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
                          residual=None, relu=False, out=None, out_mask=None):
         """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``).  ``out_mask`` (uint8 [OV], 3x3x3 stride-1

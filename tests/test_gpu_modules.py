@@ -249,6 +249,41 @@ def _check_neck_head_on(det, vol_c, rp2):
         assert max_err(a, b) < 1e-3 * max(1.0, b.abs().max().item())
 
 
+def test_reduced_precision_modes_through_neck_and_head():
+    """The opt-in one-product modes (`set_conv_mode("bf16")` / `("fp16")`, BASELINE.json configs #2 / #5) through the whole neck +
+    head (twelve chained convolutions per scale) on the oracle's fp32 volume: every head tensor stays within 2^-5 (bf16) /
+    2^-8 (fp16) of its scale against the fp32 oracle, and fp16 -- 11 significant bits against 8 at the same MFMA rate -- is at
+    least 3x closer than bf16.  The view transform of these modes is covered by the kernel tests; its top-k selections are not
+    comparable across arithmetic modes."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin.conv_plan import set_conv_mode
+    from sgcdet_amd.scene import model_config, workload
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(21)
+    det = build_detector(model_config(w)).eval()
+    rp2 = _neck_head_oracle(det, w)
+    g = torch.Generator().manual_seed(4)
+    nx, ny, nz = w["n_voxels_list"][-1]
+    vol = torch.randn(1, w["embed_dims"], nx, ny, nz, generator=g)
+    feats3d = rp2.neck(vol, prefix="neck.")
+    ctr, reg, cls = rp2.head(feats3d, prefix="head.")
+    det = det.cuda()
+    det.use_graph = det.scene_graph = False
+    worst = {}
+    try:
+        for mode in ("bf16x3", "bf16", "fp16"):
+            set_conv_mode(mode)
+            with torch.no_grad():
+                outs = det._neck_head_eager(vol.cuda())
+            got = list(outs[0]) + list(outs[1]) + list(outs[2])
+            worst[mode] = max(max_err(a, b) / max(1.0, b.abs().max().item()) for a, b in zip(got, ctr + reg + cls))
+    finally:
+        set_conv_mode("bf16x3")
+    assert worst["bf16x3"] < 1e-4 and worst["bf16"] <= 2.0 ** -5 and worst["fp16"] <= 2.0 ** -8, worst
+    assert worst["fp16"] * 3 <= worst["bf16"], worst
+
+
 def _neck_head_oracle(det, w):
     from oracle.ref_path import RefPath
     return RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},
