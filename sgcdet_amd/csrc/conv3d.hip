@@ -572,9 +572,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 // of the brick holds each halo-row residue mod 16 exactly twice (checked offline for the three brick shapes:
 // 18 for BZ = 16, 12 for BZ = 8, 6 for BZ = 4) -- the precondition of the conflict-free lane assignment.
 __host__ __device__ constexpr int halo_pitch(int BZ) { return BZ == 8 ? 12 : BZ + 2; }
-__host__ __device__ constexpr size_t halo_tab_offset(int lrows) {
-  const size_t planes = (size_t)(2 * lrows + 2 * 2 * 128) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
-  const size_t stage = (size_t)256 * (128 + 8) * sizeof(float);                        // epilogue tile [256][BNV + 8]
+__host__ __device__ constexpr size_t halo_tab_offset(int lrows, int mrows = 256, int bnv = 128) {
+  const size_t planes = (size_t)(2 * lrows + 2 * 2 * bnv) * LDKH * sizeof(uint16_t);   // A hi|lo + 2 x B hi|lo
+  const size_t stage = (size_t)mrows * (bnv + 8) * sizeof(float);                      // epilogue tile [MROWS][BNV + 8]
   return planes > stage ? planes : stage;
 }
 
@@ -594,7 +594,12 @@ __host__ __device__ constexpr size_t halo_tab_offset(int lrows) {
 template <int BX, int BY, int BZ, int BNV = 128, int NP = 3, bool TD = false, bool STG = true>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
   constexpr int NTAP = TD ? 9 : 27, XO = TD ? 0 : 1;    // taps; halo width along x
-  constexpr int RT = 2;                                 // 32-row tiles per wave
+  // MFMA rows of the brick: 256 for the standard bricks; a brick with another voxel count (a whole small grid: 10 x 10 x 4, the
+  // coarsest config-2 scale) is padded to a multiple of 128 rows (4 wave rows x 32) -- pad rows work on voxel 0 and are dropped
+  constexpr int NVOX = BX * BY * BZ, MROWS = (NVOX + 127) / 128 * 128;
+  constexpr int RT = MROWS / 128;                       // 32-row tiles per wave
+  constexpr unsigned short kPadRow = 0x8000;            // vox_tab flag of a pad row
+  static_assert(MROWS <= 512, "one table entry per thread");
   constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2 * XO, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   __bf16 *A_hi = reinterpret_cast<__bf16 *>(smem_h), *A_lo = A_hi + A_PLANE;
   __bf16 *Bbase = A_lo + A_PLANE;                   // [2][hi|lo][BNV][LDKH]
   // [8 tiles][32 lanes], behind both the staging planes and the epilogue's output tile that later overlays them
-  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS));
+  unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -627,26 +632,42 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // (measured: 38 % of the LDS cycles of this kernel were bank-conflict cycles).  Every tile holds each
   // residue exactly twice (halo_pitch guarantees it), so lane l takes the first (l < 16) or second voxel of
   // the tile whose halo row is == l mod 16 -- any assignment works as long as the epilogue uses the same one.
-  if (tid < 256) {
-    const int t = tid >> 5, l = tid & 31;
-    int seen = 0, pick = t * 32 + l;
-    for (int j = 0; j < 32; ++j) {
-      const int r = t * 32 + j;
-      const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
-      const int hr = ((x + XO) * HY + (y + 1)) * HZP + (z + 1);
-      if ((hr & 15) == (l & 15)) {
-        if (seen == (l >> 4)) pick = r;
-        ++seen;
-      }
+  // (Other brick shapes -- a whole small grid -- do not keep that precondition for every tile: the greedy pass below IS the
+  //  assignment above wherever it exists and degrades to a few two-way conflicts elsewhere, never to a wrong permutation.)
+  // One wave per tile, lane j = row j of the tile (both wave halves compute the same; the upper half does not store): a row whose
+  // residue it is the first / second to carry takes slot residue / 16 + residue; further rows of a crowded residue fill the
+  // slots of the residues that came short, in order.
+  for (int t = wid; t < MROWS / 32; t += NT / 64) {
+    const int j = lane & 31;
+    const int r = t * 32 + j, rv = r < NVOX ? r : 0;
+    const int x = rv / (BY * BZ), y = (rv / BZ) % BY, z = rv % BZ;
+    const int res = (((x + XO) * HY + (y + 1)) * HZP + (z + 1)) & 15;
+    unsigned same = 0, mine = 0;                      // rows with this row's residue / with this SLOT's residue (slot j: j & 15)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const unsigned m = (unsigned)__ballot(res == q);
+      if (res == q) same = m;
+      if ((j & 15) == q) mine = m;
     }
-    vox_tab[tid] = (unsigned short)pick;
+    const unsigned below = (1u << j) - 1u;
+    const int rank = __popc(same & below);
+    const bool slot_empty = __popc(mine) < (j >> 4) + 1;
+    const unsigned left = (unsigned)__ballot(rank >= 2), empty = (unsigned)__ballot(slot_empty);
+    const unsigned short val = r < NVOX ? (unsigned short)r : kPadRow;
+    unsigned short *tab = vox_tab + t * 32, *tmp = vox_tab + MROWS + (wid & 7) * 32;
+    if (lane < 32) {
+      if (rank < 2) tab[rank * 16 + res] = val;
+      else tmp[__popc(left & below)] = val;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // one wave, LDS operations complete in order: its own stores are visible
+    if (lane < 32 && slot_empty) tab[j] = tmp[__popc(empty & below)];
   }
   __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
   int arow[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
-    const int r = vox_tab[(wm * RT + i) * 32 + fr];
+    const int r = vox_tab[(wm * RT + i) * 32 + fr] & 0x7fff;          // pad rows read voxel 0's halo rows (valid LDS, result dropped)
     const int x = r / (BY * BZ), y = (r / BZ) % BY, z = r % BZ;
     arow[i] = ((x + XO) * HY + (y + 1)) * HZP + (z + 1);
   }
@@ -658,13 +679,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     for (int i = 0; i < RT; ++i) {
       const int r = vox_tab[(wm * RT + i) * 32 + fr];
       const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
-      if (x < p.gx && y < p.gy && z < p.gz) mine |= p.out_mask[((int64_t)x * p.gy + y) * p.gz + z] != 0;
+      if (!(r & kPadRow) && x < p.gx && y < p.gy && z < p.gz) mine |= p.out_mask[((int64_t)x * p.gy + y) * p.gz + z] != 0;
     }
     wave_live = __ballot(mine) != 0ull;
     if (!__syncthreads_or(wave_live ? 1 : 0)) {
       // dead brick: store the epilogue of a zero accumulator and leave (no staging, no taps)
       if (p.splitk > 1 && !p.ws) return;             // atomics path: y was zero-filled, the epilogue kernel finishes it
-      for (int e = tid; e < 256 * (BNV / 4); e += NT) {
+      for (int e = tid; e < NVOX * (BNV / 4); e += NT) {
         const int rl = e / (BNV / 4), c4 = e - rl * (BNV / 4);
         const int col = n0 + c4 * 4;
         if (col >= p.Cout) continue;
@@ -919,7 +940,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // leaves as 16-byte row-contiguous stores instead of 64 four-byte stores per lane.
   if ((p.Cout & 3) == 0 && (p.splitk == 1 || p.ws)) {
     constexpr int LDC = BNV + 8;
-    float *cs = reinterpret_cast<float *>(smem_h);           // [256][LDC] floats = 139 KB (launch_halo sizes LDS for it)
+    float *cs = reinterpret_cast<float *>(smem_h);           // [MROWS][LDC] floats (139 KB for 256 x 128; launch_halo sizes LDS for it)
     if constexpr (STG) __syncthreads();                      // the second half of the last tap ran after the loop's last barrier
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -930,11 +951,12 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           cs[(wm * (RT * 32) + i * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)) * LDC + wn * WCOL + j * 32 + (lane & 31)] = acc[i][j][k];
     __syncthreads();
     constexpr int C4 = BNV / 4;
-    for (int e = tid; e < 256 * C4; e += NT) {
+    for (int e = tid; e < MROWS * C4; e += NT) {
       const int rl = e / C4, c4 = e - rl * C4;
       const int col = n0 + c4 * 4;
       if (col >= p.Cout) continue;
       const int r = vox_tab[rl];
+      if (r & kPadRow) continue;
       const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
       if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
       const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
@@ -973,7 +995,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       for (int k = 0; k < 16; ++k) {
         const int r = vox_tab[(wm * RT + i) * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)];
         const int x = X0 + r / (BY * BZ), y = Y0 + (r / BZ) % BY, z = Z0 + r % BZ;
-        if (x >= p.gx || y >= p.gy || z >= p.gz) continue;
+        if ((r & kPadRow) || x >= p.gx || y >= p.gy || z >= p.gz) continue;
         const int64_t orow = ((int64_t)x * p.gy + y) * p.gz + z;
         float *dst = p.y + orow * p.Cout + col;
         if (p.splitk > 1) {
@@ -1030,6 +1052,20 @@ static int halo_brick_shape(int gx, int gy, int gz) {
   return 2;
 }
 
+// Whole-grid bricks for the coarsest scale of configs 2 / 3 (10 x 10 x 4 = 400 and 12 x 12 x 4 = 2 x 288 voxels; too few for 256-voxel
+// bricks: 61 % of their rows would be padding, and on the tile kernel these weight-streaming layers -- 113 MB of weights for
+// 400 voxels -- run at a quarter of the MFMA rate): 1 = one 10 x 10 x 4 brick, 2 = two 6 x 12 x 4 bricks, 0 = none.
+// 64-column tiles (the 512 / 384 MFMA rows of such a brick leave the accumulators room for no more).
+int g_tune_halo_small = 1;
+static int halo_small_grid(int gx, int gy, int gz, int Cout) {
+  // measured (tools/small_grid_ab.py, alternated): 1024 -> 1024 109 -> 88 us at 10x10x4, 137 -> 119 at 12x12x4; with 128 output
+  // channels (two column tiles x 32 splits) the tile kernel stays ahead (39 vs 47 / 40 us)
+  if (!g_tune_halo_small || Cout < 512) return 0;
+  if (gx == 10 && gy == 10 && gz == 4) return 1;
+  if (gx == 12 && gy == 12 && gz == 4) return 2;
+  return 0;
+}
+
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < g_tune_halo_split_target) splitk *= 2;
@@ -1045,7 +1081,9 @@ static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
   p.stamps = g_halo_stamp_buf;
 #endif
   constexpr int LROWS = (TD ? BX : BX + 2) * (BY + 2) * halo_pitch(BZ);
-  const size_t smem = halo_tab_offset(LROWS) + 256 * sizeof(uint16_t);
+  constexpr int MROWS = (BX * BY * BZ + 127) / 128 * 128;
+  const size_t smem = halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t);   // table + 8 x 32 scratch
+  static_assert(halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t) <= 160 * 1024, "brick does not fit the LDS");
   static std::atomic<uint64_t> attr_done{0};
   ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
@@ -1073,8 +1111,9 @@ template <int BX, int BY, int BZ, int BNV = 128, bool TD = false>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
   if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true>(p, OV, st);
   if (g_conv_products == 2) return launch_halo_k<BX, BY, BZ, BNV, 2, TD, true>(p, OV, st);
-  // the lockstep form is kept for the fp32-faithful mode only: it is the reference of the schedule's bit-identity test
-  if (!g_tune_halo_stagger) return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
+  // the lockstep form is kept for the fp32-faithful mode only: it is the reference of the schedule's bit-identity test, and the
+  // form of the whole-grid bricks (four row tiles per wave: the unrolled pipelined loop spills 600 registers there)
+  if (!g_tune_halo_stagger || BX * BY * BZ > 256) return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
   return launch_halo_k<BX, BY, BZ, BNV, 3, TD, true>(p, OV, st);
 }
 
@@ -1261,6 +1300,12 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
       rc = narrow_n ? launch_halo<4, 8, 8, 64>(p, OV, st) : launch_halo<4, 8, 8>(p, OV, st);
     else
       rc = narrow_n ? launch_halo<8, 8, 4, 64>(p, OV, st) : launch_halo<8, 8, 4>(p, OV, st);
+    if (rc) return rc;
+    return conv_finish(p, OV, st);
+  }
+  if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && !p.out_mask &&
+      halo_small_grid(p.gx, p.gy, p.gz, Cout)) {
+    rc = halo_small_grid(p.gx, p.gy, p.gz, Cout) == 1 ? launch_halo<10, 10, 4, 64>(p, OV, st) : launch_halo<6, 12, 4, 64>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
@@ -1658,6 +1703,8 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     const int shape = halo_brick_shape(gx, gy, gz);
     const int bx = shape == 2 ? 8 : 4, by = shape == 0 ? 4 : 8, bz = shape == 0 ? 16 : (shape == 1 ? 8 : 4);
     splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, (g_tune_halo_narrow && Cout <= 64) ? 64 : 128), Cin / BK);
+  } else if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && halo_small_grid(gx, gy, gz, Cout)) {
+    splitk = halo_splitk(halo_small_grid(gx, gy, gz, Cout), ceil_div(Cout, 64), Cin / BK);
   } else {
     ConvParams p = {};
     p.transposed = transposed; p.taps = transposed ? 1 : ksize * ksize * ksize;

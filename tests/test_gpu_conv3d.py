@@ -23,6 +23,9 @@ CASES = [  # Cin, Cout, grid, ksize, stride, transposed, residual, relu
     (64, 192, (17, 13, 16), 3, 1, False, True, True),     # partial bricks in x and y, Cout % 128 != 0
     (32, 256, (40, 40, 16), 3, 1, False, True, True),     # config-2 volume, 200 workgroups, no split-K
     (128, 28, (20, 20, 8), 3, 1, False, False, False),    # the head's fused centerness/reg/cls conv: 28 of 128 tile columns live
+    # whole-grid bricks of the coarsest scales (>= 512 output channels): 400 voxels on 512 MFMA rows, 2 x 288 on 384
+    (64, 512, (10, 10, 4), 3, 1, False, True, True),
+    (96, 576, (12, 12, 4), 3, 1, False, True, 2),
 ]
 
 
