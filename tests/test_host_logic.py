@@ -246,3 +246,23 @@ def test_bench_refuses_to_mislabel_the_gpu_count():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_committed_bench_lines_follow_from_their_own_fields():
+    """Every bench line of this round under profiles/ is self-consistent (tools/roofline_check.py): `roofline.frac` =
+    achieved / peak with achieved = algorithmic bytes (or issued FLOPs) / the measured average launch time, `path_roofline.frac`
+    = floor / measured time per scene, `value` = scenes per second of the timed region -- no hand-edited or stale field."""
+    import glob
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from roofline_check import check_line
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")))
+    assert len(files) >= 8
+    for f in files:
+        line = open(f).readline()
+        d = json.loads(line)
+        assert check_line(d, os.path.basename(f)) == []
+        assert d["self_check"]["mismatching"] == 0
