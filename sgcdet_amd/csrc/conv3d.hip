@@ -1517,6 +1517,252 @@ __global__ __launch_bounds__(WM * 128) void conv3d_wgrad_bf16x3_kernel(const Wgr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Halo form of the weight gradient for the 3x3x3 stride-1 layers (round 4).  The tile kernel above is one GEMM per tap: every
+// (co, ci) tile streams dy AND the tap-shifted x for its voxel range, so a layer moves 27 x both operands (2.8 GB for
+// 256 -> 256 at 40x40x16) and splits each element to bf16 27 times: it runs at 0.29 PF/s, bound by its staging.  Here a
+// workgroup owns 32 output channels x 32 input channels and ALL 27 taps and walks bricks of 8 x 8 x 4 voxels: per brick it
+// stages dy [256 voxels][32 co] and the brick's x halo [10 x 10 x 6 rows][32 ci] ONCE (split hi / lo once) and multiplies
+// them 27 times.  Both operands are stored voxel-major -- rows = the reduction index -- which is what the MFMA wants
+// transposed: the fragments come out of LDS through ds_read_b64_tr_b16 (a 4-row x 16-column block per 16 lanes, delivered
+// column-major; lane map checked in tools/probe/tr16_probe.hip), so no transposing pass exists anywhere.  Wave w owns taps
+// w, w + 8, w + 16 (, w + 24): its accumulators are 3 - 4 tiles of 32 x 32; the dy fragments of a k-step (16 voxels) are read
+// once per wave and reused for its taps, the x fragments of a tap are the same LDS rows shifted by the tap's halo offset --
+// with the k-steps unrolled every read is one register + an immediate.  The brick range is split over workgroups; partial
+// sums go through the workspace and wgrad_reduce_kernel (fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------
+struct WgradHaloParams {
+  const float *x, *dy;
+  float *out;               // dW [27][Cout][Cin] (one split) or the workspace [splits][27][Cout][Cin]
+  int Cin, Cout;
+  int gx, gy, gz;           // grid (input = output grid: stride 1, padding 1)
+  int nbricks, bricks_per_split;
+};
+
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+// MT = 32-channel dy tiles per workgroup (2: 64 output channels x 32 input channels; every x fragment feeds two MFMA triples,
+// which halves the LDS reads per MFMA -- with MT = 1 the k-loop is LDS-read-bound).  Rows are stored with NO padding (pitch
+// 32 bf16 = 16 banks): a transposed read touches 4 rows x 16 banks per half-wave and the staging writes are contiguous, both
+// conflict-free; a padded pitch of 40 makes row q = 3 alias row 0.
+// NW = waves per workgroup.  4: one wave per SIMD with 512 registers -- 7 taps x MT accumulator tiles, the next brick's rows
+// and BOTH operands double-buffered in registers; the fragment reads of tap t + 1 are issued before the MFMAs of tap t, so
+// the LDS latency sits under the matrix pipe inside one wave (with two lockstep waves per SIMD and read -> wait -> MFMA
+// order the two times ADD: measured 40 k cycles per brick against 21.5 k of MFMA issue).
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradHaloParams p) {
+  constexpr int BX = 8, BY = 8, BZ = 4, HY = BY + 2, HZ = BZ + 2, HROWS = (BX + 2) * HY * HZ;      // 600 halo rows
+  constexpr int PW = 32;                                                                            // row pitch (bf16)
+  constexpr int NT = 64 * NW;
+  constexpr int X_PLANE = HROWS * PW, D_IMG = 256 * PW, D_PLANE = MT * D_IMG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+  __bf16 *X_hi = reinterpret_cast<__bf16 *>(smem_g), *X_lo = X_hi + X_PLANE;
+  __bf16 *D_hi = X_lo + X_PLANE, *D_lo = D_hi + D_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroups go to the 8 XCDs round-robin by linear id: all (co, ci) tiles of one brick range are put on ONE XCD, so the
+  // 2.3 x (Cout / 64) re-reads of x and the (Cin / 32) re-reads of dy are L2 hits (without it a 256 -> 256 layer at
+  // 40 x 40 x 16 pulls 455 MB through the fabric and the loads, not the MFMAs, set the time).  gridDim.z is the split count
+  // rounded up to a multiple of 8; the surplus workgroups leave at once.
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tiles = gridDim.x * gridDim.y;
+  int split = blockIdx.z, tile = blockIdx.x + gridDim.x * blockIdx.y;
+  if ((gridDim.z & 7) == 0) { split = (lin & 7) + 8 * ((lin >> 3) / tiles); tile = (lin >> 3) % tiles; }
+  const int co0 = (tile % gridDim.x) * (32 * MT), ci0 = (tile / gridDim.x) * 32;
+  const int b_lo = split * p.bricks_per_split, b_hi = min(p.nbricks, b_lo + p.bricks_per_split);
+  if (b_lo >= b_hi) return;
+  const int nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
+  constexpr unsigned OOB = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.gx * p.gy * p.gz * p.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.dy), 0, (int)(unsigned)((int64_t)p.gx * p.gy * p.gz * p.Cout * 4), 0x00020000);
+  // staging assignment: the x halo goes slab by slab (hx = 0 .. 9; a slab is 60 rows (hy, hz) x 8 float4, APASS passes of
+  // RPP rows), dy voxel-row by voxel-row: the x index of every global load is wave-uniform, (y, z) are per-thread constants
+  constexpr int APASS = 512 / NT, RPP = HY * HZ / APASS, NA = (BX + 2) * APASS;
+  constexpr int DCH = 8 * MT, DROWS = NT / DCH, ND = 256 / DROWS;      // float4 per dy row, dy rows per pass, passes
+  const int a_r = tid >> 3, a_c4 = tid & 7;
+  const int d_r = tid / DCH, d_c4 = tid % DCH;
+  float4 ra[NA], rd[ND];
+  auto load_brick = [&](int b) {
+    const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
+    const int X0 = bi * BX, Y0 = bj * BY, Z0 = bk * BZ;
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      const int row = j * RPP + a_r, y = Y0 + row / HZ - 1, z = Z0 + row % HZ - 1;
+      const bool in = a_r < RPP && y >= 0 && y < p.gy && z >= 0 && z < p.gz;
+      const unsigned voff = in ? ((unsigned)(y * p.gz + z) * (unsigned)p.Cin + ci0 + a_c4 * 4) * 4u : OOB;
+#pragma unroll
+      for (int i = 0; i < BX + 2; ++i) {
+        const int x = X0 + i - 1;                                                       // uniform
+        const bool xin = x >= 0 && x < p.gx;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? voff : OOB, xin ? x * p.gy * p.gz * p.Cin * 4 : 0, 0);
+        ra[i * APASS + j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int vx = i * DROWS + d_r, r = vx % (BY * BZ);                               // voxel of the brick, its (by, bz) row
+      const int x = X0 + vx / (BY * BZ), y = Y0 + r / BZ, z = Z0 + r % BZ;
+      const bool xin = x < p.gx, in = y < p.gy && z < p.gz;
+      const unsigned voff = in && xin ? ((unsigned)(y * p.gz + z) * (unsigned)p.Cout + co0 + d_c4 * 4) * 4u : OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dr, voff, xin ? x * p.gy * p.gz * p.Cout * 4 : 0, 0);
+      rd[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    }
+  };
+  auto split_store = [&](const float4 &r, __bf16 *hi, __bf16 *lo, int o) {
+    const float v[4] = {r.x, r.y, r.z, r.w};
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 hb = (__bf16)v[e];
+      h[e] = hb;
+      l[e] = (__bf16)(v[e] - (float)hb);
+    }
+    *reinterpret_cast<bf16x4 *>(hi + o) = h;
+    *reinterpret_cast<bf16x4 *>(lo + o) = l;
+  };
+  auto store_brick = [&]() {
+    if (a_r < RPP) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        split_store(ra[i], X_hi, X_lo, ((i / APASS) * (HY * HZ) + (i % APASS) * RPP + a_r) * PW + a_c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      split_store(rd[i], D_hi, D_lo, (d_c4 >> 3) * D_IMG + (i * DROWS + d_r) * PW + (d_c4 & 7) * 4);
+  };
+  // transposed fragment reads: group g = lane >> 4 reads the block of rows (8 (g >> 1) + q [+ 4]) x columns 16 (g & 1) .. + 15;
+  // lane 4 q + pp of the group supplies the address of row q, columns 4 pp .. 4 pp + 3
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g4 >> 1;
+  const int d_lane = (8 * hh + q) * PW + 16 * (g4 & 1) + 4 * pp;           // + (16 s + 4 rd) * PW
+  const int x_lane = (12 * hh + q) * PW + 16 * (g4 & 1) + 4 * pp;          // + (row(s, rd) + toff(tap)) * PW, see below
+  auto tr4 = [&](const __bf16 *ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v *)ptr);
+  };
+  auto frag = [&](const __bf16 *p0, const __bf16 *p1) {
+    const bf16x4v a = tr4(p0), b = tr4(p1);
+    bf16x8 f;
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    return f;
+  };
+  constexpr int TPW = (27 + NW - 1) / NW;              // tap slots of a wave: taps wid + NW t; the last slot may be empty
+  const bool has_last = wid + NW * (TPW - 1) < 27;     // wave-uniform
+  int toff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tt = (t < TPW - 1 || has_last) ? wid + NW * t : 13;
+    toff[t] = (((tt / 9 - 1) * HY + ((tt / 3) % 3 - 1)) * HZ + (tt % 3 - 1)) * PW;
+  }
+  f32x16 acc[TPW][MT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[t][m][k] = 0.f;
+
+  bf16x8 ah[2][MT], al[2][MT], bh[2], bl[2];
+  auto read_A = [&](int s, int buf) {                  // dy fragments of k-step s: voxels 16 s .. 16 s + 15 of the brick
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const __bf16 *dp = D_hi + m * D_IMG + d_lane + 16 * s * PW;
+      ah[buf][m] = frag(dp, dp + 4 * PW);
+      al[buf][m] = frag(dp + D_PLANE, dp + D_PLANE + 4 * PW);
+    }
+  };
+  auto read_B = [&](int s, int t, int buf) {           // x fragments of k-step s shifted by tap slot t
+    // halo row of voxel 16 s + 8 hh + 4 rd + q:  ((s >> 1) + 1) * 60 + (4 (s & 1) + 2 hh + rd + 1) * 6 + q + 1
+    const int r0 = ((s >> 1) + 1) * (HY * HZ) + (4 * (s & 1) + 1) * HZ + 1;
+    const __bf16 *xp = X_hi + x_lane + r0 * PW + toff[t];
+    bh[buf] = frag(xp, xp + HZ * PW);
+    bl[buf] = frag(xp + X_PLANE, xp + X_PLANE + HZ * PW);
+  };
+
+  constexpr int WSKIP = SGC_WGRAD_SKIP;
+  if (WSKIP & 6) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ah[i][m] = al[i][m] = bf16x8{};
+      bh[i] = bl[i] = bf16x8{};
+    }
+  }
+  if (WSKIP & 16) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) rd[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  }
+  if (b_lo < b_hi && !(WSKIP & 16)) load_brick(b_lo);
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();                                   // every wave is done with the previous brick's images
+    if (!(WSKIP & 8) || b == b_lo) store_brick();
+    __syncthreads();
+    if (b + 1 < b_hi && !(WSKIP & 16)) load_brick(b + 1);               // lands under this brick's MFMAs
+    constexpr bool PIPE = NW == 4;                     // one wave per SIMD: fragments of the next tap read ahead of the MFMAs
+    if (PIPE) {
+      if (!(WSKIP & 4)) read_A(0, 0);
+      if (!(WSKIP & 2)) read_B(0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (!PIPE && !(WSKIP & 4)) read_A(s, 0);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int cur = PIPE ? (s * TPW + t) & 1 : 0, ab = PIPE ? s & 1 : 0;
+        if (!PIPE) {
+          if (!(WSKIP & 2) && (t < TPW - 1 || has_last)) read_B(s, t, 0);
+        } else if (t + 1 < TPW) {
+          if (!(WSKIP & 2)) read_B(s, t + 1, cur ^ 1);
+        } else if (s + 1 < 16) {
+          if (!(WSKIP & 4)) read_A(s + 1, (s + 1) & 1);
+          if (!(WSKIP & 2)) read_B(s + 1, 0, cur ^ 1);
+        }
+        if (WSKIP & 1) {                               // keep the reads alive
+          asm volatile("" ::"v"(bh[cur]), "v"(bl[cur]));
+          if (t == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[ab][m]), "v"(al[ab][m]));
+          }
+        } else if (t < TPW - 1 || has_last) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ab][m], bh[cur], acc[t][m], 0, 0, 0);
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ab][m], bl[cur], acc[t][m], 0, 0, 0);
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ab][m], bh[cur], acc[t][m], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // a lane owns column ci = lane & 31 of its 32 x 32 tiles: the 32 lanes of a half-wave store 128 contiguous bytes of one dW row
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (t == TPW - 1 && !has_last) break;
+    float *out = p.out + ((int64_t)split * 27 + (wid + NW * t)) * p.Cout * p.Cin;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 32 * m + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        out[(int64_t)co * p.Cin + ci0 + (lane & 31)] = acc[t][m][k];
+      }
+  }
+}
+
+namespace sgc { int g_tune_wgrad_halo = 1; }       // 1: 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the halo form, 0: tile kernel
+static bool wgrad_halo_geometry(WgradHaloParams &h, int &mt, int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
+  if (!g_tune_wgrad_halo || ksize != 3 || stride != 1 || (Cin & 31) || (Cout & 31)) return false;
+  if ((int64_t)ix * iy * iz * (Cin > Cout ? Cin : Cout) * 4 >= 0xfffffff0ll - 65536) return false;
+  h.Cin = Cin; h.Cout = Cout; h.gx = ix; h.gy = iy; h.gz = iz;
+  h.nbricks = ceil_div(ix, 8) * ceil_div(iy, 8) * ceil_div(iz, 4);
+  if ((int64_t)h.nbricks * 256 > (int64_t)2 * ix * iy * iz) return false;       // bricks mostly padding: the tile kernel wins
+  mt = (Cout & 63) ? 1 : 2;
+  const int tiles = (Cout / (32 * mt)) * (Cin / 32);
+  const int splits = std::max(1, std::min(h.nbricks / 4, ceil_div(256, tiles)));      // fill the chip; >= 4 bricks per workgroup
+  h.bricks_per_split = ceil_div(h.nbricks, splits);
+  return true;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4 *__restrict__ ws, float4 *__restrict__ dw, int64_t n4, int splits) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 a = ws[i];
@@ -1547,6 +1793,9 @@ static int wgrad_geometry(WgradParams &p, int ix, int iy, int iz, int Cin, int C
   const int tiles = ceil_div(Cout, 128) * ceil_div(Cin, 128) * p.taps;
   int splits = 1;
   while (tiles * splits < 512 && p.ksteps / (splits * 2) >= 16) splits *= 2;     // fill the chip twice over; >= 16 K-steps per split
+  // a layer that still leaves most CUs idle (the nn.Linear layers of a level: 800 rows, 4 tiles) is bound by the load latency
+  // of its serial K-steps (~2.5 us each), not by flops: spread the steps over idle CUs, down to 3 per workgroup
+  while (tiles * splits < 256 && p.ksteps / (splits * 2) >= 3) splits *= 2;
   p.steps_per_split = ceil_div(p.ksteps, splits);
   p.splits = ceil_div(p.ksteps, p.steps_per_split);
   p.ax = 32 / (p.oy * p.oz); p.by = (32 % (p.oy * p.oz)) / p.oz; p.cz = 32 % p.oz;
@@ -1556,6 +1805,12 @@ static int wgrad_geometry(WgradParams &p, int ix, int iy, int iz, int Cin, int C
 }
 
 extern "C" int64_t sgc_conv3d_wgrad_workspace_floats(int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
+  WgradHaloParams h = {};
+  int mt = 1;
+  if (wgrad_halo_geometry(h, mt, ix, iy, iz, Cin, Cout, ksize, stride)) {
+    const int splits = ceil_div(h.nbricks, h.bricks_per_split);
+    return splits > 1 ? (int64_t)splits * 27 * Cout * Cin : 0;
+  }
   WgradParams p = {};
   if (wgrad_geometry(p, ix, iy, iz, Cin, Cout, ksize, stride)) return -1;
   return p.splits > 1 ? (int64_t)p.splits * p.taps * Cout * Cin : 0;
@@ -1567,6 +1822,39 @@ extern "C" int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *d
   if (!x || !dy || !dw) return set_error(SGC_EINVAL, "sgc_conv3d_wgrad_bf16x3: null pointer");
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace_or_null) & 15)
     return set_error(SGC_EINVAL, "sgc_conv3d_wgrad_bf16x3: pointers must be 16-byte aligned");
+  hipStream_t st0 = (hipStream_t)stream;
+  WgradHaloParams h = {};
+  int mt = 1;
+  if (wgrad_halo_geometry(h, mt, ix, iy, iz, Cin, Cout, ksize, stride)) {
+    int splits = ceil_div(h.nbricks, h.bricks_per_split);
+    const int64_t n27 = (int64_t)27 * Cout * Cin;
+    if (splits > 1 && !(workspace_or_null && workspace_floats >= splits * n27)) { splits = 1; h.bricks_per_split = h.nbricks; }
+    h.x = x; h.dy = dy; h.out = splits > 1 ? workspace_or_null : dw;
+    const size_t smem_h = (size_t)2 * (600 + 256 * mt) * 32 * sizeof(uint16_t);
+    static std::atomic<uint64_t> attr_h[4] = {};
+    const dim3 grid_h(Cout / (32 * mt), Cin / 32, splits >= 8 ? (splits + 7) / 8 * 8 : splits);
+    const int nw = g_tune_wgrad_halo == 2 ? 4 : 8;
+#define SGC_WGRAD_HALO(MT_, NW_, SLOT)                                                                             \
+    do {                                                                                                           \
+      ensure_dynamic_lds((const void *)conv3d_wgrad_halo_kernel<MT_, NW_>, (int)smem_h, attr_h[SLOT]);            \
+      hipLaunchKernelGGL((conv3d_wgrad_halo_kernel<MT_, NW_>), grid_h, dim3(64 * NW_), smem_h, st0, h);            \
+    } while (0)
+    if (mt == 2 && nw == 4) SGC_WGRAD_HALO(2, 4, 0);
+    else if (mt == 2) SGC_WGRAD_HALO(2, 8, 1);
+    else if (nw == 4) SGC_WGRAD_HALO(1, 4, 2);
+    else SGC_WGRAD_HALO(1, 8, 3);
+#undef SGC_WGRAD_HALO
+    int rch = check_launch("conv3d_wgrad_halo_kernel");
+    if (rch) return rch;
+    if (splits > 1) {
+      const int64_t n4 = n27 / 4;
+      const int g = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st0, reinterpret_cast<const float4 *>(workspace_or_null),
+                         reinterpret_cast<float4 *>(dw), n4, splits);
+      rch = check_launch("wgrad_reduce_kernel");
+    }
+    return rch;
+  }
   WgradParams p = {};
   int rc = wgrad_geometry(p, ix, iy, iz, Cin, Cout, ksize, stride);
   if (rc) return rc;

@@ -13,6 +13,9 @@
 //                     buffer [workgroup < 8][wave parity 2][iteration < 32][8] x uint64 (sgc_diag_rows_stamp_buffer)
 #pragma once
 
+#if !defined(SGC_WGRAD_SKIP)
+#define SGC_WGRAD_SKIP 0   // timing builds of the halo weight gradient: 1 no MFMAs, 2 no x-fragment reads, 4 no dy-fragment reads,
+#endif                     // 8 no split + LDS stores of a brick, 16 no global loads (tools/wgrad_skip.py; results are garbage)
 #if !defined(SGC_HALO_SKIP)
 #define SGC_HALO_SKIP 0
 #endif

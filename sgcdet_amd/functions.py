@@ -187,7 +187,10 @@ class ChannelsLastConv3dFunction(Function):
                 g = up.view(-1, g.shape[1])
             dx, _ = ops.conv3d_cl_bf16x3(g.contiguous(), hi, lo, grid, ksize, 1)
         if ctx.needs_input_grad[1]:
-            dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), grid, ksize, stride)        # [taps, cout_p, cin]
+            # the halo form of the weight gradient wants 32-channel dy tiles: the head's 3 x 3 x 3 convolutions (Cout = 28 ...)
+            # get four zero columns rather than the per-tap tile kernel
+            mult = 32 if ksize == 3 and stride == 1 and cin % 32 == 0 else 4
+            dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, mult).contiguous(), grid, ksize, stride)     # [taps, cout_p, cin]
             dw = ops.unpack_conv_wgrad(dwk, weight.shape).to(weight.dtype)
         return dx, dw, None, None, None
 

@@ -188,7 +188,26 @@ WGRAD_CASES = [  # Cin, Cout, grid, ksize, stride
     (64, 132, (6, 4, 4), 1, 2),
     (96, 64, (8, 6, 4), 2, 2),             # ConvTranspose3d(2, 2) with the roles exchanged
     (36, 4, (5, 5, 3), 1, 1),
+    (64, 96, (9, 10, 5), 3, 1),            # halo form with one 32-channel dy tile per workgroup, ragged bricks in x, y and z
+    (32, 64, (17, 8, 4), 3, 1),            # halo form, a single (co, ci) tile, three bricks in one workgroup
 ]
+
+
+def test_wgrad_halo_forms_agree_with_the_tile_kernel(oracle_ops, gpu_ops):
+    """The halo form of the weight gradient (tuning key wgrad_halo: 1 = eight waves, 2 = four waves with read-ahead) and the
+    per-tap tile kernel (0) against the oracle on one layer whose brick range is split over workgroups."""
+    Cin, Cout, grid = 64, 128, (24, 17, 9)
+    g = torch.Generator().manual_seed(11)
+    V = grid[0] * grid[1] * grid[2]
+    x, dy = torch.randn(V, Cin, generator=g), torch.randn(V, Cout, generator=g)
+    ref = oracle_ops.conv3d_wgrad_bf16x3(x, dy, grid, 3, 1)
+    try:
+        for mode in (0, 1, 2):
+            gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", mode)
+            got = gpu_ops.conv3d_wgrad_bf16x3(x.cuda(), dy.cuda(), grid, 3, 1).cpu()
+            assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), mode
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", 1)
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)

@@ -15,6 +15,7 @@ ap.add_argument("--no-neck", action="store_true", help="stop at the volume (view
 ap.add_argument("--profile", action="store_true", help="print the 25 kernels with the most GPU time (torch.profiler)")
 ap.add_argument("--input-layout", default="nchw", choices=["nchw", "nhwc"],
                 help="memory layout of the feature / depth maps handed to the path (nhwc = what plugin/fpn.py produces)")
+ap.add_argument("--wgrad-layers", action="store_true", help="list every weight-gradient call of one step: shapes, kernel form, time")
 ap.add_argument("--glue", action="store_true", help="attribute the torch glue ops (copy / add / fill / sum / mul ...) to source lines of this package")
 args = ap.parse_args()
 w = workload(args.workload)
@@ -58,6 +59,29 @@ if args.profile:
     rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
     for e in rows:
         print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
+if args.wgrad_layers:
+    from sgcdet_amd import ext
+    ops = ext.ops()
+    calls, orig = [], ops.conv3d_wgrad_bf16x3
+
+    def spy(x, dy, grid, ksize, stride=1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(x, dy, grid, ksize, stride)
+        e1.record()
+        calls.append((x.shape[1], dy.shape[1], tuple(grid), ksize, stride, e0, e1))
+        return out
+    ops.conv3d_wgrad_bf16x3 = spy
+    step()
+    torch.cuda.synchronize()
+    ops.conv3d_wgrad_bf16x3 = orig
+    tot = 0.0
+    for cin, cout, grid, k, st, e0, e1 in calls:
+        us = e0.elapsed_time(e1) * 1e3
+        tot += us
+        gf = 2.0 * grid[0] * grid[1] * grid[2] / st ** 3 * cin * cout * k ** 3 * (1 if k != 2 else 1) / 1e9
+        print(f"{us:8.1f} us  Cin {cin:5d} Cout {cout:5d} grid {str(grid):16s} k {k} s {st}  {gf:6.2f} GF", file=sys.stderr)
+    print(f"{len(calls)} weight-gradient calls, {tot / 1e3:.2f} ms", file=sys.stderr)
 if args.glue:
     import collections
     from torch.profiler import profile, ProfilerActivity
