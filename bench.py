@@ -43,9 +43,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400,
-                    help="timed scenes (default 400 = 0.8 s at config 2: the clocks need about a second of load to settle)")
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps; a step is one batch of --scenes-per-step scenes (default 100 x 4 scenes = 0.8 s at "
+                         "config 2: the clocks need about a second of load to settle)")
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--scenes-per-step", type=int, default=0,
+                    help="scenes in the batch one step processes (default: one per stream, i.e. --streams; 1 without streams)")
     ap.add_argument("--prewarm", type=float, default=1.0,
                     help="seconds of untimed scenes during setup, before the --warmup steps (clock settle; 0 = none)")
     ap.add_argument("--workload", default="cfg2_scannet")
@@ -331,7 +334,9 @@ def main():
                 step(i)
                 i += 1
             torch.cuda.synchronize()
-    for i in range(args.warmup):
+    spp = args.scenes_per_step if args.scenes_per_step > 0 else max(1, args.streams)   # scenes per step: one per stream
+    n_timed = args.steps * spp
+    for i in range(args.warmup * spp):
         step(i)
     torch.cuda.synchronize()
     if dist is not None:
@@ -343,7 +348,7 @@ def main():
     # for CUs the other scenes occupy (round 3's strict-fp32 line read 855 us for a 92-us gather that way).  They are taken in a
     # separate eager pass, one scene at a time, right after the timed region.
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(n_timed):              # args.steps batches of spp scenes, batch k = scenes k * spp .. k * spp + spp - 1
         step(i)
     torch.cuda.synchronize()
     if dist is not None:
@@ -356,7 +361,7 @@ def main():
     #      bf16 MFMA work runs at boost clocks) ----
     sustained = None
     if args.sustain > 0:
-        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)) + 1)
+        n_sus = max(n_timed, int(args.sustain / max(elapsed / n_timed, 1e-6)) + 1)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -367,8 +372,8 @@ def main():
         if dist is not None:
             dist.barrier()
         el_s = sgc_dist.max_over_ranks(time.perf_counter() - ts, device=device)
-        sustained = dict(value=round(world * n_sus / el_s, 3), unit="scenes/sec", steps=n_sus, seconds=round(el_s, 2),
-                         ms_per_step=round(el_s / n_sus * 1e3, 3))
+        sustained = dict(value=round(world * n_sus / el_s, 3), unit="scenes/sec", scenes=n_sus, seconds=round(el_s, 2),
+                         ms_per_scene=round(el_s / n_sus * 1e3, 3))
     # same scenes, same kernels launched eagerly right after the timed region, one scene at a time: the deformable
     # gather is bracketed by HIP events on its launch stream (its pair count comes back to the host here)
     scene_graph_was, det.scene_graph = det.scene_graph, False
@@ -377,12 +382,12 @@ def main():
     ops.event_names = None if args.breakdown else PATH_KERNELS
     calls0 = ops.n_calls
     with torch.no_grad():
-        for i in range(max(6, min(args.steps, 20))):         # one scene at a time: the kernel on its own
+        for i in range(max(6, min(n_timed, 20))):         # one scene at a time: the kernel on its own
             feats, dpt, metas = scenes[i % n_scenes]
             det.forward_features(feats, metas, dpt)
             torch.cuda.synchronize()
     log, ops.event_log = ops.event_log, None
-    lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(args.steps, 20))
+    lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(n_timed, 20))
     det.scene_graph, det.use_graph = scene_graph_was, tail_graph
     roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                      "after the timed region (the timed region replays hipGraphs, which cannot carry events, with several "
@@ -492,7 +497,7 @@ def main():
     #      8 TB/s + the matrix work actually issued at the dense MFMA peak, per scene, over the measured time per scene ----
     path_roofline = None
     if per_kernel:
-        n_e = max(6, min(args.steps, 20))
+        n_e = max(6, min(n_timed, 20))
         gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"])
                    for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
         gbytes = 0.0
@@ -509,14 +514,14 @@ def main():
         floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         path_roofline = dict(gather_mb_algorithmic=round(gbytes / 1e6, 1), gemm_gflop_algorithmic=round(gemm / 1e9, 1),
                              gemm_gflop_issued=round(issued / 1e9, 1), floor_ms_per_scene=round(floor_ms, 3),
-                             frac=round(floor_ms / (elapsed / args.steps * 1e3) * world, 4),
+                             frac=round(floor_ms / (elapsed / n_timed * 1e3) * world, 4),
                              note="floor = compulsory bytes of the geometry-sample + deformable gathers at 8 TB/s + the MFMA work "
                                   "issued by every convolution / Linear (3 bf16 products per fp32 multiply-add) at the dense MFMA "
                                   "peak, per scene; frac = floor / measured time per scene (timed region)")
     if args.breakdown and rank == 0:
         for name, items in sorted(per_kernel.items(), key=lambda kv: -sum(t for t, _ in kv[1])):
             tot = sum(t for t, _ in items)
-            print(f"  {name:32s} {len(items):5d} launches  {tot * 1e3 / args.steps:8.3f} ms/step", file=sys.stderr)
+            print(f"  {name:32s} {len(items):5d} launches  {tot * 1e3 / max(6, min(n_timed, 20)):8.3f} ms/scene", file=sys.stderr)
             shapes = {}
             for t, m in items:                                   # per-shape split of the GEMM / convolution entry points
                 if "Cin" in m:
@@ -524,7 +529,7 @@ def main():
                     a = shapes.setdefault(key, [0, 0.0])
                     a[0] += 1
                     a[1] += t
-            n_eager = max(6, min(args.steps, 20))
+            n_eager = max(6, min(n_timed, 20))
             for key, (cnt, tt) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                 V, Cin, Cout, taps, OV = key
                 gf = 2.0 * (taps or 1) * Cin * Cout * (OV or V) / 1e9
@@ -538,7 +543,7 @@ def main():
         set_conv_mode("f32")
         sg, ug = det.scene_graph, det.use_graph
         det.scene_graph, det.use_graph = False, True        # eager view transform + hipGraph tail (no device-count GEMMs in f32)
-        n_f32 = max(4, min(args.steps, 10))
+        n_f32 = max(4, min(n_timed, 10))
         for i in range(max(3, n_scenes * max(1, args.streams))):     # every (scene, stream) tail graph of this mode captured before the clock starts
             step(i)
         torch.cuda.synchronize()
@@ -559,7 +564,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "scenes/sec (40-view ScanNet volume) at 1/2/4/8 MI355X; mAP@0.25 parity",
-            "value": round(world * args.steps / elapsed, 3),
+            "value": round(world * n_timed / elapsed, 3),
             "unit": "scenes/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -584,7 +589,7 @@ def main():
                                    f"{'/'.join(f'{f.shape[-2]}x{f.shape[-1]}' for f in scenes[0][0][:3])}, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
-                       "input_layout": args.input_layout, "scenes_per_step_per_gpu": 1, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
+                       "input_layout": args.input_layout, "scenes_per_step_per_gpu": spp, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
                        "launch_geometry": ("throughput (row GEMMs on half the CUs; fewer reduction splits in the layers with few voxels; "
                                             "conv_plan.set_throughput_mode)"
                                            if args.streams > 1 else "latency"),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick state check: conv + kernel + module GPU tests, the default bench (driver command: 20 steps) and the 400-step line
+# quick state check: conv + kernel + module GPU tests, the driver command (20 steps x 4 scenes) and the default line (100 steps x 4 scenes)
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04_bench_20.json 2> gpurun_out/r04_bench_20.err; echo rc $?

@@ -14,7 +14,8 @@ def check_line(d, name="line"):
     def near(a, b, rel, what):
         if not (abs(a - b) <= rel * max(abs(a), abs(b), 1e-12)):
             bad.append(f"{name}: {what}: {a} vs {b}")
-    near(d["value"], d["n_gpus"] * 1e3 / d["ms_per_step"], 2e-3, "value vs n_gpus / ms_per_step")
+    spp = d.get("config", {}).get("scenes_per_step_per_gpu", 1)          # scenes in the batch one step processes
+    near(d["value"], d["n_gpus"] * spp * 1e3 / d["ms_per_step"], 2e-3, "value vs n_gpus * scenes_per_step / ms_per_step")
     r = d.get("roofline")
     if r:
         near(r["frac"], r["achieved"] / r["peak"], 2e-3, "roofline.frac vs achieved / peak")
@@ -27,10 +28,10 @@ def check_line(d, name="line"):
         near(m["achieved"], m["algorithmic_gflop"] * nprod / (m["avg_launch_us"] * 1e-6) / 1e3, 1e-2, "roofline_mfma.achieved vs issued GFLOP / avg_launch_us")
     p = d.get("path_roofline")
     if p:
-        near(p["frac"], p["floor_ms_per_scene"] / d["ms_per_step"] * d["n_gpus"], 5e-3, "path_roofline.frac vs floor / ms_per_step")
+        near(p["frac"], p["floor_ms_per_scene"] / (d["ms_per_step"] / spp) * d["n_gpus"], 5e-3, "path_roofline.frac vs floor / ms per scene")
     s = d.get("sustained")
     if s:
-        near(s["value"], d["n_gpus"] * 1e3 / s["ms_per_step"], 2e-3, "sustained.value vs 1 / ms_per_step")
+        near(s["value"], d["n_gpus"] * 1e3 / s.get("ms_per_scene", s.get("ms_per_step")), 2e-3, "sustained.value vs 1 / ms per scene")
     return bad
 
 
