@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_SUSTAINED_TFLOPS = 1847.0   # dense bf16 MFMA rate the chip holds at its power limit on random operands (profiles/r04_mfma_power.txt)
 
 
 def parse():
@@ -512,9 +513,15 @@ def main():
         bf = args.conv_mode != "f32"
         issued = gemm * (3 if args.conv_mode == "bf16x3" else 1)
         floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
+        # the same floor with the matrix pipe priced at what it SUSTAINS under the package power limit on non-zero data
+        # (1847 TFLOP/s at 1.89 GHz / 1.31 kW, tools/probe/mfma_power.hip, profiles/r04_mfma_power.txt; the 2.5 PFLOP/s of
+        # the guide is reached with all-zero operands only: 2461 TFLOP/s at 2.39 GHz / 0.85 kW) -- reported beside `frac`
+        floor_pl_ms = (issued / ((MFMA_SUSTAINED_TFLOPS if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         path_roofline = dict(gather_mb_algorithmic=round(gbytes / 1e6, 1), gemm_gflop_algorithmic=round(gemm / 1e9, 1),
                              gemm_gflop_issued=round(issued / 1e9, 1), floor_ms_per_scene=round(floor_ms, 3),
                              frac=round(floor_ms / (elapsed / n_timed * 1e3) * world, 4),
+                             frac_of_power_limited_floor=round(floor_pl_ms / (elapsed / n_timed * 1e3) * world, 4),
+                             mfma_sustained_tflops=MFMA_SUSTAINED_TFLOPS,
                              note="floor = compulsory bytes of the geometry-sample + deformable gathers at 8 TB/s + the MFMA work "
                                   "issued by every convolution / Linear (3 bf16 products per fp32 multiply-add) at the dense MFMA "
                                   "peak, per scene; frac = floor / measured time per scene (timed region)")
