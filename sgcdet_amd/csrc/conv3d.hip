@@ -822,6 +822,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     }
   };
   auto mfma_half = [&](const Frag &f) {
+    if constexpr ((SGC_HALO_SKIP & 32) != 0) {          // timing / power builds: everything but the MFMAs
+#pragma unroll
+      for (int i = 0; i < RT; ++i) asm volatile("" ::"v"(f.ah[i]), "v"(f.al[i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(f.bh[j]), "v"(f.bl[j]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -1545,10 +1552,9 @@ typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 // which halves the LDS reads per MFMA -- with MT = 1 the k-loop is LDS-read-bound).  Rows are stored with NO padding (pitch
 // 32 bf16 = 16 banks): a transposed read touches 4 rows x 16 banks per half-wave and the staging writes are contiguous, both
 // conflict-free; a padded pitch of 40 makes row q = 3 alias row 0.
-// NW = waves per workgroup.  4: one wave per SIMD with 512 registers -- 7 taps x MT accumulator tiles, the next brick's rows
-// and BOTH operands double-buffered in registers; the fragment reads of tap t + 1 are issued before the MFMAs of tap t, so
-// the LDS latency sits under the matrix pipe inside one wave (with two lockstep waves per SIMD and read -> wait -> MFMA
-// order the two times ADD: measured 40 k cycles per brick against 21.5 k of MFMA issue).
+// NW = waves per workgroup (8: two per SIMD, 256 registers each).  Fragments are read right before their MFMAs: with two waves
+// per SIMD the partner's MFMAs cover the LDS round trip (a one-wave-per-SIMD variant of THIS form with read-ahead was
+// built and spilled 168 registers; the double-buffered kernel below is the form that uses one wave per SIMD).
 template <int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradHaloParams p) {
   constexpr int BX = 8, BY = 8, BZ = 4, HY = BY + 2, HZ = BZ + 2, HROWS = (BX + 2) * HY * HZ;      // 600 halo rows
@@ -1660,7 +1666,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[t][m][k] = 0.f;
 
-  bf16x8 ah[2][MT], al[2][MT], bh[2], bl[2];
+  bf16x8 ah[1][MT], al[1][MT], bh[1], bl[1];
   auto read_A = [&](int s, int buf) {                  // dy fragments of k-step s: voxels 16 s .. 16 s + 15 of the brick
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -1680,11 +1686,8 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
   constexpr int WSKIP = SGC_WGRAD_SKIP;
   if (WSKIP & 6) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) ah[i][m] = al[i][m] = bf16x8{};
-      bh[i] = bl[i] = bf16x8{};
-    }
+    for (int m = 0; m < MT; ++m) ah[0][m] = al[0][m] = bf16x8{};
+    bh[0] = bl[0] = bf16x8{};
   }
   if (WSKIP & 16) {
 #pragma unroll
@@ -1698,37 +1701,24 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
     if (!(WSKIP & 8) || b == b_lo) store_brick();
     __syncthreads();
     if (b + 1 < b_hi && !(WSKIP & 16)) load_brick(b + 1);               // lands under this brick's MFMAs
-    constexpr bool PIPE = NW == 4;                     // one wave per SIMD: fragments of the next tap read ahead of the MFMAs
-    if (PIPE) {
-      if (!(WSKIP & 4)) read_A(0, 0);
-      if (!(WSKIP & 2)) read_B(0, 0, 0);
-    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      if (!PIPE && !(WSKIP & 4)) read_A(s, 0);
+      if (!(WSKIP & 4)) read_A(s, 0);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        const int cur = PIPE ? (s * TPW + t) & 1 : 0, ab = PIPE ? s & 1 : 0;
-        if (!PIPE) {
-          if (!(WSKIP & 2) && (t < TPW - 1 || has_last)) read_B(s, t, 0);
-        } else if (t + 1 < TPW) {
-          if (!(WSKIP & 2)) read_B(s, t + 1, cur ^ 1);
-        } else if (s + 1 < 16) {
-          if (!(WSKIP & 4)) read_A(s + 1, (s + 1) & 1);
-          if (!(WSKIP & 2)) read_B(s + 1, 0, cur ^ 1);
-        }
+        if (!(WSKIP & 2) && (t < TPW - 1 || has_last)) read_B(s, t, 0);
         if (WSKIP & 1) {                               // keep the reads alive
-          asm volatile("" ::"v"(bh[cur]), "v"(bl[cur]));
+          asm volatile("" ::"v"(bh[0]), "v"(bl[0]));
           if (t == 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[ab][m]), "v"(al[ab][m]));
+            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[0][m]), "v"(al[0][m]));
           }
         } else if (t < TPW - 1 || has_last) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ab][m], bh[cur], acc[t][m], 0, 0, 0);
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ab][m], bl[cur], acc[t][m], 0, 0, 0);
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ab][m], bh[cur], acc[t][m], 0, 0, 0);
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0][m], bh[0], acc[t][m], 0, 0, 0);
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0][m], bl[0], acc[t][m], 0, 0, 0);
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0][m], bh[0], acc[t][m], 0, 0, 0);
           }
         }
       }
@@ -1749,13 +1739,241 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
   }
 }
 
-namespace sgc { int g_tune_wgrad_halo = 1; }       // 1: 3x3x3 stride-1 layers with Cin, Cout multiples of 32 on the halo form, 0: tile kernel
+// ---------------------------------------------------------------------------------------------
+// Double-buffered form of the halo weight gradient (round 4, late).  Timing builds of the form above (SGC_WGRAD_SKIP) show its
+// phases ADD: MFMAs alone 145 us, + fragment reads 186, + the split / LDS stores of a brick and its global loads 238 -- between
+// the two barriers of a brick nothing multiplies.  Here a brick is 4 x 8 x 4 voxels (halo 6 x 10 x 6 = 360 rows), BOTH LDS images
+// exist twice (154 KB), four waves (one per SIMD, 512 registers) own 7 taps x MT tiles each, and the staging of brick b + 1 is
+// cut into four pieces that ride behind the MFMAs of k-steps 0 - 3 of brick b (register -> split -> LDS), the global loads of
+// brick b + 2 behind k-steps 4 - 7: ONE barrier per brick, the matrix pipe never waits for staging.  Fragments of the next tap
+// are read ahead of the MFMAs of the current one.  Same sums in the same order per workgroup as the form above is NOT
+// guaranteed (bricks differ): the two forms agree to fp32 summation order.
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void conv3d_wgrad_halo2_kernel(const WgradHaloParams p) {
+  constexpr int BX = 4, BY = 8, BZ = 4, NVB = BX * BY * BZ, HY = BY + 2, HZ = BZ + 2, HROWS = (BX + 2) * HY * HZ;   // 360 halo rows
+  constexpr int PW = 32, NT = 256, NW = 4, KS = NVB / 16;
+  constexpr int X_PLANE = HROWS * PW, D_IMG = NVB * PW, D_PLANE = MT * D_IMG;
+  constexpr int X_BUF = 2 * X_PLANE, D_BUF = 2 * D_PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_g2[];
+  __bf16 *Xb = reinterpret_cast<__bf16 *>(smem_g2);             // [2 buffers][hi | lo][HROWS][32]
+  __bf16 *Db = Xb + 2 * X_BUF;                                  // [2 buffers][hi | lo][MT][128][32]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tiles = gridDim.x * gridDim.y;
+  int split = blockIdx.z, tile = blockIdx.x + gridDim.x * blockIdx.y;
+  if ((gridDim.z & 7) == 0) { split = (lin & 7) + 8 * ((lin >> 3) / tiles); tile = (lin >> 3) % tiles; }   // a brick range on one XCD
+  const int co0 = (tile % gridDim.x) * (32 * MT), ci0 = (tile / gridDim.x) * 32;
+  const int b_lo = split * p.bricks_per_split, b_hi = min(p.nbricks, b_lo + p.bricks_per_split);
+  if (b_lo >= b_hi) return;
+  const int nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
+  constexpr unsigned OOB = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.gx * p.gy * p.gz * p.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.dy), 0, (int)(unsigned)((int64_t)p.gx * p.gy * p.gz * p.Cout * 4), 0x00020000);
+  // staging: x halo slab by slab (hx = 0 .. 5; 60 rows x 8 float4 in two passes of 30 rows), dy in passes of DROWS voxels
+  constexpr int RPP = HY * HZ / 2, NA = (BX + 2) * 2;
+  constexpr int DCH = 8 * MT, DROWS = NT / DCH, ND = NVB / DROWS;
+  constexpr int NCH = NA + ND;                                    // float4 chunks of a brick per thread: x halo, then dy
+  static_assert(NCH <= 4 * 6, "one chunk per tap slot 0 .. 5 of four k-steps");
+  // threads 240 .. 255 have no halo row of their own in a pass: they repeat row RPP - 1 (same loads, same values, same LDS
+  // address -- a benign duplicate) so that the staging code has no predicate and can be interleaved with the MFMAs
+  const int a_r = min(tid >> 3, RPP - 1), a_c4 = tid & 7;
+  const int d_r = tid / DCH, d_c4 = tid % DCH;
+  float4 rs[NCH];
+  int X0 = 0, Y0 = 0, Z0 = 0;                                     // origin of the brick being loaded
+  unsigned a_voff[2];
+  auto load_begin = [&](int b) {
+    const int bk = b % nbz, bj = (b / nbz) % nby, bi = b / (nbz * nby);
+    X0 = bi * BX; Y0 = bj * BY; Z0 = bk * BZ;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * RPP + a_r, y = Y0 + row / HZ - 1, z = Z0 + row % HZ - 1;
+      const bool in = y >= 0 && y < p.gy && z >= 0 && z < p.gz;
+      a_voff[j] = in ? ((unsigned)(y * p.gz + z) * (unsigned)p.Cin + ci0 + a_c4 * 4) * 4u : OOB;
+    }
+  };
+  auto load_chunk = [&](int c) {
+    u32x4 v;
+    if (c < NA) {
+      const int slab = c >> 1, j = c & 1;
+      const int x = X0 + slab - 1;                                                      // uniform
+      const bool xin = x >= 0 && x < p.gx;
+      v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? a_voff[j] : OOB, xin ? x * p.gy * p.gz * p.Cin * 4 : 0, 0);
+    } else {
+      const int vx = (c - NA) * DROWS + d_r, r = vx % (BY * BZ);
+      const int x = X0 + vx / (BY * BZ), y = Y0 + r / BZ, z = Z0 + r % BZ;
+      const bool in = x < p.gx && y < p.gy && z < p.gz;
+      const unsigned voff = in ? ((unsigned)((x * p.gy + y) * p.gz + z) * (unsigned)p.Cout + co0 + d_c4 * 4) * 4u : OOB;
+      v = __builtin_amdgcn_raw_buffer_load_b128(dr, voff, 0, 0);
+    }
+    rs[c] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  };
+  auto store_chunk = [&](int c, int buf) {
+    const float v[4] = {rs[c].x, rs[c].y, rs[c].z, rs[c].w};
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 hb = (__bf16)v[e];
+      h[e] = hb;
+      l[e] = (__bf16)(v[e] - (float)hb);
+    }
+    __bf16 *hi;
+    int plane;
+    if (c < NA) {
+      hi = Xb + buf * X_BUF + ((c >> 1) * (HY * HZ) + (c & 1) * RPP + a_r) * PW + a_c4 * 4;
+      plane = X_PLANE;
+    } else {
+      hi = Db + buf * D_BUF + (d_c4 >> 3) * D_IMG + ((c - NA) * DROWS + d_r) * PW + (d_c4 & 7) * 4;
+      plane = D_PLANE;
+    }
+    *reinterpret_cast<bf16x4 *>(hi) = h;
+    *reinterpret_cast<bf16x4 *>(hi + plane) = l;
+  };
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g4 >> 1;
+  const int d_lane = (8 * hh + q) * PW + 16 * (g4 & 1) + 4 * pp;
+  const int x_lane = (12 * hh + q) * PW + 16 * (g4 & 1) + 4 * pp;
+  auto tr4 = [&](const __bf16 *ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v *)ptr);
+  };
+  auto frag = [&](const __bf16 *p0, const __bf16 *p1) {
+    const bf16x4v a = tr4(p0), b = tr4(p1);
+    bf16x8 f;
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    return f;
+  };
+  constexpr int TPW = 7;                               // tap slots of a wave: taps wid + 4 t; wave 3's last slot is empty
+  const bool has_last = wid + NW * (TPW - 1) < 27;     // wave-uniform
+  int toff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tt = (t < TPW - 1 || has_last) ? wid + NW * t : 13;
+    toff[t] = (((tt / 9 - 1) * HY + ((tt / 3) % 3 - 1)) * HZ + (tt % 3 - 1)) * PW;
+  }
+  f32x16 acc[TPW][MT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[t][m][k] = 0.f;
+  bf16x8 ah[2][MT], al[2][MT], bh[3], bl[3];      // x fragments two tap slots ahead of their MFMAs
+  auto read_A = [&](int s, int fb, int buf) {
+    const __bf16 *D_hi = Db + buf * D_BUF;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const __bf16 *dp = D_hi + m * D_IMG + d_lane + 16 * s * PW;
+      ah[fb][m] = frag(dp, dp + 4 * PW);
+      al[fb][m] = frag(dp + D_PLANE, dp + D_PLANE + 4 * PW);
+    }
+  };
+  auto read_B = [&](int s, int t, int fb, int buf) {
+    const int r0 = ((s >> 1) + 1) * (HY * HZ) + (4 * (s & 1) + 1) * HZ + 1;
+    const __bf16 *xp = Xb + buf * X_BUF + x_lane + r0 * PW + toff[t];
+    bh[fb] = frag(xp, xp + HZ * PW);
+    bl[fb] = frag(xp + X_PLANE, xp + X_PLANE + HZ * PW);
+  };
+
+  constexpr int WSKIP = SGC_WGRAD_SKIP;                // timing builds only (diag.hpp); 0 in the product
+  if (WSKIP & 6) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bh[i] = bl[i] = bf16x8{};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ah[i][m] = al[i][m] = bf16x8{};
+  }
+  load_begin(b_lo);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) load_chunk(c);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) store_chunk(c, 0);
+  load_begin(min(b_lo + 1, b_hi - 1));
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) load_chunk(c);
+  __syncthreads();
+  for (int b = b_lo; b < b_hi; ++b) {
+    const int buf = (b - b_lo) & 1;
+    // the last brick(s) of the range restage themselves once more (into the buffer nobody reads): no condition, so the
+    // staging chunks below sit in the same straight-line regions as the MFMAs
+    const int b_load = min(b + 2, b_hi - 1);
+    // slot n = s * TPW + t of the brick; its x fragments live in ring entry n % 3 and are read two slots ahead
+    if (!(WSKIP & 4)) read_A(0, 0, buf);
+    if (!(WSKIP & 2)) { read_B(0, 0, 0, buf); read_B(0, 1, 1, buf); }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int n = s * TPW + t, n2 = n + 2, s2 = n2 / TPW, t2 = n2 % TPW;
+        if (s2 < KS) {
+          if (t2 == 0 && !(WSKIP & 4)) read_A(s2, s2 & 1, buf);        // dy fragments of the next k-step, two slots ahead as well
+          if (!(WSKIP & 2)) read_B(s2, t2, n2 % 3, buf);
+        }
+        // one staging chunk per tap slot 0 .. 5: k-steps 0 - 3 split + store brick b + 1 (loaded during the previous brick),
+        // k-steps 4 - 7 load brick b + 2.  The chunk's ~30 vector instructions go BETWEEN this slot's MFMAs (group fences):
+        // a lone wave per SIMD issues in order, so a lump of staging code after the MFMAs would leave the pipe idle
+        const int ch = (s & 3) * 6 + t;
+        const bool stage = t < 6 && ch < NCH;
+        if (WSKIP & 1) {
+          asm volatile("" ::"v"(bh[n % 3]), "v"(bl[n % 3]));
+          if (t == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[s & 1][m]), "v"(al[s & 1][m]));
+          }
+        } else if (t < TPW - 1 || has_last) {
+          // product-major: consecutive MFMAs go to different accumulators (the group fences below keep this order)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s & 1][m], bh[n % 3], acc[t][m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][m], bl[n % 3], acc[t][m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][m], bh[n % 3], acc[t][m], 0, 0, 0);
+        }
+        if (stage) {
+          if (s < 4) { if (!(WSKIP & 8)) store_chunk(ch, buf ^ 1); }
+          else if (!(WSKIP & 16)) { if (ch == 0) load_begin(b_load); load_chunk(ch); }
+        }
+        // issue order of the slot: after every MFMA a share of the slot's LDS reads (they feed the slot after next) and of
+        // the staging chunk's vector work.  A wave issues in order and an LDS instruction holds the issue port for several
+        // cycles: four reads in a row, or a lump of staging code, let the matrix pipe run dry behind the one MFMA in flight
+        {
+          const bool two = s2 < KS && t2 == 0, st = stage && s < 4;       // 4 + 4 MT reads in the slot / a store chunk in it
+#pragma unroll
+          for (int i = 0; i < 3 * MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (two) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (st) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+          if (st) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                   // publishes brick b + 1; every wave is done reading brick b
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (t == TPW - 1 && !has_last) break;
+    float *out = p.out + ((int64_t)split * 27 + (wid + NW * t)) * p.Cout * p.Cin;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int co = co0 + 32 * m + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+        out[(int64_t)co * p.Cin + ci0 + (lane & 31)] = acc[t][m][k];
+      }
+  }
+}
+
+namespace sgc { int g_tune_wgrad_halo = 1; }       // 3x3x3 stride-1 layers with Cin, Cout multiples of 32: 1 double-buffered halo form, 2 single-buffered, 0 tile kernel
 static bool wgrad_halo_geometry(WgradHaloParams &h, int &mt, int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride) {
   if (!g_tune_wgrad_halo || ksize != 3 || stride != 1 || (Cin & 31) || (Cout & 31)) return false;
   if ((int64_t)ix * iy * iz * (Cin > Cout ? Cin : Cout) * 4 >= 0xfffffff0ll - 65536) return false;
   h.Cin = Cin; h.Cout = Cout; h.gx = ix; h.gy = iy; h.gz = iz;
-  h.nbricks = ceil_div(ix, 8) * ceil_div(iy, 8) * ceil_div(iz, 4);
-  if ((int64_t)h.nbricks * 256 > (int64_t)2 * ix * iy * iz) return false;       // bricks mostly padding: the tile kernel wins
+  const bool db = g_tune_wgrad_halo == 1;                                       // double-buffered form (default): bricks of 4 x 8 x 4
+  h.nbricks = ceil_div(ix, db ? 4 : 8) * ceil_div(iy, 8) * ceil_div(iz, 4);
+  if ((int64_t)h.nbricks * (db ? 128 : 256) > (int64_t)2 * ix * iy * iz) return false;       // bricks mostly padding: the tile kernel wins
   mt = (Cout & 63) ? 1 : 2;
   const int tiles = (Cout / (32 * mt)) * (Cin / 32);
   const int splits = std::max(1, std::min(h.nbricks / 4, ceil_div(256, tiles)));      // fill the chip; >= 4 bricks per workgroup
@@ -1833,17 +2051,22 @@ extern "C" int sgc_conv3d_wgrad_bf16x3(const float *x, const float *dy, float *d
     const size_t smem_h = (size_t)2 * (600 + 256 * mt) * 32 * sizeof(uint16_t);
     static std::atomic<uint64_t> attr_h[4] = {};
     const dim3 grid_h(Cout / (32 * mt), Cin / 32, splits >= 8 ? (splits + 7) / 8 * 8 : splits);
-    const int nw = g_tune_wgrad_halo == 2 ? 4 : 8;
-#define SGC_WGRAD_HALO(MT_, NW_, SLOT)                                                                             \
-    do {                                                                                                           \
-      ensure_dynamic_lds((const void *)conv3d_wgrad_halo_kernel<MT_, NW_>, (int)smem_h, attr_h[SLOT]);            \
-      hipLaunchKernelGGL((conv3d_wgrad_halo_kernel<MT_, NW_>), grid_h, dim3(64 * NW_), smem_h, st0, h);            \
-    } while (0)
-    if (mt == 2 && nw == 4) SGC_WGRAD_HALO(2, 4, 0);
-    else if (mt == 2) SGC_WGRAD_HALO(2, 8, 1);
-    else if (nw == 4) SGC_WGRAD_HALO(1, 4, 2);
-    else SGC_WGRAD_HALO(1, 8, 3);
-#undef SGC_WGRAD_HALO
+    if (g_tune_wgrad_halo == 1) {                      // double-buffered bricks of 4 x 8 x 4 (default)
+      const size_t smem2 = (size_t)2 * 2 * (360 + 128 * mt) * 32 * sizeof(uint16_t);
+      if (mt == 2) {
+        ensure_dynamic_lds((const void *)conv3d_wgrad_halo2_kernel<2>, (int)smem2, attr_h[0]);
+        hipLaunchKernelGGL(conv3d_wgrad_halo2_kernel<2>, grid_h, dim3(256), smem2, st0, h);
+      } else {
+        ensure_dynamic_lds((const void *)conv3d_wgrad_halo2_kernel<1>, (int)smem2, attr_h[1]);
+        hipLaunchKernelGGL(conv3d_wgrad_halo2_kernel<1>, grid_h, dim3(256), smem2, st0, h);
+      }
+    } else if (mt == 2) {                              // single-buffered bricks of 8 x 8 x 4, eight waves
+      ensure_dynamic_lds((const void *)conv3d_wgrad_halo_kernel<2, 8>, (int)smem_h, attr_h[2]);
+      hipLaunchKernelGGL((conv3d_wgrad_halo_kernel<2, 8>), grid_h, dim3(512), smem_h, st0, h);
+    } else {
+      ensure_dynamic_lds((const void *)conv3d_wgrad_halo_kernel<1, 8>, (int)smem_h, attr_h[3]);
+      hipLaunchKernelGGL((conv3d_wgrad_halo_kernel<1, 8>), grid_h, dim3(512), smem_h, st0, h);
+    }
     int rch = check_launch("conv3d_wgrad_halo_kernel");
     if (rch) return rch;
     if (splits > 1) {

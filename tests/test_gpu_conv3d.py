@@ -194,7 +194,7 @@ WGRAD_CASES = [  # Cin, Cout, grid, ksize, stride
 
 
 def test_wgrad_halo_forms_agree_with_the_tile_kernel(oracle_ops, gpu_ops):
-    """The halo form of the weight gradient (tuning key wgrad_halo: 1 = eight waves, 2 = four waves with read-ahead) and the
+    """The halo form of the weight gradient (tuning key wgrad_halo: 1 = double-buffered bricks of 4 x 8 x 4, the default; 2 = single-buffered bricks of 8 x 8 x 4) and the
     per-tap tile kernel (0) against the oracle on one layer whose brick range is split over workgroups."""
     Cin, Cout, grid = 64, 128, (24, 17, 9)
     g = torch.Generator().manual_seed(11)

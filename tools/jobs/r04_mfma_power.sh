@@ -7,8 +7,8 @@ try:
     c=json.load(sys.stdin)['card0']; print('   smi:', c.get('sclk clock speed:'), c.get('Current Socket Graphics Package Power (W)'), 'W')
 except Exception as e: print('   smi: n/a')
 "; sleep 0.4; done; }
-for mode in "1 5 2" "0 5 2" "1 5 1"; do
-  echo "== mfma_power $mode (random data?, seconds, waves per SIMD)"
+for mode in ${MODES:-"1 5 2" "0 5 2" "1 5 1"}; do
+  echo "== mfma_power $mode (random data?, seconds, waves per SIMD, operand order)"
   smi 12 & S=$!
   timeout 60 tools/probe/mfma_power $mode
   wait $S

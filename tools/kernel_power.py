@@ -71,7 +71,7 @@ sc, sh = torch.ones(256, device="cuda"), torch.zeros(256, device="cuda")
 wh, wl = ops.split_bf16(wt)
 flop = 2.0 * V * 256 * 256 * 27 * 3
 for nm, o in libs.items():
-    o.lib.call("sgc_set_tuning", b"halo_stagger", 1 if nm == "halo" else 0)
+    o.lib.call("sgc_set_tuning", b"halo_stagger", 1)
     measure(nm + " 256->256 40x40x16", lambda o=o: o.conv3d_cl_bf16x3(x, wh, wl, g, 3, 1, False, sc, sh, None, True), flop=flop)
 ops.lib.call("sgc_set_tuning", b"halo_stagger", 0)
 measure("halo lockstep form", lambda: ops.conv3d_cl_bf16x3(x, wh, wl, g, 3, 1, False, sc, sh, None, True), flop=flop)

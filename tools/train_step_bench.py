@@ -56,7 +56,10 @@ if args.profile:
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
+    allrows = prof.key_averages()
+    print(f"device time of all kernels: {sum(e.device_time_total for e in allrows) / 2e3:.2f} ms/step over "
+          f"{sum(e.count for e in allrows) // 2} launches (wall {ms_step} ms/step)", file=sys.stderr)
+    rows = sorted(allrows, key=lambda e: -e.device_time_total)[:25]
     for e in rows:
         print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
 if args.wgrad_layers:

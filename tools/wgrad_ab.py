@@ -1,4 +1,4 @@
-"""Weight-gradient kernels A/B: the halo form (tuning key wgrad_halo = 1: eight waves per workgroup, the product; 2: four waves with read-ahead) against the per-tap tile kernel (0) on the 3x3x3
+"""Weight-gradient kernels A/B: the halo form (tuning key wgrad_halo = 1: double-buffered bricks of 4 x 8 x 4, the product; 2: single-buffered bricks of 8 x 8 x 4) against the per-tap tile kernel (0) on the 3x3x3
 stride-1 layer shapes of the neck, alternated in one process; checks that both agree.  Usage: python tools/wgrad_ab.py"""
 import json
 import os
@@ -36,5 +36,5 @@ for Cin, Cout, grid in SHAPES:
     fl = 2.0 * V * Cin * Cout * 27 * 3
     m0, m1 = sorted(t[0])[len(t[0]) // 2], sorted(t[1])[len(t[1]) // 2]
     err = float((res[0] - res[1]).abs().max() / res[0].abs().max())
-    print(json.dumps(dict(Cin=Cin, Cout=Cout, grid=grid, tile_us=round(m0, 1), halo_us=round(m1, 1), halo4w_us=round(sorted(t[2])[len(t[2]) // 2], 1), ratio=round(m1 / m0, 3),
+    print(json.dumps(dict(Cin=Cin, Cout=Cout, grid=grid, tile_us=round(m0, 1), halo_us=round(m1, 1), halo_single_buffered_us=round(sorted(t[2])[len(t[2]) // 2], 1), ratio=round(m1 / m0, 3),
                           halo_frac_of_mfma_peak=round(fl / (m1 * 1e-6) / 2.5e15, 3), rel_diff=err)), flush=True)

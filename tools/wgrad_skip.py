@@ -1,4 +1,4 @@
-"""Where the halo weight-gradient kernel spends its time (256 -> 256 at 40x40x16): the product library against timing
+"""Where the halo weight-gradient kernel (SGC_WGRAD_HALO=1 double-buffered, 2 single-buffered) spends its time (256 -> 256 at 40x40x16): the product library against timing
 builds with parts removed (SGC_WGRAD_SKIP, csrc/diag.hpp; their results are garbage):
   for m in 1 2 4 6 7 8 16 24 30; do bash tools/diag_build.sh wskip$m conv3d.hip -DSGC_WGRAD_SKIP=$m; done
 Alternated rounds in one process; the first round is the cold one."""
@@ -11,6 +11,8 @@ from sgcdet_amd import ext
 libs = {"product": ext.ops()}
 for f in sorted(glob.glob(os.path.join(ROOT, "tools/diag/libsgc_wskip*.so")), key=lambda f: int(re.findall(r"wskip(\d+)", f)[0])):
     libs[re.findall(r"(wskip\d+)", f)[0]] = TensorOps(Library(f), "cuda")
+for o in libs.values():
+    o.lib.call("sgc_set_tuning", b"wgrad_halo", int(os.environ.get("SGC_WGRAD_HALO", "1")))
 Cin = Cout = int(os.environ.get("C", "256")); g = (40, 40, 16)
 x = torch.randn(g[0] * g[1] * g[2], Cin, device="cuda")
 dy = torch.randn(g[0] * g[1] * g[2], Cout, device="cuda")
