@@ -49,6 +49,7 @@ print(json.dumps(out, indent=1))
 PY
 timeout 600 python tools/train_step_bench.py --steps 10 --profile > gpurun_out/r04_train_step.json 2> gpurun_out/r04_train_step_kernels.raw; echo train rc $?
 grep -v "amdgpu.ids\|warn\|Warning" gpurun_out/r04_train_step_kernels.raw | cut -c1-200 > gpurun_out/r04_train_step_kernels.txt; rm -f gpurun_out/r04_train_step_kernels.raw
+timeout 300 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_wgrad_ab.txt
 timeout 300 python tools/halo_knob_ab.py halo_stagger 0,1 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_halo_schedule_ab.log
 timeout 300 python tools/halo_fixed_cost.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_halo_fixed_cost.txt
 timeout 300 python tools/small_grid_ab.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_small_grid_ab.txt
