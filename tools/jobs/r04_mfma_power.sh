@@ -1,6 +1,7 @@
 #!/bin/bash
 # the matrix pipe under the package power limit: back-to-back bf16 MFMAs on every SIMD, clocks and power sampled beside it
 mkdir -p gpurun_out
+[ -x tools/probe/mfma_power ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe/mfma_power.hip -o tools/probe/mfma_power 2>/dev/null
 smi() { for i in $(seq 1 $1); do /opt/rocm/bin/rocm-smi --showclocks --showpower --json 2>/dev/null | python3 -c "
 import json,sys
 try:
