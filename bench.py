@@ -449,17 +449,18 @@ def main():
         finest = [(t, m) for t, m in dg if m["n_pairs"] * m["C"] + m["N"] * m["H"] * m["W"] * m["C"] >= 0.5 * big]
         tiled_finest = "bin" in finest[0][1]
         t_avg = sum(t for t, _ in finest) / len(finest)
-        # bf16 storage mode: the value map costs 2 bytes per element, everything else stays fp32
+        # bf16 storage mode: the value map and the depth maps cost 2 bytes per element, everything else stays fp32
         b_avg = sum(algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"])
                     - (4 - m.get("value_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["C"]
+                    - (4 - m.get("depth_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["D"]
                     for _, m in finest) / len(finest)
         achieved = b_avg / t_avg / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
         traffic, traffic_source = None, None
-        pmc_name = ("r03_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
+        pmc_name = ("r04_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
-        if args.workload == "cfg2_scannet" and args.views in (None, 40) and os.path.exists(pmc_file):
+        if args.workload == "cfg2_scannet" and args.views in (None, 40) and args.storage == "f32" and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
             traffic_source = (f"offline PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, "
                               f"FETCH_SIZE doubled per the gfx950 correction), profiles/{pmc_name}; NOT measured in this run")
@@ -506,7 +507,8 @@ def main():
             for _, m in items:
                 if name in ("sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled"):
                     gbytes += algorithmic_bytes(m["N"], m["H"] * m["W"], m["C"], m["D"], m["M"], m["P"], m["n_pairs"]) \
-                        - (4 - m.get("value_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["C"]
+                        - (4 - m.get("value_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["C"] \
+                        - (4 - m.get("depth_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["D"]
                 elif name == "sgc_pairs_geometry_sample":     # raw map + depth map + (u, v, z) per pair + output (B_gs)
                     gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * (12 + m["C"] * 4)
         gbytes /= n_e
@@ -581,13 +583,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("bf16 (opt-in reduced precision: every convolution / Linear with operands rounded to bfloat16, one MFMA product, "
-                      "fp32 accumulate" + ("; value map of the gather stored in bfloat16" if args.storage == "bf16" else "") +
+                      "fp32 accumulate" + ("; value map and depth maps of the gather stored in bfloat16" if args.storage == "bf16" else "") +
                       "; NOT parity-exact, not the headline)" if args.conv_mode == "bf16" else
                       "fp16 (opt-in reduced precision: every convolution / Linear with operands rounded to IEEE half -- saturated at "
                       "+-65504 --, one v_mfma_f32_32x32x16_f16 product, fp32 accumulate"
-                      + ("; value map of the gather stored in bfloat16" if args.storage == "bf16" else "") +
+                      + ("; value map and depth maps of the gather stored in bfloat16" if args.storage == "bf16" else "") +
                       "; NOT parity-exact, not the headline)" if args.conv_mode == "fp16" else
-                      "bf16 storage (value map of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
+                      "bf16 storage (value map and depth maps of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
                       if args.storage == "bf16" else
                       "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)"),
             "data": "synthetic",

@@ -51,7 +51,7 @@ extern "C" {
 /* Bumped whenever the argument list of an EXISTING entry point changes (a stale prebuilt .so is then rejected at load
  * instead of being called with shifted arguments).  1 -> 2: sgc_project_points gained `sel`, sgc_nchw_to_nhwc_crop gained
  * `step` (round 2).  New entry points do not bump it: a missing symbol already fails the load. */
-#define SGC_ABI_VERSION 3
+#define SGC_ABI_VERSION 4
 
 typedef void *sgc_stream_t; /* hipStream_t */
 
@@ -273,7 +273,9 @@ int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int 
  *   value_hm [N][M][S][Cm]          value_proj output as written by sgc_linear_rows_headmajor_bf16x3: fp32, or -- with
  *                                   value_bf16 != 0, the opt-in bf16 STORAGE mode -- bfloat16 (half the map bytes and
  *                                   half the LDS per window; taps are widened to fp32, accumulation and output fp32)
- *   dist     [N][S][D]
+ *   dist     [N][S][D]              depth distributions: fp32, or -- ABI version 4 -- bfloat16 TOO when value_bf16 != 0
+ *                                   (the storage mode covers both maps: BASELINE.json config #5's reduced-precision twin,
+ *                                   TU/multi_scale_3ddeformable_attn_function.py:353-428, casts value and value_dpt_dist)
  *   pair_ref / bin_offset           from sgc_bin_pairs with the same (H, W, bin_w, bin_h)
  *   raw_hm   [n_pairs][M][P][4]     per (pair, head, point): (du, dv, dz, attention logit) -- the three Linear
  *                                   outputs of sgc_pairs_deform_gather's `raw`, columns permuted head-major; rows in
@@ -286,7 +288,7 @@ int64_t sgc_bin_pairs_workspace_bytes(int N, int Nq, int cap, int H, int W, int 
  * depth_in_lds != 0: the depth taps are served from an LDS copy of the camera's depth window as well (when it fits;
  * pays when many pairs share a bin).  D >= 2, H*W < 32767; the windows must fit 160 KB of LDS (sgc_tile_window
  * reports what would be staged).                                                                                 */
-int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const float *dist, const float *pair_ref,
+int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const void *dist, const float *pair_ref,
                                   const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
                                   float *out, int N, int H, int W, int M, int Cm, int D, int P,
                                   int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,

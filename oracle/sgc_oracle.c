@@ -696,25 +696,29 @@ int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_
 /* Same arithmetic as sgc_pairs_deform_gather (the reference kernels' order), operands head-major, pairs in the
  * binned order; the window parameters (bin / halo / head_shift) only choose what the GPU stages in LDS and cannot
  * change a result. */
-int sgc_pairs_deform_gather_tiled(const void *value_hm_any, int value_bf16, const float *dist, const float *pair_ref,
+int sgc_pairs_deform_gather_tiled(const void *value_hm_any, int value_bf16, const void *dist_any, const float *pair_ref,
                                   const int32_t *bin_offset, const float *raw_hm, const int32_t *head_shift_or_null,
                                   float *out, int N, int H, int W, int M, int Cm, int D, int P,
                                   int cam_stride_or_0, int bin_w, int bin_h, int halo_x, int halo_y,
                                   int max_shift_x, int max_shift_y, int depth_in_lds, sgc_stream_t stream) {
   (void)stream; (void)head_shift_or_null; (void)halo_x; (void)halo_y; (void)max_shift_x; (void)max_shift_y; (void)depth_in_lds;
-  if (!value_hm_any || !dist || !pair_ref || !bin_offset || !raw_hm || !out) return fail(SGC_EINVAL, "null pointer");
+  if (!value_hm_any || !dist_any || !pair_ref || !bin_offset || !raw_hm || !out) return fail(SGC_EINVAL, "null pointer");
   if (P > 64) return fail(SGC_EUNSUP, "P > 64");
   if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return fail(SGC_EINVAL, "cam_stride < H*W");
   const int64_t S = cam_stride_or_0 > 0 ? cam_stride_or_0 : (int64_t)H * W;
   const float *value_hm = (const float *)value_hm_any;
-  float *widened = NULL;
-  if (value_bf16) {          /* bf16 storage mode: the taps are the bf16 values widened to fp32 (exact) */
-    const int64_t n = (int64_t)N * M * S * Cm;
+  const float *dist = (const float *)dist_any;
+  float *widened = NULL, *dwidened = NULL;
+  if (value_bf16) {          /* bf16 storage mode: value map AND depth maps are bf16; the taps are widened to fp32 (exact) */
+    const int64_t n = (int64_t)N * M * S * Cm, nd = (int64_t)N * S * D;
     widened = (float *)malloc(sizeof(float) * (size_t)n);
-    if (!widened) return fail(SGC_EINVAL, "out of memory");
-    const uint16_t *h = (const uint16_t *)value_hm_any;
+    dwidened = (float *)malloc(sizeof(float) * (size_t)nd);
+    if (!widened || !dwidened) { free(widened); free(dwidened); return fail(SGC_EINVAL, "out of memory"); }
+    const uint16_t *h = (const uint16_t *)value_hm_any, *hd = (const uint16_t *)dist_any;
     for (int64_t i = 0; i < n; ++i) widened[i] = bf16_to_f32(h[i]);
+    for (int64_t i = 0; i < nd; ++i) dwidened[i] = bf16_to_f32(hd[i]);
     value_hm = widened;
+    dist = dwidened;
   }
   const int nb = ((W + bin_w - 1) / bin_w) * ((H + bin_h - 1) / bin_h);
   const int MC = M * Cm;
@@ -747,6 +751,7 @@ int sgc_pairs_deform_gather_tiled(const void *value_hm_any, int value_bf16, cons
     }
   }
   free(widened);
+  free(dwidened);
   return SGC_OK;
 }
 

@@ -76,7 +76,7 @@ INTROSPECTION = {
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
 }
 
-ABI_VERSION = 3      # == SGC_ABI_VERSION of include/sgcdet_amd.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 4      # == SGC_ABI_VERSION of include/sgcdet_amd.h (tests/test_abi_cpu.py compares the two)
 
 
 class SgcError(RuntimeError):

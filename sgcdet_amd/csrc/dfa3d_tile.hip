@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bin_place_kernel(const int32_t *__restric
 // ---------------------------------------------------------------------------------------------
 struct TileParams {
   const void *value;          // [N][M][S][CM] head-major, fp32 or bf16 (the kernel's VB template argument)
-  const float *dist;          // [N][S][D]
+  const void *dist;           // [N][S][D] fp32, or bf16 in the storage mode (VB = 2: the value map AND the depth maps are bfloat16)
   const float4 *pair_ref;     // [pairs] (u, v, zn, q bits) in (camera, bin) order
   const int32_t *bin_offset;  // [N*nb + 1]
   const float4 *raw;          // [pairs][M][P] x (du, dv, dz, logit)
@@ -276,8 +276,19 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   constexpr int CHB = 4 * VB;                                       // bytes of a 4-channel chunk
   const int buf_bytes = (npx + 1) * CM * VB;                        // window + one all-zero row
   unsigned char *val0 = tile_smem;
-  float *dep = reinterpret_cast<float *>(tile_smem + ((NBUF * buf_bytes + 15) & ~15));   // [dh][dw][D]
-  const float *dcam = p.dist + (int64_t)n * p.S * p.D;
+  // depth maps: fp32, or bfloat16 in the storage mode (widened by a shift: exact).  DB = bytes per depth value
+  constexpr int DB = VB == 2 ? 2 : 4;
+  const unsigned char *dep = tile_smem + ((NBUF * buf_bytes + 15) & ~15);                 // [dh][dw][D]
+  const unsigned char *dcam = reinterpret_cast<const unsigned char *>(p.dist) + (int64_t)n * p.S * p.D * DB;
+  auto depth_pair = [&](const unsigned char *q, float &a, float &b) {                      // two consecutive depth bins
+    if constexpr (DB == 4) {
+      const float2_u pr = *reinterpret_cast<const float2_u *>(q);
+      a = pr.x; b = pr.y;
+    } else {                                           // 2-byte aligned only: two 16-bit reads
+      a = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(q) << 16);
+      b = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short *>(q + 2) << 16);
+    }
+  };
   int xd0 = max(0, min(bx * p.bw - p.hx - p.smx, p.W - p.dw));
   int yd0 = max(0, min(by * p.bh - p.hy - p.smy, p.H - p.dh));
   if (p.HG == 1 && p.dw == p.tw && p.dh == p.th) {   // one head per workgroup: the depth window is the head's own value window
@@ -302,8 +313,8 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
   const int m_first = hg * p.HG;
   if (p.diag != 2) {
     if (DL)
-      lds_dma_rows<NW>(reinterpret_cast<const char *>(dcam + ((int64_t)yd0 * p.W + xd0) * p.D), (int64_t)p.W * p.D * 4, p.dh,
-                       p.dw * p.D * 4, reinterpret_cast<unsigned char *>(dep), wid, lane);
+      lds_dma_rows<NW>(reinterpret_cast<const char *>(dcam + ((int64_t)yd0 * p.W + xd0) * p.D * DB), (int64_t)p.W * p.D * DB, p.dh,
+                       p.dw * p.D * DB, const_cast<unsigned char *>(dep), wid, lane);
     fill_value(m_first, 0);
   }
   if (tid < NBUF * CV) {                                            // the zero rows (one 4-channel chunk per thread)
@@ -391,12 +402,12 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
           const int dx = cw - xd0, dy = ch - yd0;
           const bool din = ((unsigned)dx < (unsigned)p.dw) & ((unsigned)dy < (unsigned)p.dh);
           const int drow = __mul24(dy, p.dw) + dx;
-          const float *dp = dep + (__mul24(din ? drow : 0, p.D) + dbase);
-          ta[k] = dp[0]; tb[k] = dp[1];
+          const unsigned char *dp = dep + (__mul24(din ? drow : 0, p.D) + dbase) * DB;
+          if constexpr (DB == 4) { ta[k] = reinterpret_cast<const float *>(dp)[0]; tb[k] = reinterpret_cast<const float *>(dp)[1]; }
+          else depth_pair(dp, ta[k], tb[k]);
           need_g |= in3 & ok[k] & !din;
         } else {
-          const float2_u pr = *reinterpret_cast<const float2_u *>(dcam + (unsigned)(__mul24(pix[k], p.D) + dbase));
-          ta[k] = pr.x; tb[k] = pr.y;
+          depth_pair(dcam + (unsigned)(__mul24(pix[k], p.D) + dbase) * DB, ta[k], tb[k]);
         }
       }
       if (DL && __ballot(need_g)) {               // rare, wave-uniform: depth taps outside the staged depth window
@@ -406,8 +417,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
           const int dx = cw - xd0, dy = ch - yd0;
           const bool din = (unsigned)dx < (unsigned)p.dw && (unsigned)dy < (unsigned)p.dh;
           if (!din) {
-            const float2_u pr = *reinterpret_cast<const float2_u *>(dcam + (int64_t)pix[k] * p.D + dbase);
-            ta[k] = pr.x; tb[k] = pr.y;
+            depth_pair(dcam + ((int64_t)pix[k] * p.D + dbase) * DB, ta[k], tb[k]);
           }
         }
       }
@@ -582,7 +592,9 @@ static TileGeom tile_geometry(int H, int W, int Cm, int D, int bin_w, int bin_h,
   g.dw = one_head ? g.tw : (bin_w + 2 * (halo_x + smx) < W ? bin_w + 2 * (halo_x + smx) : W);
   g.dh = one_head ? g.th : (bin_h + 2 * (halo_y + smy) < H ? bin_h + 2 * (halo_y + smy) : H);
   g.dl = (g_tune_tile_depth_lds >= 0 ? g_tune_tile_depth_lds : depth_in_lds) != 0 && D % 4 == 0 && D >= 2;
-  const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * vb, dbuf = (size_t)g.dw * g.dh * D * 4;
+  const size_t db = vb == 2 ? 2 : 4;               // storage mode: bf16 depth maps beside the bf16 value map
+  const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * vb, dbuf = ((size_t)g.dw * g.dh * D * db + 15) & ~(size_t)15;
+  if ((g.dw * D * db) % 16) g.dl = false;          // the LDS-DMA deals 16-byte pieces of a row
   g.nbuf = g_tune_tile_nbuf == 2 ? 2 : 1;
   if (g.nbuf == 2 && 2 * vbuf + (g.dl ? dbuf : 0) > 160 * 1024) g.nbuf = 1;
   if (g.dl && g.nbuf * vbuf + dbuf > 160 * 1024) g.dl = false;       // depth taps from global memory instead
@@ -611,7 +623,7 @@ static int launch_tile(const TileParams &p, size_t smem, hipStream_t st) {
   return check_launch("dfa3d_fwd_tile_kernel");
 }
 
-extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const float *dist, const float *pair_ref,
+extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const void *dist, const float *pair_ref,
                                              const int32_t *bin_offset, const float *raw_hm,
                                              const int32_t *head_shift_or_null, float *out, int N, int H, int W, int M,
                                              int Cm, int D, int P, int cam_stride_or_0, int bin_w, int bin_h, int halo_x,

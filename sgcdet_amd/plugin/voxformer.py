@@ -56,7 +56,9 @@ def _ops():
 # depend on these numbers (tests/test_gpu_kernels.py::test_tiled_gather_against_oracle); they were chosen by
 # tools/tile_bench.py sweeps on MI355X.  ``min_pixels``: smaller maps keep the wave kernel.
 # ``storage``: "f32" (parity mode, the default) or "bf16" -- OPT-IN storage mode (BASELINE.json configs #2/#5): value_proj's
-# epilogue writes the head-major value map as bfloat16, the gather widens the taps and accumulates in fp32, outputs fp32.
+# epilogue writes the head-major value map as bfloat16 and the depth distributions are handed over as bfloat16 too (round 4; the
+# reference's fp16 twin casts both, TU/multi_scale_3ddeformable_attn_function.py:353-428); the gather widens the taps and
+# accumulates in fp32, outputs fp32.
 # Not parity-exact (one bf16 rounding of every value, bound stated in tests/test_gpu_kernels.py); never the headline.
 TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
                     cm32=dict(bin=(16, 22), halo=(3, 3), depth_in_lds=False),
@@ -366,7 +368,9 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 raw = gemm["raw_hm"](geo, count=pairs_cnt)
                 if not self.geo_residual:
                     del geo
-                per_pair = ops.pairs_deform_gather_tiled(value, dist, pc["pair_ref"], pc["bin_offset"], raw, H, W,
+                # the storage mode covers both maps: bf16 depth distributions beside the bf16 value map (one cast per level)
+                dist_g = dist.to(torch.bfloat16) if value.dtype == torch.bfloat16 else dist
+                per_pair = ops.pairs_deform_gather_tiled(value, dist_g, pc["pair_ref"], pc["bin_offset"], raw, H, W,
                                                          da.num_points, bw, bh, tiled["halo"][0], tiled["halo"][1],
                                                          head_shift=gemm["head_shift"], max_shift=gemm["max_shift"],
                                                          depth_in_lds=tiled["depth_in_lds"])

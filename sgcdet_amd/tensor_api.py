@@ -361,7 +361,9 @@ class TensorOps:
                     head_shift=head_shift, out=out)
         if value_hm.dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError("pairs_deform_gather_tiled: value_hm must be float32 or bfloat16 (bf16 storage mode)")
-        self._f32(dist=dist, pair_ref=pair_ref, raw_hm=raw_hm, out=out)
+        if dist.dtype != value_hm.dtype:     # the storage mode covers BOTH maps (sgcdet_amd.h, ABI version 4)
+            raise RuntimeError("pairs_deform_gather_tiled: dist must have value_hm's dtype (float32, or bfloat16 in the storage mode)")
+        self._f32(pair_ref=pair_ref, raw_hm=raw_hm, out=out)
         self._i32(bin_offset=bin_offset, head_shift=head_shift)
         N, M, S, Cm = value_hm.shape
         D = dist.shape[-1]
@@ -379,7 +381,7 @@ class TensorOps:
                    N, H, W, M, Cm, D, P, S, bin_w, bin_h, halo_x, halo_y, int(max_shift[0]), int(max_shift[1]),
                    int(bool(depth_in_lds)),
                    _meta=dict(N=N, H=H, W=W, C=M * Cm, D=D, M=M, P=P, n_pairs=rows, bin=(bin_w, bin_h), halo=(halo_x, halo_y),
-                              value_bytes=value_hm.element_size()))
+                              value_bytes=value_hm.element_size(), depth_bytes=dist.element_size()))
         return out
 
     def linear_rows_headmajor_bf16x3(self, x, w_hi, w_lo, shift, N, S, M, out_dtype=torch.float32):

@@ -15,6 +15,9 @@ timeout 600 python bench.py --conv-mode bf16 --no-cpu-baseline > gpurun_out/r04_
 timeout 600 python bench.py --conv-mode fp16 --no-cpu-baseline > gpurun_out/r04_bench_cfg2_fp16.json 2>/dev/null; echo fp16 rc $?
 timeout 600 python bench.py --conv-mode fp16 --workload cfg5_arkit_large --no-cpu-baseline > gpurun_out/r04_bench_cfg5_fp16.json 2>/dev/null; echo fp16-5 rc $?
 timeout 600 python bench.py --input-layout nhwc --no-cpu-baseline > gpurun_out/r04_bench_cfg2_nhwc.json 2>/dev/null; echo nhwc rc $?
+# the reduced-precision twin of BASELINE configs #2 / #5: fp16 products + bf16 value map and depth maps in the tiled gather
+timeout 600 python bench.py --conv-mode fp16 --storage bf16 --no-cpu-baseline > gpurun_out/r04_bench_cfg2_fp16_bf16maps.json 2>/dev/null; echo fp16+storage rc $?
+timeout 600 python bench.py --conv-mode fp16 --storage bf16 --workload cfg5_arkit_large --no-cpu-baseline > gpurun_out/r04_bench_cfg5_fp16_bf16maps.json 2>/dev/null; echo fp16+storage-5 rc $?
 bash tools/jobs/r04_trace.sh r04 > /dev/null 2>&1; echo trace rc $?
 # SQ counters of the halo kernel (90-GF layer), separate passes
 cd /tmp && export TMPDIR=/tmp
