@@ -210,6 +210,30 @@ def test_wgrad_halo_forms_agree_with_the_tile_kernel(oracle_ops, gpu_ops):
         gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", 1)
 
 
+def test_wgrad_halo_forms_on_random_shapes(gpu_ops):
+    """Seeded random layer shapes (ragged bricks in every direction, 1 - 40 voxels per axis, Cin / Cout multiples of 32 up to
+    192) through both halo forms of the 3x3x3 weight gradient against the per-tap tile kernel, which the cases below pin to the
+    oracle; repeated launches are bit-identical (tools/wgrad_fuzz.py runs more of them)."""
+    import random
+    rnd = random.Random(5)
+    try:
+        for case in range(14):
+            Cin, Cout = 32 * rnd.randint(1, 6), 32 * rnd.randint(1, 6)
+            grid = (rnd.randint(1, 40), rnd.randint(1, 24), rnd.randint(1, 18))
+            g = torch.Generator().manual_seed(case)
+            V = grid[0] * grid[1] * grid[2]
+            x, dy = torch.randn(V, Cin, generator=g).cuda(), torch.randn(V, Cout, generator=g).cuda()
+            gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", 0)
+            ref = gpu_ops.conv3d_wgrad_bf16x3(x, dy, grid, 3, 1)
+            for mode in (1, 2):
+                gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", mode)
+                got = gpu_ops.conv3d_wgrad_bf16x3(x, dy, grid, 3, 1)
+                assert torch.equal(got, gpu_ops.conv3d_wgrad_bf16x3(x, dy, grid, 3, 1)), (Cin, Cout, grid, mode)
+                assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (Cin, Cout, grid, mode)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"wgrad_halo", 1)
+
+
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_conv3d_wgrad_matches_oracle(case, oracle_ops, gpu_ops):
     """sgc_conv3d_wgrad_bf16x3 against the double-accumulating oracle loop: the 3-way bf16 split is fp32-faithful (bound
