@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Hot-path benchmark: scenes/sec of the SGCDet view transformation on MI355X.
 
-One "step" = one scene through the path BASELINE.json names: FPN maps + depth
-distributions (already resident in HBM) -> AdaptiveSparseHead (geometry/context-aware
-aggregation, coarse-to-fine refinement) -> FastIndoorImVoxelNeck -> ImVoxelHeadV2 head
-tensors.  Default workload = BASELINE.json configs[1]: 40 views x 256 ch, 40x40x16 voxels.
+One "step" = one BATCH of scenes (--scenes-per-step, default one per stream = 4; the JSON
+line says how many in config.scenes_per_step_per_gpu and also carries ms_per_scene) through
+the path BASELINE.json names: FPN maps + depth distributions (already resident in HBM) ->
+AdaptiveSparseHead (geometry/context-aware aggregation, coarse-to-fine refinement) ->
+FastIndoorImVoxelNeck -> ImVoxelHeadV2 head tensors.  `value` = scenes / s over all ranks.
+(Until the middle of round 4 a step was ONE scene: ms_per_step of BENCH_r01..r03 is per
+scene, from round 4 on per batch -- compare ms_per_scene.)
+Default workload = BASELINE.json configs[1]: 40 views x 256 ch, 40x40x16 voxels.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -565,7 +569,8 @@ def main():
         if dist is not None:
             dist.barrier()
         el_f = sgc_dist.max_over_ranks(time.perf_counter() - tf, device=device)
-        strict = dict(value=round(world * n_f32 / el_f, 3), unit="scenes/sec", steps=n_f32, ms_per_step=round(el_f / n_f32 * 1e3, 3),
+        # this leg's step() is ONE scene per call: report it per scene, in the unit of the top-level ms_per_scene
+        strict = dict(value=round(world * n_f32 / el_f, 3), unit="scenes/sec", scenes=n_f32, ms_per_scene=round(el_f / n_f32 * 1e3, 3),
                       dtype="f32 (exact fp32 products on v_mfma_f32_32x32x2_f32 for every convolution and Linear; LDS-tiled gather behind a permuting copy of the value map)")
         set_conv_mode(args.conv_mode)
         det.scene_graph, det.use_graph = sg, ug
@@ -579,6 +584,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_scene": round(elapsed / n_timed * 1e3 / world, 4),
+            "step_definition": f"one step = a batch of {spp} scenes per GPU (one per stream); ms_per_step is per batch, ms_per_scene per scene",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -72,8 +72,10 @@ int sgc_set_tuning(const char *key, int value);
  *       weights (TensorOps.split_f16), not bfloat16.  BASELINE.json config #5 ("fp16"; the reference's fp16 twin of the
  *       operator: TU/multi_scale_3ddeformable_attn_function.py:353-428); the rate of mode 1, ~2^-11 relative per operand.
  * It changes results (that is its purpose) and is therefore NOT a sgc_set_tuning key.  Process-wide; returns SGC_EINVAL for
- * any other value.  The w_lo arguments are ignored in modes 1 and 2.  The training entry points (weight / input gradients)
- * always compute in mode 3. */
+ * any other value.  The w_lo arguments are ignored in modes 1 and 2.  sgc_conv3d_wgrad_bf16x3 always computes in mode 3;
+ * the forward and input-gradient passes of training are the entry points above and FOLLOW the mode.  sgc_pack_conv_weight
+ * emits bfloat16 planes, which mode 2 would misread as IEEE half: the fp16 mode is inference-only (the host side refuses it
+ * with gradients enabled, sgcdet_amd/functions.py). */
 int sgc_set_conv_products(int products);
 int sgc_get_conv_products(void);
 const char *sgc_last_error(void);

@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
       for (int i = 0; i < BX + 2; ++i) {
         const int x = X0 + i - 1;                                                       // uniform
         const bool xin = x >= 0 && x < p.gx;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? voff : OOB, xin ? x * p.gy * p.gz * p.Cin * 4 : 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? voff : OOB, xin ? (int)((unsigned)x * (unsigned)(p.gy * p.gz) * (unsigned)p.Cin * 4u) : 0, 0);
         ra[i * APASS + j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
       }
     }
@@ -1610,7 +1610,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_wgrad_halo_kernel(const WgradH
       const int x = X0 + vx / (BY * BZ), y = Y0 + r / BZ, z = Z0 + r % BZ;
       const bool xin = x < p.gx, in = y < p.gy && z < p.gz;
       const unsigned voff = in && xin ? ((unsigned)(y * p.gz + z) * (unsigned)p.Cout + co0 + d_c4 * 4) * 4u : OOB;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dr, voff, xin ? x * p.gy * p.gz * p.Cout * 4 : 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dr, voff, xin ? (int)((unsigned)x * (unsigned)(p.gy * p.gz) * (unsigned)p.Cout * 4u) : 0, 0);
       rd[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     }
   };
@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_halo2_kernel(const WgradHalo
       const int slab = c >> 1, j = c & 1;
       const int x = X0 + slab - 1;                                                      // uniform
       const bool xin = x >= 0 && x < p.gx;
-      v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? a_voff[j] : OOB, xin ? x * p.gy * p.gz * p.Cin * 4 : 0, 0);
+      v = __builtin_amdgcn_raw_buffer_load_b128(xr, xin ? a_voff[j] : OOB, xin ? (int)((unsigned)x * (unsigned)(p.gy * p.gz) * (unsigned)p.Cin * 4u) : 0, 0);
     } else {
       const int vx = (c - NA) * DROWS + d_r, r = vx % (BY * BZ);
       const int x = X0 + vx / (BY * BZ), y = Y0 + r / BZ, z = Z0 + r % BZ;
@@ -2216,6 +2216,12 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     splitk = halo_splitk(ceil_div(gx, bx) * ceil_div(gy, by) * ceil_div(gz, bz), ceil_div(Cout, (g_tune_halo_narrow && Cout <= 64) ? 64 : 128), Cin / BK);
   } else if (bf16x3 && g_tune_conv_halo && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && halo_small_grid(gx, gy, gz, Cout)) {
     splitk = halo_splitk(halo_small_grid(gx, gy, gz, Cout), ceil_div(Cout, 64), Cin / BK);
+    // a MASKED call on these grids takes the tile kernel (the whole-grid brick carries no output mask): size for whichever
+    // form splits further, so that neither ever falls back to float atomics for want of workspace
+    ConvParams p = {};
+    p.taps = 27; p.Cin = Cin; p.M = (int)M; p.gx = gx; p.gy = gy; p.gz = gz;
+    const int tile_split = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, Cout <= 64 ? 64 : 128), g_tune_split_target);
+    if (tile_split > splitk) splitk = tile_split;
   } else {
     ConvParams p = {};
     p.transposed = transposed; p.taps = transposed ? 1 : ksize * ksize * ksize;

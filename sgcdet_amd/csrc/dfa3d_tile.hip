@@ -595,6 +595,9 @@ static TileGeom tile_geometry(int H, int W, int Cm, int D, int bin_w, int bin_h,
   const size_t db = vb == 2 ? 2 : 4;               // storage mode: bf16 depth maps beside the bf16 value map
   const size_t vbuf = ((size_t)g.tw * g.th + 1) * Cm * vb, dbuf = ((size_t)g.dw * g.dh * D * db + 15) & ~(size_t)15;
   if ((g.dw * D * db) % 16) g.dl = false;          // the LDS-DMA deals 16-byte pieces of a row
+  // (the window's SOURCE address is pixel-aligned only: 48 bytes per fp32 pixel at D = 12, but 24 per bf16 pixel -- an odd
+  //  origin column then starts 8 bytes into a 16-byte unit.  global_load_lds_dwordx4 needs dword alignment of the global
+  //  address, not 16 bytes; test_bf16_storage_mode_of_the_tiled_gather runs odd origins against the oracle.)
   g.nbuf = g_tune_tile_nbuf == 2 ? 2 : 1;
   if (g.nbuf == 2 && 2 * vbuf + (g.dl ? dbuf : 0) > 160 * 1024) g.nbuf = 1;
   if (g.dl && g.nbuf * vbuf + dbuf > 160 * 1024) g.dl = false;       // depth taps from global memory instead

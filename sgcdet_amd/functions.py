@@ -133,6 +133,15 @@ class PairListDeformAttnFunction(Function):
         return gv, gd, None, None, gl, ga, None
 
 
+def _require_bf16_planes(who):
+    """``sgc_pack_conv_weight`` emits bfloat16 bit patterns; in the fp16 arithmetic mode (``sgc_set_conv_products(2)``) the MFMA
+    kernels would read them as IEEE half.  The training Functions therefore refuse that mode instead of computing garbage."""
+    from .plugin import conv_plan
+    if conv_plan.CONV_PRODUCTS == 2:
+        raise RuntimeError(f"{who}: the fp16 arithmetic mode (set_conv_mode('fp16')) is inference-only -- the training Functions "
+                           "pack bfloat16 weight planes; switch to 'bf16x3' / 'bf16' or run under torch.no_grad()")
+
+
 def _pad_cols(t, mult):
     """[rows, C] -> [rows, ceil(C / mult) * mult] with zero columns (a view when nothing is added)."""
     c = t.shape[-1]
@@ -157,6 +166,7 @@ class ChannelsLastConv3dFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, grid, ksize, stride):
+        _require_bf16_planes("ChannelsLastConv3dFunction")
         ops = ext.ops()
         cout, cin = weight.shape[:2]
         # parameter [Cout, Cin, k, k, k] -> the kernel's [taps, Cout (multiple of 4), Cin] bf16 hi / lo planes in ONE launch
@@ -203,6 +213,7 @@ class ChannelsLastConvTranspose3dFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, grid):
+        _require_bf16_planes("ChannelsLastConvTranspose3dFunction")
         ops = ext.ops()
         cin, cout = weight.shape[:2]
         hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True)            # [Cin, Cout, 8] -> [8, Cout, Cin]
@@ -260,6 +271,7 @@ class LinearRowsFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        _require_bf16_planes("LinearRowsFunction")
         ops = ext.ops()
         cout, cin = weight.shape
         x = x.float().contiguous()
@@ -292,8 +304,8 @@ class LinearRowsFunction(Function):
 def linear_rows(module, x):
     """``module(x)`` for an ``nn.Linear`` with the passes on the HIP kernels when the shapes allow (CUDA fp32, in_features %
     32 == 0, at least a tile of rows); any leading shape."""
-    from .plugin.conv_plan import TRAIN_CONV
-    if (TRAIN_CONV != "hip" or not x.is_cuda or x.dtype != torch.float32 or module.in_features % 32
+    from .plugin.conv_plan import TRAIN_CONV, train_products_ok
+    if (TRAIN_CONV != "hip" or not train_products_ok() or not x.is_cuda or x.dtype != torch.float32 or module.in_features % 32
             or x.numel() // max(1, module.in_features) < 128):
         return module(x)
     y = LinearRowsFunction.apply(x.reshape(-1, module.in_features), module.weight, module.bias)

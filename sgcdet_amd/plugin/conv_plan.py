@@ -113,8 +113,16 @@ def set_train_conv(mode):
 
 def train_conv_on_hip(x, channels):
     """Can the autograd path of a conv chain run on the HIP kernels?  (one scene, CUDA, channel counts the K tile accepts)"""
-    return (TRAIN_CONV == "hip" and CONV_MODE == "bf16x3" and x.is_cuda and x.shape[0] == 1
+    return (TRAIN_CONV == "hip" and CONV_MODE == "bf16x3" and train_products_ok() and x.is_cuda and x.shape[0] == 1
             and all(c % _PAD == 0 for c in channels))
+
+
+def train_products_ok():
+    """The autograd Functions pack their weight planes with ``sgc_pack_conv_weight``, which emits bfloat16 hi / lo bits; the
+    forward and input-gradient kernels follow the process-wide arithmetic mode.  Modes 3 and 1 read those bits as bfloat16;
+    mode 2 (fp16) would read them as IEEE half (bf16 1.0 = 0x3F80 is 1.875 as a half) -- so the fp16 mode is inference-only:
+    with gradients enabled the convolutions / Linears take torch's library path (fp32) instead."""
+    return CONV_PRODUCTS != 2
 
 
 def conv_rows(conv, rows, grid):

@@ -79,9 +79,17 @@ class DenseHead(nn.Module):
         vc = self.vox_coords
         vc._sgc_flat = (vc._version, True)
 
-    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() build a new tensor object: tag it again
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float() build a new tensor object: carry the tag over -- but only if the tensor that is being
+        moved still held a VALID one.  In the usual order build -> load_state_dict -> .cuda() the in-place load has bumped the
+        version and voided the tag; the moved copy then stays untagged and ``_coords_are_flat`` checks the loaded content once
+        on the host (a checkpoint's persistent buffer, DenseHead.py:29, is data, not something to assert about)."""
+        vc = self.vox_coords
+        tag = getattr(vc, "_sgc_flat", None)
+        was_flat = tag is not None and tag[0] == vc._version and tag[1]
         out = super()._apply(fn, *args, **kwargs)
-        self._tag_flat_coords()
+        if was_flat:
+            self._tag_flat_coords()
         return out
 
     def get_voxel_indices(self):

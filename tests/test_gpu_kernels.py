@@ -616,6 +616,10 @@ def test_bf16_storage_mode_of_the_tiled_gather(C, HW, bins, oracle_ops, gpu_ops)
     raw = torch.randn(cap, M * P * 4, generator=g)
     raw[:, :M * P * 3] *= 1.5
     bw, bh = bins
+    # a bf16 depth pixel is D * 2 = 24 bytes, so the depth window of a bin whose origin column xd0 = bx * bw - 3
+    # is ODD starts 8 bytes (not 16) into a line: the LDS-DMA source of the `depth_in_lds` path is then only 8-byte aligned.
+    # Both shapes have bin columns with an odd origin -- this test is the coverage of that case.
+    assert (D * 2) % 16 == 8 and any((bx * bw - 3) % 2 == 1 for bx in range(1, -(-W // bw)))
     before = dict(pc, slot=pc["slot"].clone())
     b_c = oracle_ops.bin_pairs(rc, dict(pc, slot=pc["slot"].clone()), H, W, bw, bh)
     old = check_bins(b_c, before, rc, n_pairs, H, W, bw, bh)

@@ -284,6 +284,49 @@ def test_reduced_precision_modes_through_neck_and_head():
     assert worst["fp16"] * 3 <= worst["bf16"], worst
 
 
+def test_fp16_mode_with_gradients_enabled_never_feeds_bf16_planes_to_the_half_mfma():
+    """the training Functions pack bfloat16 weight planes (sgc_pack_conv_weight), which the fp16 arithmetic mode
+    would read as IEEE half.  With gradients enabled in that mode (a) the Functions themselves refuse loudly, (b) the neck's
+    training path takes torch's library convolutions instead, so its output and input gradient agree with the fp32-faithful
+    mode to the library path's own tolerance rather than being garbage."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.functions import ChannelsLastConv3dFunction, LinearRowsFunction
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin.conv_plan import set_conv_mode, train_conv_on_hip
+    from sgcdet_amd.scene import model_config, workload
+    w = workload("cfg1_plumbing")
+    torch.manual_seed(5)
+    det = build_detector(model_config(w)).cuda().train()
+    nx, ny, nz = w["n_voxels_list"][-1]
+    vol = torch.randn(1, w["embed_dims"], nx, ny, nz, device="cuda")
+    outs = {}
+    try:
+        for mode in ("bf16x3", "fp16"):
+            set_conv_mode(mode)
+            torch.manual_seed(6)                               # same BatchNorm statistics path
+            x = vol.clone().requires_grad_(True)
+            assert train_conv_on_hip(x, [w["embed_dims"]]) == (mode == "bf16x3")
+            y = det.neck_3d(x)
+            loss = sum((t.float() ** 2).mean() for t in y)
+            loss.backward()
+            outs[mode] = ([t.detach().clone() for t in y], x.grad.detach().clone())
+        rows = torch.randn(512, 64, device="cuda", requires_grad=True)
+        wt = torch.randn(32, 64, 3, 3, 3, device="cuda", requires_grad=True)
+        with pytest.raises(RuntimeError, match="inference-only"):
+            ChannelsLastConv3dFunction.apply(rows, wt, (8, 8, 8), 3, 1)
+        with pytest.raises(RuntimeError, match="inference-only"):
+            LinearRowsFunction.apply(rows, torch.randn(32, 64, device="cuda", requires_grad=True), None)
+    finally:
+        set_conv_mode("bf16x3")
+    for a, b in zip(outs["fp16"][0], outs["bf16x3"][0]):
+        assert torch.isfinite(a).all()
+        assert max_err(a, b) <= 2e-3 * max(1.0, b.abs().max().item())
+    ga, gb = outs["fp16"][1], outs["bf16x3"][1]
+    assert torch.isfinite(ga).all()
+    cos = torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item()
+    assert cos > 0.999, cos
+
+
 def _neck_head_oracle(det, w):
     from oracle.ref_path import RefPath
     return RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},

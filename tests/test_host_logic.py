@@ -259,10 +259,38 @@ def test_committed_bench_lines_follow_from_their_own_fields():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     from roofline_check import check_line
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(root, "profiles", "r05_bench_*.json")))
     assert len(files) >= 8
     for f in files:
         line = open(f).readline()
         d = json.loads(line)
         assert check_line(d, os.path.basename(f)) == []
         assert d["self_check"]["mismatching"] == 0
+
+
+def test_dense_head_flat_tag_follows_the_content_not_the_move():
+    """DenseHead tags the vox_coords it BUILDS as flat (column 3 == arange); a module move (.to / .cuda builds a
+    new tensor object) carries the tag over only while it is still valid.  build -> load_state_dict -> move: the in-place load
+    voids the tag, so the moved buffer is untagged and the transformer checks the loaded content itself."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.mmcv_lite import build_head
+    w = workload("cfg1_plumbing")
+    head = build_head(model_config(w)["voxel_head"]).base_heads[0]
+    enc = head.cross_transformer
+
+    def valid_tag(t):
+        tag = getattr(t, "_sgc_flat", None)
+        return tag is not None and tag[0] == t._version
+
+    assert valid_tag(head.vox_coords) and enc._coords_are_flat(head.vox_coords)
+    head._apply(lambda t: t.clone())                       # what .to() / .cuda() do: a new tensor object per buffer
+    assert valid_tag(head.vox_coords) and head.vox_coords._sgc_flat[1]
+    sd = head.state_dict()
+    sd["vox_coords"] = sd["vox_coords"].clone()
+    sd["vox_coords"][:, 3] = sd["vox_coords"][:, 3].flip(0)          # a checkpoint whose column 3 is NOT arange
+    head.load_state_dict(sd)
+    assert not valid_tag(head.vox_coords)                  # the in-place copy bumped the version
+    head._apply(lambda t: t.clone())
+    assert not valid_tag(head.vox_coords)                  # ... and the move must not re-assert "flat"
+    assert enc._coords_are_flat(head.vox_coords) is False  # one host check of the loaded content
+    assert valid_tag(head.vox_coords) and head.vox_coords._sgc_flat[1] is False

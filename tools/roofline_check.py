@@ -1,7 +1,7 @@
 """Every bench line committed under profiles/ must follow from its own fields: roofline.frac = achieved / peak with
 achieved = algorithmic bytes / average launch time (HBM-bound kernel) or issued FLOPs / average launch time (MFMA kernel),
 path_roofline.frac = floor / measured time per scene, value = scenes / second of the timed region.
-Usage: python tools/roofline_check.py [files...]   (default: profiles/r04_bench_*.json); exits non-zero on a mismatch.
+Usage: python tools/roofline_check.py [files...]   (default: profiles/r04_bench_*.json and r05_bench_*.json); exits non-zero on a mismatch.
 tests/test_host_logic.py runs it over the committed files."""
 import glob, json, os, sys
 
@@ -16,6 +16,8 @@ def check_line(d, name="line"):
             bad.append(f"{name}: {what}: {a} vs {b}")
     spp = d.get("config", {}).get("scenes_per_step_per_gpu", 1)          # scenes in the batch one step processes
     near(d["value"], d["n_gpus"] * spp * 1e3 / d["ms_per_step"], 2e-3, "value vs n_gpus * scenes_per_step / ms_per_step")
+    if "ms_per_scene" in d:                                              # round 5: the per-scene unit beside the per-batch one
+        near(d["value"], 1e3 / d["ms_per_scene"], 2e-3, "value vs 1 / ms_per_scene")
     r = d.get("roofline")
     if r:
         near(r["frac"], r["achieved"] / r["peak"], 2e-3, "roofline.frac vs achieved / peak")
@@ -36,7 +38,7 @@ def check_line(d, name="line"):
 
 
 if __name__ == "__main__":
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")))
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
     bad = []
     for f in files:
         line = open(f).readline()
