@@ -85,6 +85,11 @@ def parse():
     ap.add_argument("--masked-tail", action="store_true",
                     help="output-masked finest decoder tail + head convolutions (north star's 'sparse 3D convolution over the "
                          "occupancy-masked voxels'): head tensors are then defined only where the head's valid pyramid is 1")
+    ap.add_argument("--occupancy", default="predicted", choices=["predicted", "clustered"],
+                    help="which scores the refined levels' top-k ranks: the predicted occupancy (the reference's behaviour, the "
+                         "headline) or a seeded SURFACE-CLUSTERED override (sgcdet_amd.scene.clustered_occupancy; SURVEY.md 8d "
+                         "allows a controlled mask): the workload on which --masked-tail can skip bricks.  Its own line, never "
+                         "the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of the extra `sustained` leg (same configuration, back to back; 0 = skip)")
@@ -281,6 +286,9 @@ def main():
     if args.graph == "scene" and args.conv_mode == "f32":
         args.graph = "tail"                      # the device-count GEMM entry point exists for the bf16x3 path only
     det.masked_tail = os.environ.get("SGC_MASKED_TAIL", "0") == "1" or args.masked_tail
+    if args.occupancy == "clustered":
+        from sgcdet_amd.scene import clustered_occupancy
+        det.voxel_head.occupancy_override = clustered_occupancy(w["n_voxels_list"], seed=0, device=device)
     from sgcdet_amd.plugin import voxformer as _vf
     _vf.TILED_GATHER["storage"] = args.storage
     det.use_graph = args.graph != "none"
@@ -504,7 +512,9 @@ def main():
     path_roofline = None
     if per_kernel:
         n_e = max(6, min(n_timed, 20))
-        gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"])
+        # (a block-diagonal Linear run as a dense GEMM -- the per-voxel V projection of the projected-query attention -- counts with
+        #  its structurally non-zero fraction `useful`: the zero blocks are launch geometry, not work the path has to do)
+        gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0)
                    for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
         gbytes = 0.0
         for name, items in per_kernel.items():
@@ -575,6 +585,20 @@ def main():
         set_conv_mode(args.conv_mode)
         det.scene_graph, det.use_graph = sg, ug
 
+    tail_stats = None
+    if rank == 0 and (det.masked_tail or args.occupancy != "predicted"):
+        # what the output masks of the decoder tail keep alive on the last scene (tools/valid_stats.py prints more): fractions of
+        # voxels in valid / dilate(valid) / dilate^2(valid) and of the halo kernel's 256-voxel bricks holding one such voxel
+        import torch.nn.functional as F
+        with torch.no_grad():
+            v = det.forward_features(*[scenes[0][k] for k in (0, 2, 1)])["valid"].float()
+            d1 = F.max_pool3d(v, 3, 1, 1)
+            d2 = F.max_pool3d(d1, 3, 1, 1)
+            bshape = (8, 8, 4) if (v.shape[-1] >= 16 and v.shape[-3] % 8 == 0 and v.shape[-2] % 8 == 0) else (4, 4, 16)
+            live = lambda m: round(float(F.max_pool3d(m, bshape, bshape, ceil_mode=True).mean()), 3)   # noqa: E731
+            tail_stats = dict(voxels=dict(valid=round(float(v.mean()), 3), dilate1=round(float(d1.mean()), 3), dilate2=round(float(d2.mean()), 3)),
+                              live_bricks={"brick": "x".join(map(str, bshape)), "head_conv(valid)": live(v),
+                                           "out_block_0(dilate1)": live(d1), "up_block_1(dilate2)": live(d2)})
     if rank == 0:
         out = {
             "metric": "scenes/sec (40-view ScanNet volume) at 1/2/4/8 MI355X; mAP@0.25 parity",
@@ -605,6 +629,9 @@ def main():
                                    f"{'/'.join(f'{f.shape[-2]}x{f.shape[-1]}' for f in scenes[0][0][:3])}, "
                                    f"D=12, voxels {'x'.join(map(str, w['n_voxels_list'][-1]))}, top-k {w['topk_list']}, "
                                    f"neck 3-scale -> {w['head']}",
+                       "occupancy": ("predicted" if args.occupancy == "predicted" else
+                                     "clustered override (seeded floor + two walls + a box shell; top-k ranks the distance to them)"),
+                       "masked_tail": bool(det.masked_tail), "masked_tail_stats": tail_stats,
                        "input_layout": args.input_layout, "scenes_per_step_per_gpu": spp, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
                        "launch_geometry": ("throughput (row GEMMs on half the CUs; fewer reduction splits in the layers with few voxels; "
                                             "conv_plan.set_throughput_mode)"

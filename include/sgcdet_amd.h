@@ -342,6 +342,23 @@ int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slo
                              const float *ctx, const float *grad_ctx, float *grad_q, float *grad_kv,
                              int N, int Nq, int C, int heads, int n_valid, sgc_stream_t stream);
 
+/* The same attention with the K / V in-projections moved off the pair list (round 5; a new entry point: no ABI bump).  Both commute with the
+ * softmax over views: score(n, h) = (scale W_k,h^T q_h) . x_n + a constant per (voxel, head) that the softmax drops, and
+ * ctx_h = W_v,h (sum_n a(n, h) x_n) + b_v,h.  So instead of a [pairs, C] x [C, 2C] GEMM (2.1 M pairs per scene at 100 views) the
+ * caller projects the QUERY once per voxel and head,
+ *   qp [n_valid, heads, C] = scale * W_k,h^T q_h        (one Linear C -> heads * C on the voxels),
+ * this entry point computes, on the RAW per-pair features x [n_pairs, C],
+ *   a(n, h) = softmax_n (qp_h . x_n)    over the cameras n that see the voxel (slot[n, q] >= 0),
+ *   s [n_valid, heads, C],  s_h = sum_n a(n, h) x_n,
+ * and the caller applies V once per voxel: ctx[h * hd + j] = W_v[h * hd + j, :] . s_h + b_v (a block-diagonal Linear).
+ * Same function of (q, x, weights) as sgc_view_attend on the in-projected tensors (TU/deformable_cross_attention.py:826-833);
+ * the sums are associated differently (~1e-6 relative).  Supported: heads == 8, C in {128, 256}, N <= 128
+ * (sgc_view_attend_pq_supported); the caller keeps sgc_view_attend for everything else.                                   */
+int sgc_view_attend_pq(const float *qp, const float *x, const int32_t *slot, const int32_t *valid_index, float *s,
+                       int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                       sgc_stream_t stream);
+int sgc_view_attend_pq_supported(int N, int C, int heads);
+
 /* ------------------------------------------------------------------------- *
  * 6. Volume glue
  * ------------------------------------------------------------------------- */

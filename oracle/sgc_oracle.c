@@ -823,6 +823,50 @@ int sgc_view_attend(const float *q, const float *kv, const int32_t *slot,
   return SGC_OK;
 }
 
+/* Projected-query form of the view softmax (see the header): qp [n_valid, heads, C], x [n_pairs, C] -> s [n_valid, heads, C].
+ * Plain restatement of the formula, double accumulation; the reference function it equals is the MHA above
+ * (TU/deformable_cross_attention.py:826-833) with k = W_k x + b_k, v = W_v x + b_v folded by the caller. */
+int sgc_view_attend_pq_supported(int N, int C, int heads) { return heads > 0 && C > 0 && N > 0 && N <= 4096; }
+int sgc_view_attend_pq(const float *qp, const float *x, const int32_t *slot, const int32_t *valid_index, float *s,
+                       int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                       sgc_stream_t stream) {
+  (void)stream;
+  if (!qp || !x || !slot || !valid_index || !s) return fail(SGC_EINVAL, "null pointer");
+  if (heads <= 0 || N > 4096) return fail(SGC_EUNSUP, "heads / N");
+  if (n_valid_dev_or_null && *n_valid_dev_or_null < n_valid) n_valid = *n_valid_dev_or_null;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_valid; ++i) {
+    const int vq = valid_index[i];
+    double d[4096];
+    for (int h = 0; h < heads; ++h) {
+      const float *q = qp + ((int64_t)i * heads + h) * C;
+      float *o = s + ((int64_t)i * heads + h) * C;
+      double mx = -INFINITY, sum = 0.0;
+      for (int n = 0; n < N; ++n) {
+        const int32_t p = slot[(int64_t)n * Nq + vq];
+        d[n] = 0.0;
+        if (p < 0) continue;
+        const float *xr = x + (int64_t)p * C;
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) acc += (double)q[c] * (double)xr[c];
+        d[n] = acc;
+        if (acc > mx) mx = acc;
+      }
+      for (int n = 0; n < N; ++n)
+        if (slot[(int64_t)n * Nq + vq] >= 0) sum += exp(d[n] - mx);
+      for (int c = 0; c < C; ++c) {
+        double acc = 0.0;
+        for (int n = 0; n < N; ++n) {
+          const int32_t p = slot[(int64_t)n * Nq + vq];
+          if (p >= 0) acc += exp(d[n] - mx) / sum * (double)x[(int64_t)p * C + c];
+        }
+        o[c] = (float)acc;
+      }
+    }
+  }
+  return SGC_OK;
+}
+
 /* backward of the view softmax above (double accumulation): see the header */
 int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slot, const int32_t *valid_index,
                              const float *ctx, const float *grad_ctx, float *grad_q, float *grad_kv,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sgc_view_mean": [_p] * 4 + [_i] * 3 + [_p, _i] + [_p],
     "sgc_view_attend": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_view_attend_backward": [_p] * 8 + [_i] * 5 + [_p],
+    "sgc_view_attend_pq": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 7 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
@@ -72,6 +73,7 @@ INTROSPECTION = {
     "sgc_bn_rows_workspace_floats": (C.c_int64, [_i] * 2),
     "sgc_topk_select_workspace_bytes": (C.c_int64, [_i]),
     "sgc_level_tail_supported": (C.c_int, [_i] * 2),
+    "sgc_view_attend_pq_supported": (C.c_int, [_i] * 3),
     "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
 }

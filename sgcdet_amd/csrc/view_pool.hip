@@ -167,6 +167,132 @@ __global__ __launch_bounds__(256) void view_attend_group_kernel(const float *__r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Projected-query form of the same attention (round 5).  nn.MultiheadAttention over the views (query length 1,
+// TU/deformable_cross_attention.py:826-833) in-projects K and V for EVERY visible (camera, voxel) pair: a [pairs, C] x
+// [C, 2C] GEMM whose result (2 KB per pair at C = 256) is written, read back once by the softmax, and thrown away --
+// at 100 views 2.1 M pairs per scene, the largest Linear of the path.  Both projections commute with the softmax:
+//   score(n, h) = (scale q_h) . (W_k,h x_n + b_k,h) = (scale W_k,h^T q_h) . x_n + const(h)        (the constant
+//                 is the same for every camera n and drops out of the softmax over n),
+//   ctx_h       = sum_n a(n, h) (W_v,h x_n + b_v,h) = W_v,h (sum_n a(n, h) x_n) + b_v,h          (sum_n a = 1),
+// so the per-pair work is the raw pair feature x_n against a PROJECTED QUERY qp_h = scale W_k,h^T q_h (C floats per voxel
+// and head, one [n_valid, C] x [C, heads C] GEMM on the voxels), and V is applied once per voxel to the attention-weighted
+// feature s_h = sum_n a(n, h) x_n ([n_valid, heads C] x block-diagonal [heads C, C]).  Same function of the inputs as
+// sgc_view_attend on the in-projected tensors; sums are associated differently (~1e-6 relative).
+//
+// One group of LG = C / 4 lanes per voxel (one wave at C = 256, half a wave at C = 128), 8 heads.  Per visible camera
+// the lane holds 4 channels of x_n and the same 4 channels of the 8 projected queries: 8 partial dot products, reduced
+// over the group with a packed butterfly (the first three exchange steps halve the number of values a lane carries:
+// 4 + 2 + 1 shuffles, then one value over the remaining lane bits), scores parked in LDS.  An exact two-pass softmax
+// (max, expf, sum, true division -- torch's softmax) over the voxel's cameras, then a second walk over the same pair
+// rows (L2 hits) accumulates the 8 weighted features.  No atomics, fixed order: the same bits every run.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPqHeads = 8, kPqMaxViews = 128;
+
+template <int LG>
+__global__ __launch_bounds__(256) void view_attend_pq_kernel(const float *__restrict__ qp, const float *__restrict__ x,
+                                                             const int32_t *__restrict__ slot,
+                                                             const int32_t *__restrict__ valid_index, float *__restrict__ s,
+                                                             int N, int Nq, int n_valid, const int32_t *__restrict__ n_dev) {
+  if (n_dev) n_valid = min(n_valid, *n_dev);
+  if (n_valid <= 0) return;
+  constexpr int C = LG * 4, H = kPqHeads, GPW = 64 / LG, GPB = 4 * GPW;      // groups per wave / per block
+  __shared__ __attribute__((aligned(16))) float sc[GPB][kPqMaxViews][H];     // scores, then softmax weights: [camera][head]
+  __shared__ int plist[GPB][kPqMaxViews];                                     // pair index of the voxel's j-th visible camera
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gl = lane & (LG - 1), gbase = lane & ~(LG - 1);
+  const int grp = wid * GPW + (lane / LG);
+  float (*my_sc)[H] = sc[grp];
+  int *my_pl = plist[grp];
+  const bool b0 = gl & 1, b1 = gl & 2, b2 = gl & 4;
+  const int hm = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);                 // the head whose sum this lane holds after the butterfly
+  const int64_t ngroups = n_valid, gstride = (int64_t)gridDim.x * GPB;
+  // every lane of a wave runs the same number of iterations (shuffles need the whole wave): dead groups redo the last voxel
+  const int64_t first = (int64_t)blockIdx.x * GPB + grp;
+  const int64_t iters = (ngroups - (int64_t)blockIdx.x * GPB - wid * GPW + gstride - 1) / gstride;     // of this wave's first group
+  int64_t i_raw = first;
+  for (int64_t it = 0; it < iters; ++it, i_raw += gstride) {
+    const bool live = i_raw < ngroups;
+    const int i = (int)(live ? i_raw : ngroups - 1);
+    const int vq = valid_index[i];
+    // ---- the voxel's visible cameras, ascending camera index ----
+    int cnt = 0;
+    for (int nb = 0; nb < N; nb += LG) {
+      const int pl = nb + gl < N ? slot[(int64_t)(nb + gl) * Nq + vq] : -1;
+      unsigned long long m = __ballot(pl >= 0);
+      if (LG == 32) m = (m >> gbase) & 0xffffffffull;
+      if (pl >= 0) my_pl[cnt + __popcll(m & ((1ull << gl) - 1ull))] = pl;
+      cnt += __popcll(m);
+    }
+    float4 q[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) q[h] = *reinterpret_cast<const float4 *>(qp + ((int64_t)i * H + h) * C + gl * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 1: scores ----
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt > 0) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[0] * C + gl * 4);
+    for (int j = 0; j < cnt; ++j) {
+      const float4 xv = xn;
+      if (j + 1 < cnt) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + 1] * C + gl * 4);
+      float v[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) v[h] = ((q[h].x * xv.x + q[h].y * xv.y) + q[h].z * xv.z) + q[h].w * xv.w;
+      float t[4], u[2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = (b0 ? v[4 + k] : v[k]) + __shfl_xor(b0 ? v[k] : v[4 + k], 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) u[k] = (b1 ? t[2 + k] : t[k]) + __shfl_xor(b1 ? t[k] : t[2 + k], 2);
+      float d = (b2 ? u[1] : u[0]) + __shfl_xor(b2 ? u[0] : u[1], 4);
+#pragma unroll
+      for (int o = 8; o < LG; o <<= 1) d += __shfl_xor(d, o);
+      if (gl < 8) my_sc[j][hm] = d;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- softmax over the cameras, per head: lane = (head gl & 7, cameras (gl >> 3) + k LG / 8) ----
+    {
+      const int h = gl & 7, j0 = gl >> 3;
+      constexpr int JS = LG / 8;
+      float mx = -INFINITY;
+      for (int j = j0; j < cnt; j += JS) mx = fmaxf(mx, my_sc[j][h]);
+#pragma unroll
+      for (int o = 8; o < LG; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+      for (int j = j0; j < cnt; j += JS) {
+        const float e = expf(my_sc[j][h] - mx);
+        my_sc[j][h] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 8; o < LG; o <<= 1) sum += __shfl_xor(sum, o);
+      for (int j = j0; j < cnt; j += JS) my_sc[j][h] = my_sc[j][h] / sum;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2: the 8 attention-weighted features ----
+    float4 acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt > 0) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[0] * C + gl * 4);
+    for (int j = 0; j < cnt; ++j) {
+      const float4 xv = xn;
+      if (j + 1 < cnt) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + 1] * C + gl * 4);
+      const float4 a0 = *reinterpret_cast<const float4 *>(&my_sc[j][0]), a1 = *reinterpret_cast<const float4 *>(&my_sc[j][4]);
+      const float a[H] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        acc[h].x += a[h] * xv.x; acc[h].y += a[h] * xv.y; acc[h].z += a[h] * xv.z; acc[h].w += a[h] * xv.w;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<float4 *>(s + ((int64_t)i * H + h) * C + gl * 4) = acc[h];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next voxel overwrites this group's LDS
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Softmax over views for query length 1 (nn.MultiheadAttention, :829-833): one group of
 // G = head_dim/VEC lanes per (voxel, head); the dot product is reduced over the group with
 // wave shuffles, the softmax over views runs online (running max / sum) in registers.
@@ -435,6 +561,10 @@ static int grid_for(int64_t work, int block) {
   return (int)g;
 }
 
+extern "C" int sgc_view_attend_pq_supported(int N, int C, int heads) {
+  return heads == sgc::kPqHeads && (C == 128 || C == 256) && N > 0 && N <= sgc::kPqMaxViews ? 1 : 0;
+}
+
 extern "C" int sgc_view_mean(const float *feat, const int32_t *slot, const int32_t *valid_index,
                              float *mean, int N, int Nq, int C, const int32_t *n_valid_dev_or_null, int n_valid,
                              sgc_stream_t stream) {
@@ -485,6 +615,28 @@ extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *s
     hipLaunchKernelGGL(view_attend_kernel<1>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
                        slot, valid_index, ctx, N, Nq, C, heads, n_valid, G, scale, n_dev);
   return check_launch("view_attend_kernel");
+}
+
+extern "C" int sgc_view_attend_pq(const float *qp, const float *x, const int32_t *slot, const int32_t *valid_index, float *s,
+                                  int N, int Nq, int C, int heads, const int32_t *n_valid_dev_or_null, int n_valid,
+                                  sgc_stream_t stream) {
+  if (!qp || !x || !slot || !valid_index || !s) return set_error(SGC_EINVAL, "sgc_view_attend_pq: null pointer");
+  if (!sgc_view_attend_pq_supported(N, C, heads))
+    return set_error(SGC_EUNSUP, "sgc_view_attend_pq: needs heads == %d, C in {128, 256}, N <= %d (got heads %d, C %d, N %d)",
+                     kPqHeads, kPqMaxViews, heads, C, N);
+  if (((uintptr_t)qp | (uintptr_t)x | (uintptr_t)s) & 15) return set_error(SGC_EINVAL, "sgc_view_attend_pq: pointers must be 16-byte aligned");
+  if (n_valid <= 0) return SGC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 256) {
+    const int groups_per_block = 4;
+    const int grid = (int)std::min<int64_t>(((int64_t)n_valid + groups_per_block - 1) / groups_per_block, 256 * 16);
+    hipLaunchKernelGGL(view_attend_pq_kernel<64>, dim3(grid), dim3(256), 0, st, qp, x, slot, valid_index, s, N, Nq, n_valid, n_valid_dev_or_null);
+  } else {
+    const int groups_per_block = 8;
+    const int grid = (int)std::min<int64_t>(((int64_t)n_valid + groups_per_block - 1) / groups_per_block, 256 * 16);
+    hipLaunchKernelGGL(view_attend_pq_kernel<32>, dim3(grid), dim3(256), 0, st, qp, x, slot, valid_index, s, N, Nq, n_valid, n_valid_dev_or_null);
+  }
+  return check_launch("view_attend_pq_kernel");
 }
 
 extern "C" int sgc_view_attend_backward(const float *q, const float *kv, const int32_t *slot, const int32_t *valid_index,

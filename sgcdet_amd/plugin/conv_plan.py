@@ -197,9 +197,12 @@ class LinearSpec:
     """nn.Linear (or a row-block of stacked weights) prepared for ``sgc_conv3d_cl_bf16x3`` as a 1x1x1
     convolution over M rows: y[M, out] = x[M, in] @ W^T + b on the bf16 matrix cores with the 3-way split."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, useful=None):
+        """``useful``: fraction of the weight matrix that is structurally non-zero (a block-diagonal matrix run as a dense
+        GEMM); only bench.py's flop accounting reads it (the zero blocks are not algorithmic work)."""
         w = weight.detach().float()
         cout, cin = w.shape
+        self.useful = useful
         if cin % _PAD:
             raise ValueError("LinearSpec needs in_features % 32 == 0")
         cout_p = _pad_to(cout, 4)
@@ -223,7 +226,7 @@ class LinearSpec:
                 buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
                 buf[M].zero_()
                 out = buf[:M]
-            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count, out=out)
+            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count, out=out, useful=self.useful)
         if count is not None:
             raise NotImplementedError("device-side row counts need the bf16x3 path and out_features % 4 == 0")
         if CONV_MODE == "bf16x3":

@@ -158,6 +158,21 @@ class AdaptiveSparseHead(nn.Module):
         self.occ_pred_heads = nn.ModuleList(
             [nn.Sequential(nn.Linear(embed_dims, 1), nn.Sigmoid()) for _ in range(len(self.base_heads) - 1)])
         self.loss = nn.BCELoss()
+        # Controlled selection for synthetic scenes ("optionally override the mask"): a list with one score
+        # tensor [V_i] (float32, on the module's device) or None per refined level; the level's top-k then ranks THESE scores
+        # instead of the predicted occupancy (which is still computed and returned).  None = the reference's behaviour.
+        # sgcdet_amd.scene.clustered_occupancy builds a surface-clustered one.
+        self.occupancy_override = None
+
+    def _selection_scores(self, i, occ):
+        """scores the top-k of refined level i (1-based) ranks: the predicted occupancy, or the controlled override"""
+        ov = self.occupancy_override
+        if ov is None or ov[i - 1] is None:
+            return occ
+        s = ov[i - 1].view_as(occ)
+        if s.device != occ.device or s.dtype != occ.dtype:
+            raise RuntimeError("occupancy_override: scores must live on the module's device as float32")
+        return s
 
     def _level_inputs(self, i, mlvl_feats, img_meta, mlvl_dpt_dists):
         """level i samples FPN map n_lvl-1-i cropped to the un-padded image (AdaptiveSparseHead.py:52-59)"""
@@ -188,7 +203,7 @@ class AdaptiveSparseHead(nn.Module):
                 # the k highest occupancy scores as an ascending index list (== nonzero(mask)) in ONE launch; ties at the
                 # cut go to the lowest flat index (csrc/rows.hip) -- no topk / sort / scatter library kernels, no host sync
                 last = i == len(self.base_heads) - 1
-                idx, valid, _ = ops.topk_select(occ, self.topk_list[i - 1], want_valid=last)
+                idx, valid, _ = ops.topk_select(self._selection_scores(i, occ), self.topk_list[i - 1], want_valid=last)
                 seed = self.base_heads[i].seed_rows([feat], img_meta, idx, mlvl_dpt_dists=[dpt], **extra)
                 ops.scatter_add_rows(seed.contiguous(), idx, up)
             else:
@@ -227,10 +242,11 @@ class AdaptiveSparseHead(nn.Module):
             occ_preds_list.append(occ)
             mask, idx = None, None
             if (i - 1) < len(self.topk_list):
+                sel = self._selection_scores(i, occ)
                 if occ.is_cuda and occ.dtype == torch.float32:
-                    idx, _, mask = ext.ops().topk_select(occ.detach().contiguous(), self.topk_list[i - 1], want_mask=True)
+                    idx, _, mask = ext.ops().topk_select(sel.detach().contiguous(), self.topk_list[i - 1], want_mask=True)
                 else:
-                    _, top = torch.topk(occ, k=self.topk_list[i - 1], dim=1)
+                    _, top = torch.topk(sel, k=self.topk_list[i - 1], dim=1)
                     mask = torch.zeros_like(occ).scatter_(1, top, 1.0).squeeze(0)
                     idx = top.squeeze(0).sort().values                   # == nonzero(mask), no host sync
             volume = up + self.base_heads[i]([feat], img_meta, proposal=mask, proposal_idx=idx,

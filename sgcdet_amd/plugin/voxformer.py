@@ -303,8 +303,44 @@ class DeformCrossAttention_DFA3D(BaseModule):
                           mha.in_proj_weight[:C].detach().float() @ self.output_proj.bias.detach().float()
                           + mha.in_proj_bias[:C].detach().float()),
             o=LinearSpec(mha.out_proj.weight, mha.out_proj.bias))
+        plan.update(self._projected_query_plan(mha, plan))
         self.__dict__["_gemm_cache"] = (fp, plan)
         return plan
+
+    # Projected-query form of the inter-view attention (sgc_view_attend_pq, round 5): K and V leave the pair list.
+    #   "auto": wherever the kernel supports the shape (8 heads, C in {128, 256}, <= 128 views) and a voxel is seen by enough
+    #           cameras for the per-voxel GEMMs (C -> heads * C and heads * C -> C) to cost less than the per-pair K | V GEMM
+    #           (C -> 2C on every visible pair): break-even at ~8 visible cameras per voxel, i.e. ~25 ring views;
+    #   True / False force it on (where supported) / off.  Same function of the inputs either way (~1e-6: association of sums).
+    projected_query = {"0": False, "1": True}.get(__import__("os").environ.get("SGC_PROJECTED_QUERY", ""), "auto")   # env: A/B runs
+    projected_query_min_views = 24
+
+    def _projected_query_plan(self, mha, plan):
+        """qp = scale * W_k,h^T q_h as ONE Linear on the pooled feature (composed with the q / output projections of `qo`), and
+        V as a block-diagonal Linear heads * C -> C; composed in float64, stored fp32 (the GEMMs then run like every other)."""
+        C, Hn = self.embed_dims, mha.num_heads
+        if not _ops().view_attend_pq_supported(1, C, Hn):
+            return dict(qp=None, vbd=None)
+        hd = C // Hn
+        w = mha.in_proj_weight.detach().double()
+        b = mha.in_proj_bias.detach().double()
+        wqo = w[:C] @ self.output_proj.weight.detach().double()                     # q = wqo mean + bqo (as `qo`)
+        bqo = w[:C] @ self.output_proj.bias.detach().double() + b[:C]
+        wk, wv, bv = w[C:2 * C], w[2 * C:], b[2 * C:]
+        scale = (1.0 / hd) ** 0.5                                                    # torch MHA: q * sqrt(1 / head_dim)
+        wqp = torch.cat([scale * wk[h * hd:(h + 1) * hd].t() @ wqo[h * hd:(h + 1) * hd] for h in range(Hn)], 0)      # [Hn C, C]
+        bqp = torch.cat([scale * wk[h * hd:(h + 1) * hd].t() @ bqo[h * hd:(h + 1) * hd] for h in range(Hn)], 0)      # [Hn C]
+        wbd = torch.zeros((C, Hn * C), dtype=torch.float64, device=w.device)
+        for h in range(Hn):
+            wbd[h * hd:(h + 1) * hd, h * C:(h + 1) * C] = wv[h * hd:(h + 1) * hd]
+        return dict(qp=LinearSpec(wqp.float(), bqp.float()), vbd=LinearSpec(wbd.float(), bv.float(), useful=1.0 / Hn))
+
+    def _use_projected_query(self, gemm, n_views):
+        if gemm is None or gemm.get("qp") is None or self.projected_query is False:
+            return False
+        if not _ops().view_attend_pq_supported(n_views, self.embed_dims, self.attention_pooling.num_heads):
+            return False
+        return self.projected_query is True or n_views >= self.projected_query_min_views
 
     # ---- inference: pair-list pipeline --------------------------------------------------
     def _forward_pairs(self, query, feat, dist, ref_cam, mask_u8, H, W, zero_query=False, static_counts=False, want_ctx=False):
@@ -398,13 +434,22 @@ class DeformCrossAttention_DFA3D(BaseModule):
         if self.inter_view_aggregation == "attn":
             mha = self.attention_pooling
             w, b = mha.in_proj_weight, mha.in_proj_bias
-            if use_mfma:
-                q = gemm["qo"](mean, count=valid_cnt)
-                kv = gemm["kv"](per_pair, count=pairs_cnt)
+            if use_mfma and self._use_projected_query(gemm, N):
+                # K and V off the pair list (sgc_view_attend_pq): one projected query per (voxel, head) against the raw pair
+                # features, V applied once per voxel to the attention-weighted feature
+                qp = gemm["qp"](mean, count=valid_cnt)                                   # [n_valid, heads * C]
+                sw = ops.view_attend_pq(qp, per_pair, slot, valid_index, mha.num_heads, count=valid_cnt)
+                del qp
+                ctx = gemm["vbd"](sw, count=valid_cnt)                                   # [n_valid, C]
+                del sw
             else:
-                q = F.linear(pooled, w[:C], b[:C])
-                kv = F.linear(per_pair, w[C:], b[C:])
-            ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads, count=valid_cnt)
+                if use_mfma:
+                    q = gemm["qo"](mean, count=valid_cnt)
+                    kv = gemm["kv"](per_pair, count=pairs_cnt)
+                else:
+                    q = F.linear(pooled, w[:C], b[:C])
+                    kv = F.linear(per_pair, w[C:], b[C:])
+                ctx = ops.view_attend(q, kv, slot, valid_index, mha.num_heads, count=valid_cnt)
             if want_ctx and use_mfma:
                 return ctx, pc["row_of"]
             pooled = gemm["o"](ctx, count=valid_cnt) if use_mfma else F.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)

@@ -83,6 +83,36 @@ def make_scene(n_views, channels, kind="scannet", n_depth=12, seed=0, device="cp
     return feats, dpt, make_img_meta(n_views, kind, seed, img_hw=img_hw)
 
 
+def clustered_occupancy(n_voxels_list, seed=0, device="cpu"):
+    """A controlled, SURFACE-CLUSTERED occupancy for the refined levels (SURVEY.md 8d allows a controlled mask in place of the
+    data-dependent one; with random weights the learned occupancy scatters the top 25 % uniformly, which no sparse kernel can
+    exploit -- real occupancy sits on surfaces).  Returns one score tensor [X*Y*Z] float32 per refined level (levels 1 ...),
+    for ``AdaptiveSparseHead.occupancy_override``: score = -(distance of the voxel centre to the nearest surface of a small
+    seeded "room") + a seeded tie-breaker, so the level's top-k picks the k voxels nearest to the surfaces -- a floor, two
+    walls and the shell of a box (a piece of furniture), the same world surfaces at every level.  Coordinates are the unit
+    cube; k itself stays the config's ``topk_list`` (25 % of the level)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = torch.rand(8, generator=g)
+    floor_z = 0.06 + 0.06 * float(r[0])
+    wall_x = 0.05 + 0.08 * float(r[1])
+    wall_y = 0.95 - 0.08 * float(r[2])
+    lo = torch.tensor([0.30 + 0.2 * float(r[3]), 0.25 + 0.2 * float(r[4]), floor_z])
+    hi = lo + torch.tensor([0.25 + 0.1 * float(r[5]), 0.30 + 0.1 * float(r[6]), 0.30 + 0.2 * float(r[7])])
+    out = []
+    for nx, ny, nz in n_voxels_list[1:]:
+        ax = [(torch.arange(n, dtype=torch.float32) + 0.5) / n for n in (nx, ny, nz)]
+        x, y, z = torch.meshgrid(*ax, indexing="ij")
+        p = torch.stack([x, y, z], -1)
+        d_planes = torch.minimum(torch.minimum((z - floor_z).abs(), (x - wall_x).abs()), (y - wall_y).abs())
+        q = torch.maximum(lo - p, p - hi)                              # signed box distance, per axis
+        outside = q.clamp(min=0).norm(dim=-1)
+        inside = q.max(dim=-1).values.clamp(max=0)
+        d = torch.minimum(d_planes, (outside + inside).abs())
+        noise = torch.rand(d.shape, generator=g) * 1e-4                # breaks the exact ties of a symmetric grid
+        out.append((-(d + noise)).reshape(-1).contiguous().to(device))
+    return out
+
+
 # BASELINE.json configs as concrete hot-path shapes (SURVEY.md section 8d, A.6)
 def _lvl(finest, finest_size):
     grids = [tuple(v // 4 for v in finest), tuple(v // 2 for v in finest), tuple(finest)]

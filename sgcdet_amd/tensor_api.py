@@ -443,6 +443,27 @@ class TensorOps:
         self._call("sgc_view_attend", q, kv, slot, valid_index, ctx, N, Nq, Cc, heads, count, n_valid)
         return ctx
 
+    def view_attend_pq_supported(self, N, C, heads):
+        return bool(self.lib._dll.sgc_view_attend_pq_supported(int(N), int(C), int(heads)))
+
+    def view_attend_pq(self, qp, x, slot, valid_index, heads, count=None):
+        """Projected-query form of the softmax over views (``sgc_view_attend_pq``): qp [n_valid, heads * C] (= scale W_k,h^T q_h
+        per head), x [n_pairs, C] raw per-pair features, slot [N, Nq], valid_index [n_valid] -> s [n_valid, heads * C], the
+        attention-weighted pair feature of every head (the caller applies V per voxel)."""
+        self._check(qp=qp, x=x, slot=slot, valid_index=valid_index, count=count)
+        self._f32(qp=qp, x=x)
+        self._i32(slot=slot, valid_index=valid_index, count=count)
+        N, Nq = slot.shape
+        n_valid, HC = qp.shape
+        Cc = x.shape[1]
+        if HC != heads * Cc:
+            raise RuntimeError("view_attend_pq: qp must be [n_valid, heads * C]")
+        s = torch.empty_like(qp)
+        if n_valid == 0:
+            return s
+        self._call("sgc_view_attend_pq", qp, x, slot, valid_index, s, N, Nq, Cc, heads, count, n_valid)
+        return s
+
     # ---- 6. volume glue --------------------------------------------------------
     def scatter_rows(self, rows, idx, vol, idx2=None, count=None):
         self._check(rows=rows, idx=idx, vol=vol, idx2=idx2, count=count)
@@ -577,7 +598,7 @@ class TensorOps:
                    b2, ln2[0], ln2[1], float(ln2[2]), y, Nq, C, F, _meta=dict(V=Nq, Cin=C, Cout=5 * C, taps=1, OV=Nq))
         return y
 
-    def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None):
+    def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None, useful=None):
         """y[r] = x[r] @ W^T + shift for the first ``count`` rows (int32 device tensor; None = all rows) of
         x [rows_cap, Cin]; W as the bf16 split [1, Cout, Cin] of ``split_bf16``.  Rows past the count are left
         untouched (uninitialised in a fresh result)."""
@@ -594,8 +615,10 @@ class TensorOps:
             raise RuntimeError("linear_rows_bf16x3: bad `out` tensor")
         y = out if out is not None else torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
         if rows:
-            self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout,
-                       _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
+            meta = dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows)
+            if useful is not None:
+                meta["useful"] = useful           # block-diagonal weights run as a dense GEMM: the non-zero fraction (flop accounting)
+            self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout, _meta=meta)
         return y
 
     def conv2d_nhwc_bf16x3(self, x, w_hi, w_lo, nhw, ksize, scale=None, shift=None, residual=None, relu=False, out=None):

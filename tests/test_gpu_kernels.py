@@ -926,3 +926,38 @@ def test_batch_norm_rows_kernels_against_the_oracle_and_torch(rows, C, oracle_op
     assert float((xg.grad.cpu().double() - xd.grad).abs().max()) < 2e-4 * max(1.0, float(xd.grad.abs().max()))
     assert float((wg.grad.cpu().double() - wd.grad).abs().max()) < 2e-4 * max(1.0, float(wd.grad.abs().max()))
     assert float((bg.grad.cpu().double() - bd.grad).abs().max()) < 2e-4 * max(1.0, float(bd.grad.abs().max()))
+
+
+@pytest.mark.parametrize("N,Nq,C", [(40, 700, 256), (100, 900, 128), (3, 100, 256), (128, 300, 128)])
+def test_projected_query_attention_against_oracle(N, Nq, C, oracle_ops, gpu_ops):
+    """sgc_view_attend_pq vs its oracle twin (double accumulation) on random visible-pair lists: one and many cameras per voxel,
+    voxels seen by exactly one camera (softmax weight 1), the device-side count, and -- composed with the V projection -- against
+    sgc_view_attend on the in-projected k | v (the function it replaces).  Repeated launches are bit-identical."""
+    from tests.test_oracle_identity import _pq_case
+    heads = 8
+    pooled, x, slot, valid_index, mha = _pq_case(N, Nq, C, heads, seed=5 + N, vis=0.3 if N > 3 else 0.6)
+    hd = C // heads
+    w, b = mha.in_proj_weight.detach().double(), mha.in_proj_bias.detach().double()
+    q = pooled.double() @ w[:C].t() + b[:C]
+    scale = (1.0 / hd) ** 0.5
+    qp = torch.cat([scale * q[:, h * hd:(h + 1) * hd] @ w[C:2 * C][h * hd:(h + 1) * hd] for h in range(heads)], 1).float().contiguous()
+    want = oracle_ops.view_attend_pq(qp, x, slot, valid_index, heads)
+    cu = lambda t: t.cuda()
+    got = gpu_ops.view_attend_pq(cu(qp), cu(x), cu(slot), cu(valid_index), heads)
+    scale_s = max(1.0, float(want.abs().max()))
+    assert (got.cpu() - want).abs().max() < 1e-5 * scale_s
+    again = gpu_ops.view_attend_pq(cu(qp), cu(x), cu(slot), cu(valid_index), heads)
+    assert torch.equal(got, again)
+    # device-side row count: rows past it are not written
+    n_valid = valid_index.numel()
+    cnt = torch.tensor([n_valid - 3], dtype=torch.int32, device="cuda")
+    part = gpu_ops.view_attend_pq(cu(qp), cu(x), cu(slot), cu(valid_index), heads, count=cnt)
+    assert torch.equal(part[:n_valid - 3], got[:n_valid - 3])
+    # composed with V: the attention it replaces
+    ctx_pq = torch.cat([got.cpu()[:, h * C:(h + 1) * C].double() @ w[2 * C:][h * hd:(h + 1) * hd].t() for h in range(heads)], 1) + b[2 * C:]
+    kv = (x.double() @ w[C:].t() + b[C:]).float().contiguous()
+    ctx_ref = gpu_ops.view_attend(cu(q.float().contiguous()), cu(kv), cu(slot), cu(valid_index), heads).cpu()
+    assert (ctx_pq.float() - ctx_ref).abs().max() < 2e-5 * max(1.0, float(ctx_ref.abs().max()))
+    assert gpu_ops.view_attend_pq_supported(N, C, heads) and not gpu_ops.view_attend_pq_supported(129, C, heads)
+    with pytest.raises(RuntimeError):
+        gpu_ops.view_attend_pq(cu(qp[:, :4 * C].contiguous()), cu(x), cu(slot), cu(valid_index), 4)

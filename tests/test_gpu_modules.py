@@ -99,11 +99,15 @@ def test_neck_and_heads_against_reference_golden():
         assert max_err(boxes.cpu()[key_g], d["boxes"][key_r]) < 1e-3
 
 
-@pytest.mark.parametrize("name,n_views", [("cfg1_plumbing", 2), ("cfg2_scannet", 6), ("cfg3_arkit", 4),
-                                          ("cfg4_scannet200_large", 3), ("cfg5_arkit_large", 3)])
-def test_hot_path_against_oracle(name, n_views):
+@pytest.mark.parametrize("name,n_views,pq", [("cfg1_plumbing", 2, "auto"), ("cfg2_scannet", 6, "auto"), ("cfg3_arkit", 4, "auto"),
+                                             ("cfg4_scannet200_large", 3, "auto"), ("cfg5_arkit_large", 3, "auto"),
+                                             ("cfg2_scannet", 6, True), ("cfg5_arkit_large", 3, True)])
+def test_hot_path_against_oracle(name, n_views, pq):
     """Seeded synthetic scene of the BASELINE shapes (views reduced for cfg2 so the CPU oracle
-    finishes in seconds) -- volume / neck / head tensors within 1e-3, masks and top-k sets bit-exact."""
+    finishes in seconds) -- volume / neck / head tensors within 1e-3, masks and top-k sets bit-exact.
+    ``pq`` True: the projected-query form of the inter-view attention (sgc_view_attend_pq) forced on at these small view
+    counts ("auto" takes it from 24 views on: the full-view-count tests below run it) -- against the same oracle, which
+    restates nn.MultiheadAttention on the reference's dense slots."""
     import sgcdet_amd.plugin  # noqa: F401
     from sgcdet_amd.mmcv_lite import build_detector
     from sgcdet_amd.scene import make_scene, model_config, workload
@@ -111,6 +115,12 @@ def test_hot_path_against_oracle(name, n_views):
     w = workload(name)
     torch.manual_seed(7)
     det = build_detector(model_config(w)).eval()
+    n_pq = 0
+    for m in det.modules():
+        if hasattr(m, "projected_query"):
+            m.projected_query = pq
+            n_pq += 1
+    assert n_pq == 3
     gen = torch.Generator().manual_seed(3)
     with torch.no_grad():   # default init leaves the attention data-independent: perturb deterministically
         for n, p in det.voxel_head.named_parameters():
@@ -127,6 +137,16 @@ def test_hot_path_against_oracle(name, n_views):
     n_fin = w["n_voxels_list"][-1][0] * w["n_voxels_list"][-1][1] * w["n_voxels_list"][-1][2]
     res = check_sparse_head(r["volume"], r["valid"], r["occ"], vol_c, valid_c, occ_c, n_fin, w["topk_list"])
     assert res["tie_flips"] <= 4       # selected sets bit-exact up to near ties at the cut
+    if pq is True:                     # the form under test really ran (call log of the library binding)
+        from sgcdet_amd import ext
+        ops = ext.ops()
+        ops.event_log, ops.event_names = [], {"sgc_view_attend_pq", "sgc_view_attend"}
+        with torch.no_grad():
+            det.forward_features([f.cuda() for f in feats], [meta], dpt.cuda())
+        torch.cuda.synchronize()
+        names = [e[0] for e in ops.event_log]
+        ops.event_log, ops.event_names = None, None
+        assert names.count("sgc_view_attend_pq") == 3 and "sgc_view_attend" not in names
     # neck + head on the oracle's volume (torch-CPU conv3d) vs the GPU path
     rp2 = RefPath({**{"neck." + k: v for k, v in det.neck_3d.state_dict().items()},
                    **{"head." + k: v for k, v in det.bbox_head.state_dict().items()}},
@@ -891,14 +911,16 @@ def test_scene_graph_follows_weight_updates():
         assert torch.equal(x, y)
 
 
-def test_masked_decoder_tail_gives_the_dense_detections():
+@pytest.mark.parametrize("occupancy", ["predicted", "clustered"])
+def test_masked_decoder_tail_gives_the_dense_detections(occupancy):
     """Row N1 (north star: "sparse 3D convolution over the occupancy-masked voxels"): with ``masked_tail`` the finest
     decoder convolutions and the head convolutions only have to be right where the head's valid pyramid (or its 3x3x3
     dilations) is 1.  On a config-2 scene: head tensors bit-identical to the dense path wherever valid, everything
-    finite, and the decoded + NMS'ed detections identical."""
+    finite, and the decoded + NMS'ed detections identical.  ``clustered``: the surface-clustered occupancy override
+    (scene.clustered_occupancy) -- the workload on which whole bricks are dead, so the skip paths of the masked kernel run."""
     import sgcdet_amd.plugin  # noqa: F401
     from sgcdet_amd.mmcv_lite import build_detector
-    from sgcdet_amd.scene import make_scene, model_config, workload
+    from sgcdet_amd.scene import clustered_occupancy, make_scene, model_config, workload
     w = workload("cfg2_scannet")
     torch.manual_seed(3)
     det = build_detector(model_config(w)).eval()
@@ -908,6 +930,8 @@ def test_masked_decoder_tail_gives_the_dense_detections():
             p.add_(torch.randn(p.shape, generator=gen) * 0.05)
     det = det.cuda()
     det.use_graph = False
+    if occupancy == "clustered":
+        det.voxel_head.occupancy_override = clustered_occupancy(w["n_voxels_list"], seed=0, device="cuda")
     feats, dpt, meta = make_scene(12, w["embed_dims"], kind="scannet", seed=2, device="cuda")
     with torch.no_grad():
         det.masked_tail = False
@@ -920,6 +944,16 @@ def test_masked_decoder_tail_gives_the_dense_detections():
         det.masked_tail = False
     assert torch.equal(dense["valid"], sparse["valid"]) and torch.equal(dense["volume"], sparse["volume"])
     valid = dense["valid"].float()
+    assert int(valid.sum()) == w["topk_list"][-1]
+    if occupancy == "clustered":                         # the override really clusters: a third of the 8x8x4 bricks hold no valid voxel
+        live = torch.nn.functional.max_pool3d(valid, (8, 8, 4), (8, 8, 4)).mean().item()
+        assert live < 0.75, live
+        # ... and it is the selection of the override's scores, ties and all (lowest flat index first, as sgc_topk_select)
+        sc = det.voxel_head.occupancy_override[-1]
+        order = torch.sort(sc, descending=True, stable=True).indices[:w["topk_list"][-1]]
+        want = torch.zeros_like(sc, dtype=torch.int64)
+        want[order] = 1
+        assert torch.equal(want.view_as(dense["valid"]), dense["valid"])
     n_checked = 0
     for key in ("centerness", "bbox_pred", "cls_score"):
         for a, b in zip(dense[key], sparse[key]):

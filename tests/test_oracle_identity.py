@@ -166,3 +166,50 @@ def test_oracle_view_attend_backward_is_multihead_attention_autograd():
     out[0].backward(gout.double())
     assert (ctx.double() - out[0].detach()).abs().max() < 2e-6
     assert (gq.double() - qd.grad).abs().max() < 2e-6 and (gkv.double() - kvd.grad).abs().max() < 2e-6
+
+
+def _pq_case(N, Nq, C, heads, seed, vis=0.35):
+    """Random visible-pair list + MHA weights: (q_in [n_valid, C] pooled features, x [pairs, C], slot, valid_index, mha)."""
+    g = torch.Generator().manual_seed(seed)
+    mask = torch.rand(N, Nq, generator=g) < vis
+    mask[0, ::7] = True                                   # some voxels seen by exactly the first camera
+    slot = torch.full((N, Nq), -1, dtype=torch.int32)
+    slot[mask] = torch.arange(int(mask.sum()), dtype=torch.int32)
+    valid_index = torch.nonzero(mask.any(0)).reshape(-1).to(torch.int32)
+    x = torch.randn(int(mask.sum()), C, generator=g)
+    pooled = torch.randn(valid_index.numel(), C, generator=g)
+    torch.manual_seed(seed)
+    mha = torch.nn.MultiheadAttention(C, heads, batch_first=False)
+    with torch.no_grad():
+        mha.in_proj_bias.copy_(torch.randn(3 * C, generator=g) * 0.3)
+        mha.in_proj_weight.mul_(3.0)                     # sharper softmax than the xavier default
+    return pooled, x, slot, valid_index, mha
+
+
+@pytest.mark.parametrize("N,Nq,C,heads", [(5, 60, 32, 8), (40, 150, 128, 8), (13, 90, 256, 8)])
+def test_projected_query_attention_equals_multihead_attention(N, Nq, C, heads, oracle_ops):
+    """sgc_view_attend_pq (K and V off the pair list) is the same function as nn.MultiheadAttention over the views
+    (TU/deformable_cross_attention.py:826-833): against torch's module itself on the reference's dense [N, L, C] slots with
+    its key_padding_mask, and against the oracle's sgc_view_attend on the in-projected k | v."""
+    pooled, x, slot, valid_index, mha = _pq_case(N, Nq, C, heads, seed=11)
+    hd = C // heads
+    w, b = mha.in_proj_weight.detach().double(), mha.in_proj_bias.detach().double()
+    q = (pooled.double() @ w[:C].t() + b[:C])
+    scale = (1.0 / hd) ** 0.5
+    qp = torch.cat([scale * q[:, h * hd:(h + 1) * hd] @ w[C:2 * C][h * hd:(h + 1) * hd] for h in range(heads)], 1).float().contiguous()
+    s = oracle_ops.view_attend_pq(qp, x, slot, valid_index, heads)                       # [n_valid, heads * C]
+    ctx_pq = torch.cat([s[:, h * C:(h + 1) * C].double() @ w[2 * C:][h * hd:(h + 1) * hd].t() for h in range(heads)], 1) + b[2 * C:]
+    # (1) the oracle's MHA on in-projected pairs
+    kv = (x.double() @ w[C:].t() + b[C:]).float().contiguous()
+    ctx_ref = oracle_ops.view_attend(q.float().contiguous(), kv, slot, valid_index, heads)
+    assert (ctx_pq.float() - ctx_ref).abs().max() < 2e-5 * max(1.0, float(ctx_ref.abs().max()))
+    # (2) torch's nn.MultiheadAttention on dense slots with the padding mask (the reference's formulation)
+    n_valid = valid_index.numel()
+    dense = torch.zeros(N, n_valid, C)
+    sl = slot[:, valid_index.long()]
+    dense[sl >= 0] = x[sl[sl >= 0].long()]
+    with torch.no_grad():
+        out, _ = mha(pooled[None], dense, dense, key_padding_mask=(sl < 0).t())
+    want = out[0]
+    got = (ctx_pq @ mha.out_proj.weight.detach().double().t() + mha.out_proj.bias.detach().double()).float()
+    assert (got - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))

@@ -1,6 +1,7 @@
 """How sparse is the decoder tail really?  For bench-like scenes: fraction of finest-level voxels in valid, in its
 3x3x3 dilations (what out_block_0 / up_block_1's 3x3x3 conv must produce for the head to be exact on valid), and the
-fraction of 256-voxel bricks (4x4x16 / 4x8x8 / 8x8x4) holding at least one such voxel.  python tools/valid_stats.py [workload]"""
+fraction of 256-voxel bricks (4x4x16 / 4x8x8 / 8x8x4) holding at least one such voxel.
+python tools/valid_stats.py [workload] [predicted|clustered]   (clustered: scene.clustered_occupancy as the selection's scores)"""
 import os
 import sys
 
@@ -14,6 +15,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_scannet"
 from sgcdet_amd.scene import make_scene, workload  # noqa: E402
 w = workload(name)
 det = bench.build_path(w, "cuda")
+if len(sys.argv) > 2 and sys.argv[2] == "clustered":
+    from sgcdet_amd.scene import clustered_occupancy  # noqa: E402
+    det.voxel_head.occupancy_override = clustered_occupancy(w["n_voxels_list"], seed=0, device="cuda")
+    print("occupancy: clustered override")
 for seed in range(3):
     feats, dpt, meta = make_scene(w["n_views"], w["embed_dims"], kind=w["kind"], seed=seed, device="cuda",
                                   img_hw=(256, 320) if name.startswith("cfg2") else None)
