@@ -120,7 +120,8 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 # entry points whose launches the eager pass brackets with events: the gathers (HBM roofline) and every GEMM-shaped launch
 # (MFMA roofline); together they are the work the whole-path floor of `path_roofline` is made of
 PATH_KERNELS = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_pairs_geometry_sample", "sgc_conv3d_cl_bf16x3",
-                "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3", "sgc_linear_rows_headmajor_bf16x3"}
+                "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_bf16x3_act", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3",
+                "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3"}
 
 
 def usable_cores():

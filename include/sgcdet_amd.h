@@ -480,6 +480,16 @@ int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi, const uint
                                 const float *shift, const float *residual_or_null, float *y, const uint8_t *out_mask,
                                 int ix, int iy, int iz, int Cin, int Cout, int relu,
                                 float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream);
+/* The same 3x3x3 stride-1 convolution with an output activation on a column range (round 5): columns [act_c0, act_c1) leave as
+ * expf(v * *act_scale_dev), v being the epilogue's result (scale / shift / relu / residual as above) -- ImVoxelHeadV2's
+ * `torch.exp(self.scales[i](reg_conv(x)))` (dense_heads/imvoxel_head_v2.py:79,103-110; mmcv Scale = a learnable scalar, read from
+ * the device) inside the fused centerness | reg | cls convolution instead of two elementwise launches per scale.
+ * out_mask_or_null as in sgc_conv3d_cl_bf16x3_masked.  All other columns are bit-identical to sgc_conv3d_cl_bf16x3.            */
+int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                             const float *shift, const float *residual_or_null, float *y, const uint8_t *out_mask_or_null,
+                             int ix, int iy, int iz, int Cin, int Cout, int relu, int act_c0, int act_c1,
+                             const float *act_scale_dev, float *workspace_or_null, int64_t workspace_floats,
+                             sgc_stream_t stream);
 /* mask_out = 3x3x3 dilation of mask_in ([X*Y*Z] uint8 {0,1}, flat index (x*Y + y)*Z + z); must not alias. */
 int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream);
 /* Head valid mask of scale `factor` (1, 2, 4): nn.Upsample(size, mode='trilinear')(valid.float()).round().bool()
@@ -495,6 +505,13 @@ int sgc_valid_pyramid(const int64_t *valid, uint8_t *mask_out, int X, int Y, int
 int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                            float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
                            sgc_stream_t stream);
+
+/* The same Linear with ONE extra all-zero row behind its result (round 5): y holds rows_cap + 1 rows, rows [0, count) are the
+ * Linear, row rows_cap is set to zero by the same launch -- the row sgc_pairs_deform_gather's value_has_zero_row points
+ * out-of-image corners at (a separate fill was one more launch per level).  rows_cap > 0.                                    */
+int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                                sgc_stream_t stream);
 
 /* value_proj (TU/deformable_cross_attention.py:417) with the result stored HEAD-MAJOR for the tiled gather:
  *   x [N*S][Cin] camera-major pixel rows -> y [N][M][S][Cm], y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j].

@@ -1139,6 +1139,25 @@ int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi, const uint
                               workspace_or_null, workspace_floats, stream);
 }
 
+/* the head's fused convolution with exp(scale(reg)) on columns [act_c0, act_c1) (dense_heads/imvoxel_head_v2.py:79,103-110):
+ * the dense convolution, then the activation as the reference applies it -- x * scale (mmcv Scale), then exp */
+int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                             const float *shift, const float *residual_or_null, float *y, const uint8_t *out_mask_or_null,
+                             int ix, int iy, int iz, int Cin, int Cout, int relu, int act_c0, int act_c1,
+                             const float *act_scale_dev, float *workspace_or_null, int64_t workspace_floats,
+                             sgc_stream_t stream) {
+  (void)out_mask_or_null;
+  if (!act_scale_dev || act_c0 < 0 || act_c1 > Cout || act_c1 <= act_c0) return fail(SGC_EINVAL, "bad activation range");
+  const int rc = sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, 3, 1, 0, relu,
+                                      workspace_or_null, workspace_floats, stream);
+  if (rc) return rc;
+  const int64_t OV = (int64_t)ix * iy * iz;
+  const float s = *act_scale_dev;
+  for (int64_t v = 0; v < OV; ++v)
+    for (int c = act_c0; c < act_c1; ++c) y[v * Cout + c] = expf(y[v * Cout + c] * s);
+  return SGC_OK;
+}
+
 int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream) {
   (void)stream;
   if (!mask_in || !mask_out || mask_in == mask_out) return fail(SGC_EINVAL, "null or aliased pointers");
@@ -1189,6 +1208,15 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
   if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
   if (rows <= 0) return SGC_OK;
   return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, NULL, 0, stream);
+}
+
+/* the same with one all-zero row behind the result (y holds rows_cap + 1 rows) */
+int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                                sgc_stream_t stream) {
+  if (rows_cap <= 0 || !y) return fail(SGC_EINVAL, "needs rows_cap > 0 and an output");
+  for (int c = 0; c < Cout; ++c) y[(int64_t)rows_cap * Cout + c] = 0.f;
+  return sgc_linear_rows_bf16x3(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, stream);
 }
 
 /* value_proj with a head-major result: y[n][h][s][j] = (x[n*S+s] @ W^T + shift)[h*Cm + j] */

@@ -39,11 +39,13 @@ SIGNATURES = {
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3_masked": [_p] * 8 + [_i] * 6 + [_p, C.c_int64] + [_p],
+    "sgc_conv3d_cl_bf16x3_act": [_p] * 8 + [_i] * 8 + [_p, _p, C.c_int64] + [_p],
     "sgc_conv2d_nhwc_bf16x3": [_p] * 7 + [_i] * 7 + [_p],
     "sgc_conv3d_wgrad_bf16x3": [_p] * 3 + [_i] * 7 + [_p, C.c_int64] + [_p],
     "sgc_mask_dilate3": [_p, _p, _i, _i, _i, _p],
     "sgc_valid_pyramid": [_p, _p, _i, _i, _i, _i, _p],
     "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
+    "sgc_linear_rows_zrow_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
     "sgc_level_tail": [_p] * 7 + [_f] + [_p] * 8 + [_f] + [_p] + [_i] * 3 + [_p],
     "sgc_topk_select": [_p, _i, _i, _p, _p, _p, _p],
     "sgc_topk_select_ws": [_p, _i, _i, _p, _p, _p, _p, C.c_int64, _p],

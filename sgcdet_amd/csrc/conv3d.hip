@@ -58,7 +58,7 @@ int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo ke
 bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_t ldx);
 int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                      const float *shift, const float *residual, void *y, const int32_t *m_dev, int M, int K, int N, int relu,
-                     int hm_S, int hm_cm, int hm_bf16, hipStream_t st);
+                     int hm_S, int hm_cm, int hm_bf16, hipStream_t st, float *zero_row = nullptr);
 
 struct ConvParams {
   const float *x;         // [IV, Cin] channels-last input volume
@@ -91,10 +91,20 @@ struct ConvParams {
   int xcd_deal;           // tile kernel: how workgroups are dealt to the 8 XCDs (hardware: linear id % 8).  0 = as launched;
                           // 1 = consecutive ROW tiles of one (column tile, split) on one XCD (they share a weight slab);
                           // 2 = consecutive COLUMN tiles of one (row tile, split) on one XCD (they share the gathered rows)
+  float *zero_row;        // optional: Cout floats this launch sets to zero (workgroup (0, 0, 0); sgc_linear_rows_zrow_bf16x3)
+  const float *act_scale; // optional: columns [act_c0, act_c1) leave as expf(v * *act_scale) -- the head's `exp(scale(reg))` (dense_heads/
+  int act_c0, act_c1;     // imvoxel_head_v2.py:79,110: mmcv Scale then torch.exp) applied last in the epilogue (sgc_conv3d_cl_bf16x3_act)
   int hm_bf16;            // head-major output stored as bfloat16 (RNE of the fp32 result)
   int hm_S, hm_cm;        // hm_cm > 0: HEAD-MAJOR output of a row-list GEMM -- row r = n * hm_S + s, column c = h * hm_cm + j
                           // is stored at y[((n * (Cout / hm_cm) + h) * hm_S + s) * hm_cm + j] (sgc_linear_rows_headmajor_bf16x3)
 };
+
+// the optional output activation of a column range (ConvParams.act_*): applied after scale / shift / relu / residual
+__device__ __forceinline__ float act_col(float v, int col, int c0, int c1, float s) { return (col >= c0 && col < c1) ? expf(v * s) : v; }
+__device__ __forceinline__ float4 act_col4(float4 v, int col, int c0, int c1, float s) {
+  if (c1 <= c0) return v;
+  return make_float4(act_col(v.x, col, c0, c1, s), act_col(v.y, col + 1, c0, c1, s), act_col(v.z, col + 2, c0, c1, s), act_col(v.w, col + 3, c0, c1, s));
+}
 
 constexpr int BM = 128, BK = 32, LDK = BK + 4;
 
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_f32_kernel(const ConvParams 
           if (p.relu == 2) v = fmaxf(v, 0.f);
           if (p.residual) v += p.residual[orow * p.Cout + col];
           if (p.relu == 1) v = fmaxf(v, 0.f);
+          if (p.act_scale) v = act_col(v, col, p.act_c0, p.act_c1, *p.act_scale);
           *dst = v;
         }
       }
@@ -281,6 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     else                 { by = t % gridDim.y; t /= gridDim.y; bx = t % gridDim.x; bz = t / gridDim.x; }
   }
   const int m0 = bx * BMT, n0 = by * BN;
+  if (p.zero_row && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int c = threadIdx.x; c < p.Cout; c += NT) p.zero_row[c] = 0.f;
   const int Mrows = p.m_dev ? min(p.M, *p.m_dev) : p.M;
   if (m0 >= Mrows) return;
   int zid = bz;
@@ -519,6 +532,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
       }
       if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.act_scale) v = act_col4(v, col, p.act_c0, p.act_c1, *p.act_scale);
       *reinterpret_cast<float4 *>(p.y + orow * p.Cout + col) = v;
     }
     return;
@@ -550,6 +564,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
           if (p.relu == 2) v = fmaxf(v, 0.f);
           if (p.residual) v += p.residual[orow * p.Cout + col];
           if (p.relu == 1) v = fmaxf(v, 0.f);
+          if (p.act_scale) v = act_col(v, col, p.act_c0, p.act_c1, *p.act_scale);
           *dst = v;
         }
       }
@@ -699,6 +714,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           if (p.relu == 2) v = fmaxf(v, 0.f);
           if (p.residual) v += p.residual[orow * p.Cout + col + q];
           if (p.relu == 1) v = fmaxf(v, 0.f);
+          if (p.act_scale) v = act_col(v, col + q, p.act_c0, p.act_c1, *p.act_scale);
           p.y[orow * p.Cout + col + q] = v;
         }
       }
@@ -986,6 +1002,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
       }
       if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.act_scale) v = act_col4(v, col, p.act_c0, p.act_c1, *p.act_scale);
       *reinterpret_cast<float4 *>(p.y + orow * p.Cout + col) = v;
     }
     return;
@@ -1013,6 +1030,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
           if (p.relu == 2) v = fmaxf(v, 0.f);
           if (p.residual) v += p.residual[orow * p.Cout + col];
           if (p.relu == 1) v = fmaxf(v, 0.f);
+          if (p.act_scale) v = act_col(v, col, p.act_c0, p.act_c1, *p.act_scale);
           *dst = v;
         }
       }
@@ -1126,7 +1144,8 @@ static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
 
 __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restrict__ scale,
                                      const float *__restrict__ shift, const float *__restrict__ residual,
-                                     int64_t total4, int C4, int relu, const float *__restrict__ ws, int splits) {
+                                     int64_t total4, int C4, int relu, const float *__restrict__ ws, int splits,
+                                     const float *__restrict__ act_scale, int act_c0, int act_c1) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
     float4 v;
@@ -1148,6 +1167,7 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (act_scale) v = act_col4(v, c * 4, act_c0, act_c1, *act_scale);
     reinterpret_cast<float4 *>(y)[i] = v;
   }
 }
@@ -1204,7 +1224,7 @@ static int conv_finish(const ConvParams &p, int64_t OV, hipStream_t st) {
   const int64_t total4 = OV * p.Cout / 4;
   const int g = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(conv_epilogue_kernel, dim3(g), dim3(256), 0, st, p.y, p.scale, p.shift, p.residual, total4,
-                     p.Cout / 4, p.relu, (const float *)p.ws, p.splitk);
+                     p.Cout / 4, p.relu, (const float *)p.ws, p.splitk, p.act_scale, p.act_c0, p.act_c1);
   return check_launch("conv_epilogue_kernel");
 }
 
@@ -1281,10 +1301,12 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                          const float *shift, const float *residual_or_null, float *y,
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                          int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
-                         const uint8_t *out_mask_or_null, sgc_stream_t stream, int two_d = 0) {
+                         const uint8_t *out_mask_or_null, sgc_stream_t stream, int two_d = 0,
+                         const float *act_scale = nullptr, int act_c0 = 0, int act_c1 = 0) {
   ConvParamsB p = {};
   p.out_mask = out_mask_or_null;
   p.two_d = two_d;
+  p.act_scale = act_c1 > act_c0 ? act_scale : nullptr; p.act_c0 = act_c0; p.act_c1 = act_c1;
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
   if (rc) return rc;
@@ -2147,6 +2169,21 @@ extern "C" int sgc_conv3d_cl_bf16x3_masked(const float *x, const uint16_t *w_hi,
                        workspace_or_null, workspace_floats, out_mask, stream);
 }
 
+// 3x3x3 stride-1 convolution whose columns [act_c0, act_c1) leave as expf(v * *act_scale_dev) -- the head's fused
+// centerness | reg | cls convolution with `torch.exp(scale(reg))` (dense_heads/imvoxel_head_v2.py:79,103-110: mmcv Scale, a
+// learnable scalar, then exp) in the epilogue instead of two elementwise launches per scale.  out_mask_or_null as in
+// sgc_conv3d_cl_bf16x3_masked.  The other columns are bit-identical to sgc_conv3d_cl_bf16x3.
+extern "C" int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
+                                        const float *shift, const float *residual_or_null, float *y,
+                                        const uint8_t *out_mask_or_null, int ix, int iy, int iz, int Cin, int Cout, int relu,
+                                        int act_c0, int act_c1, const float *act_scale_dev,
+                                        float *workspace_or_null, int64_t workspace_floats, sgc_stream_t stream) {
+  if (!act_scale_dev || act_c0 < 0 || act_c1 > Cout || act_c1 <= act_c0)
+    return set_error(SGC_EINVAL, "sgc_conv3d_cl_bf16x3_act: needs 0 <= act_c0 < act_c1 <= Cout and a scale pointer");
+  return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, 3, 1, 0, relu,
+                       workspace_or_null, workspace_floats, out_mask_or_null, stream, 0, act_scale_dev, act_c0, act_c1);
+}
+
 // 3x3x3 dilation of a {0,1} voxel mask (what a 3x3x3 convolution must produce so that its consumer is exact on `in`)
 __global__ void mask_dilate3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int X, int Y, int Z) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2238,7 +2275,7 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
 // back costs a host round trip per level.  The grid covers rows_cap; workgroups past *rows_dev exit at once.
 static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                        float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout, int hm_S, int hm_cm,
-                       int hm_bf16, sgc_stream_t stream) {
+                       int hm_bf16, sgc_stream_t stream, float *zero_row = nullptr) {
   if (!x || !w_hi || !w_lo || !y) return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: null pointer");
   if (rows_cap <= 0) return SGC_OK;
   if (Cin % 32 || Cout % 4) return set_error(SGC_EUNSUP, "sgc_linear_rows_bf16x3: needs Cin %% 32 == 0 and Cout %% 4 == 0");
@@ -2250,8 +2287,9 @@ static int linear_rows(const float *x, const uint16_t *w_hi, const uint16_t *w_l
     return set_error(SGC_EINVAL, "sgc_linear_rows_bf16x3: pointers must be 16-byte aligned");
   if (rows_gemm_supported(Cin, Cout, hm_cm, hm_S, rows_cap, Cin))
     return rows_gemm_launch(x, Cin, w_hi, w_lo, nullptr, shift, nullptr, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, hm_S, hm_cm,
-                            hm_bf16, (hipStream_t)stream);
+                            hm_bf16, (hipStream_t)stream, zero_row);
   ConvParamsB p = {};
+  p.zero_row = zero_row;
   p.x = x; p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.y = y; p.shift = shift;
   p.Cin = Cin; p.Cout = Cout;
@@ -2272,6 +2310,16 @@ extern "C" int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, cons
                                       float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
                                       sgc_stream_t stream) {
   return linear_rows(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, 0, 0, stream);
+}
+
+// ... with one extra all-zero row behind the result: y holds rows_cap + 1 rows and row rows_cap is set to zero by the SAME launch
+// (the wave gather points out-of-image corners at that row, sgc_pairs_deform_gather's value_has_zero_row -- a separate fill was one
+// more launch per level).  rows_cap > 0.
+extern "C" int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
+                                           float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,
+                                           sgc_stream_t stream) {
+  if (rows_cap <= 0 || !y) return set_error(SGC_EINVAL, "sgc_linear_rows_zrow_bf16x3: needs rows_cap > 0 and an output");
+  return linear_rows(x, w_hi, w_lo, shift, y, rows_dev_or_null, rows_cap, Cin, Cout, 0, 0, 0, stream, y + (int64_t)rows_cap * Cout);
 }
 
 // The same GEMM with a HEAD-MAJOR result: x holds N * S rows (camera-major pixels), the Cout columns are M heads of

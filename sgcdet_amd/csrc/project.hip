@@ -139,6 +139,118 @@ __global__ __launch_bounds__(1024) void valid_index_kernel(const int32_t *__rest
   if (threadIdx.x == 0) totals[1] = running;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the same compaction in TWO launches of independent 1024-query segments (the five kernels above are one block per
+// camera walking all Nq queries, a one-thread scan of the camera counts, and ONE block walking all Nq voxels: 5 launches and
+// 30 us per level at config 2, 100 us per level at config 5 where Nq = 73 728).
+//   scan1  grid (S, N + 1), S = ceil(Nq / 1024).  Row y < N: camera y, segment x -- local rank of every visible query inside the
+//          segment -> slot, the segment's count -> seg_cam[y * S + x].  Row y == N: voxel segment x -- #cameras seeing q ->
+//          vox_count, local rank of the seen voxels -> row_of, the segment's count -> seg_vox[x].
+//   scan2  same grid.  Every block sums the segment counts in front of it (<= N * S ints, a block reduction) and adds that
+//          base: slot / pair_cam / pair_q (camera rows), valid_index / row_of (voxel row); the blocks of segment 0 also write
+//          cam_count / cam_offset, block (0, N) the totals.
+// Pure integer work: the outputs are identical to the five-kernel form (tested), which stays for workspace == null.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_sum_1024(int v, int *wave_sums) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();                                  // wave_sums may still be read by a previous use
+  if (lane == 0) wave_sums[wid] = v;
+  __syncthreads();
+  int tot = 0;
+  for (int w = 0; w < 16; ++w) tot += wave_sums[w];
+  return tot;
+}
+
+__global__ __launch_bounds__(1024) void pairs_scan1_kernel(const uint8_t *__restrict__ mask, int N, int Nq, int S,
+                                                           int32_t *__restrict__ slot, int32_t *__restrict__ vox_count,
+                                                           int32_t *__restrict__ row_of, int32_t *__restrict__ seg_cam,
+                                                           int32_t *__restrict__ seg_vox) {
+  __shared__ int wave_sums[16];
+  const int seg = blockIdx.x, y = blockIdx.y, q = seg * 1024 + threadIdx.x;
+  int tot;
+  if (y < N) {
+    const bool f = q < Nq && mask[(int64_t)y * Nq + q] != 0;
+    const int r = block_scan_flags(f, &tot, wave_sums);
+    if (q < Nq) slot[(int64_t)y * Nq + q] = f ? r : -1;
+    if (threadIdx.x == 0) seg_cam[y * S + seg] = tot;
+  } else {
+    int c = 0;
+    if (q < Nq)
+      for (int n = 0; n < N; ++n) c += mask[(int64_t)n * Nq + q] != 0;
+    const bool f = c > 0;
+    const int r = block_scan_flags(f, &tot, wave_sums);
+    if (q < Nq) { vox_count[q] = c; row_of[q] = f ? r : -1; }
+    if (threadIdx.x == 0) seg_vox[seg] = tot;
+  }
+}
+
+__global__ __launch_bounds__(1024) void pairs_scan2_kernel(int N, int Nq, int S, int32_t *__restrict__ slot,
+                                                           int32_t *__restrict__ pair_cam, int32_t *__restrict__ pair_q,
+                                                           int32_t *__restrict__ cam_count, int32_t *__restrict__ cam_offset,
+                                                           int32_t *__restrict__ valid_index, int32_t *__restrict__ row_of,
+                                                           int32_t *__restrict__ totals, const int32_t *__restrict__ seg_cam,
+                                                           const int32_t *__restrict__ seg_vox) {
+  __shared__ int wave_sums[16];
+  const int seg = blockIdx.x, y = blockIdx.y, tid = threadIdx.x, q = seg * 1024 + tid;
+  if (y < N) {
+    const int before = y * S + seg;                  // segment counts in front of this one, camera-major
+    int part = 0;
+    for (int i = tid; i < before; i += 1024) part += seg_cam[i];
+    const int base = block_sum_1024(part, wave_sums);
+    if (seg == 0) {                                  // base == pairs of the cameras before y
+      int mine = 0;
+      for (int i = tid; i < S; i += 1024) mine += seg_cam[y * S + i];
+      const int cnt = block_sum_1024(mine, wave_sums);
+      if (tid == 0) { cam_offset[y] = base; cam_count[y] = cnt; }
+    }
+    if (q < Nq) {
+      const int r = slot[(int64_t)y * Nq + q];
+      if (r >= 0) {
+        const int p = base + r;
+        slot[(int64_t)y * Nq + q] = p;
+        pair_cam[p] = y;
+        pair_q[p] = q;
+      }
+    }
+  } else {
+    int part = 0;
+    for (int i = tid; i < seg; i += 1024) part += seg_vox[i];
+    const int base = block_sum_1024(part, wave_sums);
+    if (q < Nq) {
+      const int r = row_of[q];
+      if (r >= 0) { valid_index[base + r] = q; row_of[q] = base + r; }
+    }
+    if (seg == 0) {                                  // totals: {n_pairs, n_valid, max pairs of a camera, 0}
+      int vt = 0;
+      for (int i = tid; i < S; i += 1024) vt += seg_vox[i];
+      const int n_valid = block_sum_1024(vt, wave_sums);
+      int psum = 0, pmax = 0;
+      for (int n = tid; n < N; n += 1024) {
+        int c = 0;
+        for (int i = 0; i < S; ++i) c += seg_cam[n * S + i];
+        psum += c;
+        pmax = c > pmax ? c : pmax;
+      }
+      const int n_pairs = block_sum_1024(psum, wave_sums);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) pmax = max(pmax, __shfl_xor(pmax, o));
+      __syncthreads();
+      if ((tid & 63) == 0) wave_sums[tid >> 6] = pmax;
+      __syncthreads();
+      if (tid == 0) {
+        int mx = 0;
+        for (int w = 0; w < 16; ++w) mx = wave_sums[w] > mx ? wave_sums[w] : mx;
+        totals[0] = n_pairs; totals[1] = n_valid; totals[2] = mx; totals[3] = 0;
+        cam_offset[N] = n_pairs;
+      }
+    }
+  }
+}
+
+int g_tune_compact2 = 1;       // 1: the two-launch segment form of sgc_compact_pairs (needs the workspace), 0: the five kernels
+
 }  // namespace sgc
 
 using namespace sgc;
@@ -165,6 +277,15 @@ extern "C" int sgc_compact_pairs(const uint8_t *mask, int N, int Nq,
     return set_error(SGC_EINVAL, "sgc_compact_pairs: null pointer");
   if (N <= 0 || Nq <= 0 || N > 65535) return set_error(SGC_EINVAL, "sgc_compact_pairs: bad N/Nq");
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && g_tune_compact2 && N <= 4096) {
+    // workspace: row_of [Nq] | seg_cam [N * S] | seg_vox [S]   (N * S + S <= N * Nq + 2 N + 64: the documented size covers it)
+    const int S = ceil_div(Nq, 1024);
+    int32_t *row_of = workspace, *seg_cam = workspace + Nq, *seg_vox = seg_cam + (int64_t)N * S;
+    hipLaunchKernelGGL(pairs_scan1_kernel, dim3(S, N + 1), dim3(1024), 0, st, mask, N, Nq, S, slot, vox_count, row_of, seg_cam, seg_vox);
+    hipLaunchKernelGGL(pairs_scan2_kernel, dim3(S, N + 1), dim3(1024), 0, st, N, Nq, S, slot, pair_cam, pair_q, cam_count, cam_offset,
+                       valid_index, row_of, totals, seg_cam, seg_vox);
+    return check_launch("sgc_compact_pairs (segment form)");
+  }
   hipLaunchKernelGGL(cam_rank_kernel, dim3(N), dim3(1024), 0, st, mask, Nq, slot, cam_count);
   hipLaunchKernelGGL(cam_offset_kernel, dim3(1), dim3(64), 0, st, cam_count, N, cam_offset, totals);
   hipLaunchKernelGGL(fill_pairs_kernel, dim3(ceil_div(Nq, 256), N), dim3(256), 0, st, cam_offset, N, Nq, slot,

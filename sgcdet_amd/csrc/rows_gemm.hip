@@ -63,6 +63,8 @@ struct RowsGemmParams {
   int diag;                    // see g_tune_rows_diag
   unsigned long long *stamps;  // diagnostic builds only
   int64_t y_bytes;             // head-major output: bytes of the whole buffer (the range the stores are checked against)
+  float *zero_row;             // optional: N floats the launch sets to zero (the all-zero row behind the value map the wave gather
+                               // points out-of-image corners at, sgc_linear_rows_zrow_bf16x3) -- by workgroup 0, before its tiles
 };
 
 constexpr int RG_ROWS = 32;
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
+  if (p.zero_row && blockIdx.x == 0)
+    for (int c = tid; c < p.N; c += NT) p.zero_row[c] = 0.f;
   const int Mrows = p.m_dev ? min(p.M, *p.m_dev) : p.M;
   const int ntiles = (Mrows + RG_ROWS - 1) / RG_ROWS;
   // blocks that share an XCD (equal blockIdx % 8) take the column groups of the same stripes: the second group's
@@ -410,8 +414,9 @@ static int device_cus() {
 
 int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                      const float *shift, const float *residual, void *y, const int32_t *m_dev, int M, int K, int N, int relu,
-                     int hm_S, int hm_cm, int hm_bf16, hipStream_t st) {
+                     int hm_S, int hm_cm, int hm_bf16, hipStream_t st, float *zero_row) {
   RowsGemmParams p = {};
+  p.zero_row = zero_row;
   p.x = x; p.ldx = ldx;
   p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
   p.scale = scale; p.shift = shift; p.residual = residual; p.y = y; p.m_dev = m_dev;

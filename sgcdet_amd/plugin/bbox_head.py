@@ -88,16 +88,26 @@ class ImVoxelHeadV2(nn.Module):
     def _forward_hip(self, feats, valid_masks=None):
         """``valid_masks``: per scale a uint8 [X*Y*Z] mask (the head's own valid pyramid, :123,258): the tensors are only
         consumed there (scores are multiplied by it, :301), so the convolution may skip tiles without a valid voxel."""
+        from .conv_plan import CONV_MODE
         spec, n_reg = self._plan()
         ctr, reg, cls = [], [], []
+        # exp(scale(reg)) of the box distances (:79,110; the first 6 regression outputs of either head class) runs in the
+        # convolution's epilogue on the MFMA path -- no elementwise launches; the strict-fp32 convolution keeps the torch ops
+        fused = CONV_MODE == "bf16x3" and self.reg_exp_cols > 0
         for i, (x, scale) in enumerate(zip(feats, self.scales)):
             rows, grid = to_channels_last_rows(x)
-            y, g = spec(rows, grid, out_mask=None if valid_masks is None else valid_masks[i])
+            mask = None if valid_masks is None else valid_masks[i]
+            if fused:
+                y, g = spec(rows, grid, out_mask=mask, act=(1, 1 + self.reg_exp_cols, scale.scale))
+            else:
+                y, g = spec(rows, grid, out_mask=mask)
             full = rows_to_ncdhw(y, g, spec.cout)
             ctr.append(full[:, :1])
-            reg.append(self._reg_activation(full[:, 1:1 + n_reg], scale))
+            reg.append(full[:, 1:1 + n_reg] if fused else self._reg_activation(full[:, 1:1 + n_reg], scale))
             cls.append(full[:, 1 + n_reg:])
         return ctr, reg, cls
+
+    reg_exp_cols = 6          # both head classes: exp(scale(.)) on the six face distances; SunRgbd's seventh output (yaw) stays raw
 
     def _forward_autograd_hip(self, feats):
         """Training / autograd path on the HIP kernels: the three 3x3x3 convolutions of a scale as ONE convolution with the

@@ -68,11 +68,15 @@ class ConvSpec:
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.ksize, self.stride, self.transposed = ksize, stride, transposed
 
-    def __call__(self, x, grid, residual=None, relu=0, out_mask=None):
-        """``out_mask`` (uint8 [OV], bf16x3 mode, 3x3x3 stride-1 layers): only rows with 1 are needed downstream."""
+    def __call__(self, x, grid, residual=None, relu=0, out_mask=None, act=None):
+        """``out_mask`` (uint8 [OV], bf16x3 mode, 3x3x3 stride-1 layers): only rows with 1 are needed downstream.
+        ``act`` = (c0, c1, scale tensor): columns [c0, c1) leave as exp(v * scale) (bf16x3 mode; the caller applies it itself in
+        the strict-fp32 mode -- ``supports_act``)."""
         if CONV_MODE == "bf16x3":
             return ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, grid, self.ksize, self.stride,
-                                              self.transposed, self.scale, self.shift, residual, relu, out_mask=out_mask)
+                                              self.transposed, self.scale, self.shift, residual, relu, out_mask=out_mask, act=act)
+        if act is not None:
+            raise NotImplementedError("the output activation lives in the bf16x3 convolution's epilogue")
         return ext.ops().conv3d_cl(x, self.wt, grid, self.ksize, self.stride, self.transposed, self.scale,
                                    self.shift, residual, relu)
 
@@ -221,12 +225,8 @@ class LinearSpec:
         live rows of ``x`` (its remaining rows are capacity): rows past it are neither read nor written."""
         M = x.shape[0]
         if CONV_MODE == "bf16x3" and self.cout_p == self.cout:
-            out = None
-            if extra_zero_row:
-                buf = torch.empty((M + 1, self.cout), dtype=torch.float32, device=x.device)
-                buf[M].zero_()
-                out = buf[:M]
-            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count, out=out, useful=self.useful)
+            return ext.ops().linear_rows_bf16x3(x, self.w_hi, self.w_lo, self.shift, count=count, useful=self.useful,
+                                                zero_tail=bool(extra_zero_row) and M > 0)
         if count is not None:
             raise NotImplementedError("device-side row counts need the bf16x3 path and out_features % 4 == 0")
         if CONV_MODE == "bf16x3":

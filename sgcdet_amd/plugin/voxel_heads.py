@@ -101,7 +101,8 @@ class DenseHead(nn.Module):
         vox_coords = torch.cat([grid.reshape(3, -1).t(), flat[:, None]], dim=-1)
         new_origin = -self.n_voxels / 2.0 * self.voxel_size
         points = grid * self.voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
-        return vox_coords, points.view(3, -1).permute(1, 0)
+        # contiguous [Nvox, 3]: the projection kernel reads it as rows (a permuted view cost one strided copy per level and scene)
+        return vox_coords, points.view(3, -1).permute(1, 0).contiguous()
 
     def seed_rows(self, mlvl_feats, img_meta, idx=None, **kwargs):
         """Inference building block: features of the selected voxels as rows [Nq, C] (``idx`` ascending
@@ -194,9 +195,15 @@ class AdaptiveSparseHead(nn.Module):
         rows = self.base_heads[0].seed_rows([feat], img_meta, None, mlvl_dpt_dists=[dpt], **extra).contiguous()
         grid = tuple(int(v) for v in self.base_heads[0].n_voxels)
         occ_list, valid = [], None
+        # the reference returns cat(occ_preds_list[::-1], dim=1) (finest level first, AdaptiveSparseHead.py:99): every level's
+        # scores are written straight into their slice of that vector (no cat launch)
+        sizes = [int(h.n_voxels.prod()) for h in self.base_heads[1:]]
+        occ_all = torch.empty((1, sum(sizes)), dtype=torch.float32, device=rows.device) if sizes else None
+        ends = [sum(sizes[j:]) for j in range(len(sizes))]                    # level i occupies [ends[i-1] - sizes[i-1], ends[i-1])
         for i in range(1, len(self.base_heads)):
             lin = self.occ_pred_heads[i - 1][0]
-            up, occ, grid = ops.upsample2x_occ(rows, grid, lin.weight.reshape(-1), lin.bias)
+            up, occ, grid = ops.upsample2x_occ(rows, grid, lin.weight.reshape(-1), lin.bias,
+                                               occ_out=occ_all[0, ends[i - 1] - sizes[i - 1]:ends[i - 1]])
             occ_list.append(occ.view(1, -1))
             feat, dpt = self._level_inputs(i, mlvl_feats, img_meta, mlvl_dpt_dists)
             if (i - 1) < len(self.topk_list):
@@ -214,7 +221,7 @@ class AdaptiveSparseHead(nn.Module):
         volume = rows.view(nx, ny, nz, C).permute(3, 0, 1, 2).unsqueeze(0)
         if not occ_list:
             return volume, torch.ones([1, 1, nx, ny, nz], device=volume.device), None
-        occ_preds = torch.cat(occ_list[::-1], dim=1)
+        occ_preds = occ_all
         if valid is None:                       # no top-k at the last level (not an SGCDet config): everything is valid
             valid = torch.ones(nx * ny * nz, dtype=torch.int64, device=volume.device)
         return volume, valid.view(1, 1, nx, ny, nz), occ_preds

@@ -310,10 +310,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
     # Projected-query form of the inter-view attention (sgc_view_attend_pq, round 5): K and V leave the pair list.
     #   "auto": wherever the kernel supports the shape (8 heads, C in {128, 256}, <= 128 views) and a voxel is seen by enough
     #           cameras for the per-voxel GEMMs (C -> heads * C and heads * C -> C) to cost less than the per-pair K | V GEMM
-    #           (C -> 2C on every visible pair): break-even at ~8 visible cameras per voxel, i.e. ~25 ring views;
+    #           (C -> 2C on every visible pair): with the block-diagonal V run as a dense GEMM the break-even was MEASURED at ~45 ring views;
     #   True / False force it on (where supported) / off.  Same function of the inputs either way (~1e-6: association of sums).
     projected_query = {"0": False, "1": True}.get(__import__("os").environ.get("SGC_PROJECTED_QUERY", ""), "auto")   # env: A/B runs
-    projected_query_min_views = 24
+    projected_query_min_views = 48      # measured (profiles/r05_pq_ab.txt): 40 views -1 %, 50 views +1 %, 60 views +2.6 %, 100 views +9.8 %
 
     def _projected_query_plan(self, mha, plan):
         """qp = scale * W_k,h^T q_h as ONE Linear on the pooled feature (composed with the q / output projections of `qo`), and

@@ -526,9 +526,10 @@ class TensorOps:
         return self.split_f16(w) if self.lib._dll.sgc_get_conv_products() == 2 else self.split_bf16(w)
 
     def conv3d_cl_bf16x3(self, x, w_hi, w_lo, grid, ksize, stride=1, transposed=False, scale=None, shift=None,
-                         residual=None, relu=False, out=None, out_mask=None):
+                         residual=None, relu=False, out=None, out_mask=None, act=None):
         """As ``conv3d_cl`` with pre-split bf16 weights (see ``split_bf16``).  ``out_mask`` (uint8 [OV], 3x3x3 stride-1
-        layers only): rows with 0 are not needed by the caller (``sgc_conv3d_cl_bf16x3_masked``)."""
+        layers only): rows with 0 are not needed by the caller (``sgc_conv3d_cl_bf16x3_masked``).  ``act`` = (c0, c1, scale
+        tensor on the device): columns [c0, c1) leave as exp(v * scale) (``sgc_conv3d_cl_bf16x3_act``, 3x3x3 stride 1)."""
         self._check(x=x, w_hi=w_hi, w_lo=w_lo, scale=scale, shift=shift, residual=residual, out_mask=out_mask)
         self._f32(x=x, scale=scale, shift=shift, residual=residual)
         if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape:
@@ -548,6 +549,18 @@ class TensorOps:
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError("conv3d_cl_bf16x3: residual shape mismatch")
         ws, ws_n = self._conv_workspace(x.device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, 1)
+        if act is not None:
+            c0, c1, act_scale = act
+            self._check(act_scale=act_scale)
+            self._f32(act_scale=act_scale)
+            if transposed or ksize != 3 or stride != 1 or act_scale.numel() != 1:
+                raise RuntimeError("conv3d_cl_bf16x3: `act` needs a 3x3x3 stride-1 layer and a one-element scale tensor")
+            if out_mask is not None and (out_mask.dtype != torch.uint8 or out_mask.numel() != y.shape[0]):
+                raise RuntimeError("conv3d_cl_bf16x3: out_mask must be a uint8 mask of [OV]")
+            self._call("sgc_conv3d_cl_bf16x3_act", x, w_hi, w_lo, scale, shift, residual, y, out_mask, ix, iy, iz, Cin, Cout,
+                       int(relu), int(c0), int(c1), act_scale, ws, ws_n,
+                       _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0], masked=out_mask is not None))
+            return y, og
         if out_mask is not None:
             if transposed or ksize != 3 or stride != 1 or out_mask.dtype != torch.uint8 or out_mask.numel() != y.shape[0]:
                 raise RuntimeError("conv3d_cl_bf16x3: out_mask needs a 3x3x3 stride-1 layer and a uint8 mask of [OV]")
@@ -598,10 +611,11 @@ class TensorOps:
                    b2, ln2[0], ln2[1], float(ln2[2]), y, Nq, C, F, _meta=dict(V=Nq, Cin=C, Cout=5 * C, taps=1, OV=Nq))
         return y
 
-    def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None, useful=None):
+    def linear_rows_bf16x3(self, x, w_hi, w_lo, shift=None, count=None, out=None, useful=None, zero_tail=False):
         """y[r] = x[r] @ W^T + shift for the first ``count`` rows (int32 device tensor; None = all rows) of
         x [rows_cap, Cin]; W as the bf16 split [1, Cout, Cin] of ``split_bf16``.  Rows past the count are left
-        untouched (uninitialised in a fresh result)."""
+        untouched (uninitialised in a fresh result).  ``zero_tail``: the result is a view of a [rows + 1, Cout] buffer whose last
+        row the same launch sets to zero (``sgc_linear_rows_zrow_bf16x3``)."""
         self._check(x=x, w_hi=w_hi, w_lo=w_lo, shift=shift, count=count, out=out)
         self._f32(x=x, shift=shift, out=out)
         self._i32(count=count)
@@ -613,6 +627,13 @@ class TensorOps:
             raise RuntimeError("linear_rows_bf16x3: inconsistent shapes")
         if out is not None and (out.shape != (rows, Cout)):
             raise RuntimeError("linear_rows_bf16x3: bad `out` tensor")
+        if zero_tail:
+            if out is not None or rows == 0:
+                raise RuntimeError("linear_rows_bf16x3: zero_tail allocates its own [rows + 1, Cout] buffer (rows > 0)")
+            buf = torch.empty((rows + 1, Cout), dtype=torch.float32, device=x.device)
+            self._call("sgc_linear_rows_zrow_bf16x3", x, w_hi, w_lo, shift, buf, count, rows, Cin, Cout,
+                       _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows))
+            return buf[:rows]
         y = out if out is not None else torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
         if rows:
             meta = dict(V=rows, Cin=Cin, Cout=Cout, taps=1, OV=rows)
@@ -899,16 +920,19 @@ class TensorOps:
         return y, og
 
     # ---- coarse-to-fine glue -------------------------------------------------------------
-    def upsample2x_occ(self, vol, grid, w=None, b=None):
-        """vol [X*Y*Z, C] rows -> (up [8*X*Y*Z, C], occ [8*X*Y*Z] or None, (2X, 2Y, 2Z))."""
-        self._check(vol=vol, w=w, b=b)
-        self._f32(vol=vol, w=w, b=b)
+    def upsample2x_occ(self, vol, grid, w=None, b=None, occ_out=None):
+        """vol [X*Y*Z, C] rows -> (up [8*X*Y*Z, C], occ [8*X*Y*Z] or None, (2X, 2Y, 2Z)).  ``occ_out``: a contiguous fp32
+        [8*X*Y*Z] tensor (e.g. a slice of the level-concatenated occupancy vector) to write the scores into."""
+        self._check(vol=vol, w=w, b=b, occ_out=occ_out)
+        self._f32(vol=vol, w=w, b=b, occ_out=occ_out)
         ix, iy, iz = grid
         V, Cc = vol.shape
         if V != ix * iy * iz or (w is not None and w.numel() != Cc):
             raise RuntimeError("upsample2x_occ: inconsistent shapes")
+        if occ_out is not None and (w is None or occ_out.shape != (8 * V,)):
+            raise RuntimeError("upsample2x_occ: occ_out must be [8 * X * Y * Z] (and needs the occupancy Linear)")
         up = torch.empty((8 * V, Cc), dtype=torch.float32, device=vol.device)
-        occ = torch.empty(8 * V, dtype=torch.float32, device=vol.device) if w is not None else None
+        occ = occ_out if occ_out is not None else (torch.empty(8 * V, dtype=torch.float32, device=vol.device) if w is not None else None)
         self._call("sgc_upsample2x_occ", vol, w, b, up, occ, ix, iy, iz, Cc)
         return up, occ, (2 * ix, 2 * iy, 2 * iz)
 

@@ -490,3 +490,33 @@ def test_tile_kernel_options_are_bit_identical(cin, cout, grid, k, s, tr, oracle
         finally:
             gpu_ops.lib.call("sgc_set_tuning", key, back)
         assert torch.equal(y_v, y_d), (key, val)
+
+
+@pytest.mark.parametrize("grid,cin,cout", [((40, 40, 16), 128, 28), ((20, 20, 8), 128, 28), ((10, 10, 4), 128, 28), ((12, 12, 4), 64, 200),
+                                           ((24, 24, 8), 128, 24)])
+def test_conv_with_the_head_activation_in_its_epilogue(grid, cin, cout, oracle_ops, gpu_ops):
+    """sgc_conv3d_cl_bf16x3_act: columns [1, 7) leave as exp(v * scale) -- ImVoxelHeadV2's exp(scale(reg)) inside the fused
+    centerness | reg | cls convolution (dense_heads/imvoxel_head_v2.py:79,103-110) -- on every kernel the head's three scales reach
+    (halo bricks with 64-column tiles, the tile kernel with a split reduction and its epilogue kernel), with and without an
+    output mask.  Against the oracle twin; the untouched columns and torch's own exp(scale * x) of the plain launch, bit for bit."""
+    g = torch.Generator().manual_seed(sum(grid) + cout)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(27, cout, cin, generator=g) * 0.02
+    hi, lo = gpu_ops.split_bf16(w)
+    shift = torch.randn(cout, generator=g) * 0.1
+    s = torch.tensor(0.83)
+    want, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, None, shift, None, 0, act=(1, 7, s))
+    cu = lambda t: t.cuda()
+    plain, _ = gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, None, cu(shift), None, 0)
+    got, _ = gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, None, cu(shift), None, 0, act=(1, 7, cu(s)))
+    assert (got.cpu() - want).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))
+    assert torch.equal(got[:, :1], plain[:, :1]) and torch.equal(got[:, 7:], plain[:, 7:])
+    ref = torch.exp(plain[:, 1:7] * cu(s))                                     # what the two torch launches computed
+    assert ((got[:, 1:7] - ref).abs() <= 2.4e-7 * ref.abs()).all()             # same product, exp within 2 ulp of torch's
+    mask = (torch.rand(V, generator=g) < 0.3).to(torch.uint8).cuda()
+    mask[: V // 3] = 0                                                          # dead bricks
+    gm, _ = gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, None, cu(shift), None, 0, out_mask=mask, act=(1, 7, cu(s)))
+    assert torch.isfinite(gm).all() and torch.equal(gm[mask.bool()], got[mask.bool()])
+    with pytest.raises(RuntimeError):
+        gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, None, cu(shift), None, 0, act=(5, 5, cu(s)))

@@ -137,8 +137,18 @@ def _scene(N, Nq, seed):
     return ref3d.contiguous(), origin, proj.contiguous()
 
 
-@pytest.mark.parametrize("N,Nq", [(5, 400), (13, 3001)])
-def test_projection_and_compaction_bit_exact(N, Nq, oracle_ops, gpu_ops):
+@pytest.mark.parametrize("N,Nq,form", [(5, 400, 1), (13, 3001, 1), (13, 3001, 0), (100, 7000, 1), (3, 1024, 1), (40, 1025, 1), (2, 9, 1)])
+def test_projection_and_compaction_bit_exact(N, Nq, form, oracle_ops, gpu_ops):
+    """``form`` 1: the two-launch segment form of sgc_compact_pairs (round 5; one and many 1024-query segments, ragged last
+    segment, a single query), 0: the five kernels it replaces -- both against the oracle, every output, and the inverse map."""
+    gpu_ops.lib.call("sgc_set_tuning", b"compact2", form)
+    try:
+        _compaction_case(N, Nq, oracle_ops, gpu_ops)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"compact2", 1)
+
+
+def _compaction_case(N, Nq, oracle_ops, gpu_ops):
     ref3d, origin, proj = _scene(N, Nq, 3)
     rc_c, mk_c = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
     rc_g, mk_g = gpu_ops.project_points(ref3d.cuda(), origin.cuda(), proj.cuda(), 320., 239., 0.2, 5.0)
@@ -155,6 +165,10 @@ def test_projection_and_compaction_bit_exact(N, Nq, oracle_ops, gpu_ops):
     assert torch.equal(pg["pair_cam"][:n_pairs].cpu(), pc["pair_cam"][:n_pairs])
     assert torch.equal(pg["pair_q"][:n_pairs].cpu(), pc["pair_q"][:n_pairs])
     assert torch.equal(pg["valid_index"][:n_valid].cpu(), pc["valid_index"][:n_valid])
+    assert int(tot[3]) == 0 and torch.equal(pg["row_of"].cpu(), pc["row_of"])          # inverse of valid_index (sgc_level_tail's gather index)
+    inv = torch.full((Nq,), -1, dtype=torch.int32)
+    inv[pc["valid_index"][:n_valid].long()] = torch.arange(n_valid, dtype=torch.int32)
+    assert torch.equal(pg["row_of"].cpu(), inv)
 
 
 @pytest.mark.parametrize("C,M,P,HW", [(256, 8, 4, (15, 20)), (128, 8, 4, (14, 20)), (32, 8, 4, (7, 10))])
@@ -961,3 +975,31 @@ def test_projected_query_attention_against_oracle(N, Nq, C, oracle_ops, gpu_ops)
     assert gpu_ops.view_attend_pq_supported(N, C, heads) and not gpu_ops.view_attend_pq_supported(129, C, heads)
     with pytest.raises(RuntimeError):
         gpu_ops.view_attend_pq(cu(qp[:, :4 * C].contiguous()), cu(x), cu(slot), cu(valid_index), 4)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(3000, 256, 256), (777, 64, 36), (12800, 128, 128)])
+def test_linear_rows_with_the_zero_row_behind_the_result(rows, cin, cout, oracle_ops, gpu_ops):
+    """sgc_linear_rows_zrow_bf16x3: the Linear's rows are bit-identical to sgc_linear_rows_bf16x3 (persistent row GEMM and tile
+    kernel), the row behind them is zero after the SAME launch even when the buffer held garbage, with and without a
+    device-side count."""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, cin, generator=g).cuda()
+    w = torch.randn(1, cout, cin, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    hi, lo = hi.cuda(), lo.cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    plain = gpu_ops.linear_rows_bf16x3(x, hi, lo, b)
+    for trial in range(3):
+        junk = torch.full((rows + 1, cout), float("nan"), device="cuda")       # whatever the allocator hands out next
+        del junk
+        y = gpu_ops.linear_rows_bf16x3(x, hi, lo, b, zero_tail=True)
+        assert torch.equal(y, plain)
+        tail = torch.as_strided(y, (1, cout), (cout, 1), storage_offset=y.storage_offset() + rows * cout)
+        assert torch.equal(tail, torch.zeros_like(tail))
+    cnt = torch.tensor([rows - 5], dtype=torch.int32, device="cuda")
+    y = gpu_ops.linear_rows_bf16x3(x, hi, lo, b, count=cnt, zero_tail=True)
+    assert torch.equal(y[:rows - 5], plain[:rows - 5])
+    tail = torch.as_strided(y, (1, cout), (cout, 1), storage_offset=y.storage_offset() + rows * cout)
+    assert torch.equal(tail, torch.zeros_like(tail))
+    want = oracle_ops.linear_rows_bf16x3(x.cpu(), hi.cpu(), lo.cpu(), b.cpu(), zero_tail=True)
+    assert (y[:rows - 5].cpu() - want[:rows - 5]).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))

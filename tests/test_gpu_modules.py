@@ -106,7 +106,7 @@ def test_hot_path_against_oracle(name, n_views, pq):
     """Seeded synthetic scene of the BASELINE shapes (views reduced for cfg2 so the CPU oracle
     finishes in seconds) -- volume / neck / head tensors within 1e-3, masks and top-k sets bit-exact.
     ``pq`` True: the projected-query form of the inter-view attention (sgc_view_attend_pq) forced on at these small view
-    counts ("auto" takes it from 24 views on: the full-view-count tests below run it) -- against the same oracle, which
+    counts ("auto" takes it from 48 views on: the full-view-count tests of configs 3 / 4 / 5 below run it) -- against the same oracle, which
     restates nn.MultiheadAttention on the reference's dense slots."""
     import sgcdet_amd.plugin  # noqa: F401
     from sgcdet_amd.mmcv_lite import build_detector
