@@ -95,6 +95,11 @@ def parse():
                     help="seconds of the extra `sustained` leg (same configuration, back to back; 0 = skip)")
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the short `strict_fp32` leg (--conv-mode f32)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
+    ap.add_argument("--eager-geometry", default="as-timed", choices=["as-timed", "latency"],
+                    help="launch geometry of the eager one-scene-at-a-time pass behind the `roofline` objects and --breakdown: "
+                         "as-timed = the geometry of the timed region (with scenes in flight: the throughput geometry, which sizes "
+                         "the layers with few voxels for CU-time, not for their own latency), latency = every kernel alone at its "
+                         "latency-optimal split (what a per-layer table of kernel-alone times should be read with)")
     return ap.parse_args()
 
 
@@ -392,6 +397,8 @@ def main():
     # gather is bracketed by HIP events on its launch stream (its pair count comes back to the host here)
     scene_graph_was, det.scene_graph = det.scene_graph, False
     tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
+    if args.eager_geometry == "latency":
+        set_throughput_mode(False)
     ops.event_log = []
     ops.event_names = None if args.breakdown else PATH_KERNELS
     calls0 = ops.n_calls
@@ -403,6 +410,8 @@ def main():
     log, ops.event_log = ops.event_log, None
     lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(n_timed, 20))
     det.scene_graph, det.use_graph = scene_graph_was, tail_graph
+    if args.eager_geometry == "latency":
+        set_throughput_mode(args.streams > 1)       # back to the geometry the graphs were captured with (the self check compares bits)
     roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                      "after the timed region (the timed region replays hipGraphs, which cannot carry events, with several "
                      "scenes in flight; inside it the kernel shares the chip with the other scenes and runs 0-3 % longer, see "
@@ -481,7 +490,7 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         kernel=("sgc::dfa3d_fwd_tile_kernel (LDS-staged head windows, finest level)" if tiled_finest else
                                 "sgc::dfa3d_fwd_wave_kernel<kPairsDeform, P=4, M=8> (finest level)"),
-                        measured=roofline_pass,
+                        measured=roofline_pass, eager_geometry=args.eager_geometry,
                         avg_launch_us=round(t_avg * 1e6, 1), algorithmic_bytes=int(b_avg), launches=len(finest))
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
     roofline_mfma = None

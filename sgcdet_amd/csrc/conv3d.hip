@@ -47,7 +47,8 @@ int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
-int g_tune_halo_narrow = 1;       // halo kernel: 64-column tiles for layers with <= 64 output channels
+int g_tune_halo_narrow = 1;       // halo kernel: 1 = 64-column tiles for layers with <= 64 output channels and 32-column tiles (8 x 1
+                                  // waves) for <= 32; 64 = never below 64 columns (the round-2..4 form, A/B); 0 = always 128
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -611,11 +612,14 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   constexpr int NTAP = TD ? 9 : 27, XO = TD ? 0 : 1;    // taps; halo width along x
   // MFMA rows of the brick: 256 for the standard bricks; a brick with another voxel count (a whole small grid: 10 x 10 x 4, the
   // coarsest config-2 scale) is padded to a multiple of 128 rows (4 wave rows x 32) -- pad rows work on voxel 0 and are dropped
-  constexpr int NVOX = BX * BY * BZ, MROWS = (NVOX + 127) / 128 * 128;
-  constexpr int RT = MROWS / 128;                       // 32-row tiles per wave
+  // wave layout: WMV (rows) x WNV (columns) = 8 waves.  4 x 2 for 128- and 64-column tiles; 8 x 1 for the 32-column tile of the
+  // head's fused 28-column convolution (round 5: on 64 columns more than half of its matrix work was padding)
+  constexpr int WNV = BNV >= 64 ? 2 : 1, WMV = 8 / WNV;
+  constexpr int NVOX = BX * BY * BZ, MROWS = (NVOX + 32 * WMV - 1) / (32 * WMV) * (32 * WMV);
+  constexpr int RT = MROWS / (32 * WMV);                // 32-row tiles per wave
   constexpr unsigned short kPadRow = 0x8000;            // vox_tab flag of a pad row
   static_assert(MROWS <= 512, "one table entry per thread");
-  constexpr int TN = BNV / 64, WCOL = BNV / 2;          // 32-column tiles per wave, columns per wave
+  constexpr int TN = BNV / (32 * WNV), WCOL = BNV / WNV; // 32-column tiles per wave, columns per wave
   constexpr int HX = BX + 2 * XO, HY = BY + 2, HZ = BZ + 2, HROWS = HX * HY * HZ;
   constexpr int HZP = halo_pitch(BZ), LROWS = HX * HY * HZP;   // z-pitch of the LDS image (see halo_pitch)
   constexpr int NT = 512;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   unsigned short *vox_tab = reinterpret_cast<unsigned short *>(smem_h + halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WNV, wn = wid % WNV;
   const int nby = (p.gy + BY - 1) / BY, nbz = (p.gz + BZ - 1) / BZ;
   int bid = blockIdx.x;
   const int bk = bid % nbz; bid /= nbz;
@@ -1106,7 +1110,8 @@ static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
   p.stamps = g_halo_stamp_buf;
 #endif
   constexpr int LROWS = (TD ? BX : BX + 2) * (BY + 2) * halo_pitch(BZ);
-  constexpr int MROWS = (BX * BY * BZ + 127) / 128 * 128;
+  constexpr int RGRAN = BNV >= 64 ? 128 : 256;          // rows per (wave rows x 32): see the kernel's wave layout
+  constexpr int MROWS = (BX * BY * BZ + RGRAN - 1) / RGRAN * RGRAN;
   const size_t smem = halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t);   // table + 8 x 32 scratch
   static_assert(halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t) <= 160 * 1024, "brick does not fit the LDS");
   static std::atomic<uint64_t> attr_done{0};
@@ -1321,14 +1326,15 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     return rows_gemm_launch(x, Cin, w_hi, w_lo, scale, shift, residual_or_null, y, nullptr, (int)OV, Cin, Cout, relu, 0, 0, 0, st);
   // 3x3x3 stride-1 layers with enough voxels: halo-resident kernel (bricks of 256 voxels)
   if (g_tune_conv_halo && !p.two_d && !transposed && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout && p.M >= g_tune_halo_min_m) {
-    const bool narrow_n = g_tune_halo_narrow && Cout <= 64;          // 64-column tiles for the head's 28 / 32-column layers
+    const bool narrow_n = g_tune_halo_narrow && Cout <= 64;          // 64-column tiles for layers with <= 64 output channels,
+    const bool narrow_32 = g_tune_halo_narrow >= 1 && g_tune_halo_narrow != 64 && Cout <= 32;   // 32-column tiles (8 x 1 waves) for the head's 28 columns
     const int brick = halo_brick_shape(p.gx, p.gy, p.gz);
     if (brick == 0)
-      rc = narrow_n ? launch_halo<4, 4, 16, 64>(p, OV, st) : launch_halo<4, 4, 16>(p, OV, st);
+      rc = narrow_32 ? launch_halo<4, 4, 16, 32>(p, OV, st) : narrow_n ? launch_halo<4, 4, 16, 64>(p, OV, st) : launch_halo<4, 4, 16>(p, OV, st);
     else if (brick == 1)
-      rc = narrow_n ? launch_halo<4, 8, 8, 64>(p, OV, st) : launch_halo<4, 8, 8>(p, OV, st);
+      rc = narrow_32 ? launch_halo<4, 8, 8, 32>(p, OV, st) : narrow_n ? launch_halo<4, 8, 8, 64>(p, OV, st) : launch_halo<4, 8, 8>(p, OV, st);
     else
-      rc = narrow_n ? launch_halo<8, 8, 4, 64>(p, OV, st) : launch_halo<8, 8, 4>(p, OV, st);
+      rc = narrow_32 ? launch_halo<8, 8, 4, 32>(p, OV, st) : narrow_n ? launch_halo<8, 8, 4, 64>(p, OV, st) : launch_halo<8, 8, 4>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }

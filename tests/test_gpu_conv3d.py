@@ -520,3 +520,35 @@ def test_conv_with_the_head_activation_in_its_epilogue(grid, cin, cout, oracle_o
     assert torch.isfinite(gm).all() and torch.equal(gm[mask.bool()], got[mask.bool()])
     with pytest.raises(RuntimeError):
         gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, None, cu(shift), None, 0, act=(5, 5, cu(s)))
+
+
+@pytest.mark.parametrize("grid,cin,cout,relu,res", [((40, 40, 16), 128, 28, 0, False), ((20, 20, 8), 128, 28, 1, True), ((24, 24, 8), 256, 32, 2, True),
+                                                     ((17, 9, 16), 64, 20, 0, False), ((16, 16, 32), 32, 8, 1, False)])
+def test_32_column_tiles_are_bit_identical_to_the_64_column_form(grid, cin, cout, relu, res, oracle_ops, gpu_ops):
+    """Round 5: layers with <= 32 output channels (the head's fused 28-column convolution) run the halo kernel with 32-column
+    tiles and an 8 x 1 wave layout instead of 64 columns of which more than half were padding.  Every output sees the same
+    (tap, k-half, product) order: bit-identical to the 64-column form (`halo_narrow` = 64) on every brick shape, ragged grids,
+    split channel slices, with residual / relu modes and an output mask; and within tolerance of the oracle."""
+    g = torch.Generator().manual_seed(sum(grid) + cin + cout)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(27, cout, cin, generator=g) * 0.05
+    hi, lo = gpu_ops.split_bf16(w)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    residual = torch.randn(V, cout, generator=g) if res else None
+    cu = lambda t: None if t is None else t.cuda()
+    mask = (torch.rand(V, generator=g) < 0.3).to(torch.uint8).cuda()
+    mask[: V // 4] = 0
+    outs = {}
+    try:
+        for form in (64, 1):
+            gpu_ops.lib.call("sgc_set_tuning", b"halo_narrow", form)
+            outs[form] = [gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, cu(scale), cu(shift), cu(residual), relu)[0],
+                          gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, cu(scale), cu(shift), cu(residual), relu, out_mask=mask)[0]]
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"halo_narrow", 1)
+    assert torch.equal(outs[1][0], outs[64][0])
+    live = mask.bool()
+    assert torch.isfinite(outs[1][1]).all() and torch.equal(outs[1][1][live], outs[64][0][live])
+    want, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+    assert (outs[1][0].cpu() - want).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))
