@@ -480,7 +480,10 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled per the gfx950 correction); collected offline, committed under profiles/
         traffic, traffic_source = None, None
-        pmc_name = ("r04_gather_tile_pmc_hbm.json" if tiled_finest else "r01_gather_pmc_v5.json") if args.img == "256x320" else "none"
+        pmc_name = "none"
+        if args.img == "256x320":        # the newest committed PMC pass of this kernel
+            pmc_name = next((n for n in ("r05_gather_tile_pmc_hbm.json", "r04_gather_tile_pmc_hbm.json")
+                             if os.path.exists(os.path.join(ROOT, "profiles", n))), "none") if tiled_finest else "r01_gather_pmc_v5.json"
         pmc_file = os.path.join(ROOT, "profiles", pmc_name)
         if args.workload == "cfg2_scannet" and args.views in (None, 40) and args.storage == "f32" and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")

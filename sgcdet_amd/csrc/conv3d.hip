@@ -1095,9 +1095,26 @@ static int halo_small_grid(int gx, int gy, int gz, int Cout) {
   return 0;
 }
 
+int g_tune_halo_wave_fix = 1;  // latency geometry only: one more split when the workgroups of a launch overflow the CUs by a small
+                               // remainder (cfg3: 288 workgroups on 256 CUs took two full rounds)
+
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
   while (splitk < nchunks && (int64_t)bricks * nb * splitk < g_tune_halo_split_target) splitk *= 2;
+  // Wave quantisation (round 5).  One workgroup per CU: W workgroups take ceil(W / CUs) rounds of (fixed + slices * per_slice).  When a
+  // launch overflows the CUs by a small remainder -- 144 bricks x 2 column tiles = 288 workgroups on 256 CUs, BASELINE config 3's
+  // 256 -> 256 layers at 48 x 48 x 16: two full rounds, 0.36 of the MFMA peak against 0.47 for config 2's 200 workgroups -- halving the
+  // slices per workgroup (576 workgroups, three rounds of half the length) is faster alone although it adds a reduce pass.  Only in
+  // the LATENCY geometry (halo_split_target >= 192): with scenes in flight the other streams fill the idle CUs of the second round and
+  // what counts is CU-time, which a split only raises.  Cost model: 13.6 us fixed + 24.2 us per slice
+  // (profiles/r04_halo_fixed_cost.txt), + 20 us for the workspace round trip of a split.
+  if (g_tune_halo_wave_fix && g_tune_halo_split_target >= 192 && splitk == 1 && nchunks >= 2) {
+    const int cus = 256;
+    const int64_t w1 = (int64_t)bricks * nb, w2 = 2 * w1;
+    const double t1 = (double)((w1 + cus - 1) / cus) * (13.6 + 24.2 * nchunks);
+    const double t2 = (double)((w2 + cus - 1) / cus) * (13.6 + 24.2 * ((nchunks + 1) / 2)) + 20.0;
+    if (t2 < 0.92 * t1) splitk = 2;
+  }
   const int per = (nchunks + splitk - 1) / splitk;
   return (nchunks + per - 1) / per;
 }

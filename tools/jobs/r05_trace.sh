@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel-trace of a bench command: per-kernel shares.  usage: r05_trace.sh TAG WORKLOAD [extra bench args]
-# writes gpurun_out/${TAG}_kernel_stats.csv, ${TAG}_kernels_from_trace.json, ${TAG}_under_rocprof.json
+# writes gpurun_out/${TAG}_kernel_stats.csv, ${TAG}_kernels.json, ${TAG}_bench_line.json   (TAG must not start with rNN_bench_: that glob is the bench lines)
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r05_bench_cfg2}
@@ -8,12 +8,12 @@ WL=${2:-cfg2_scannet}
 shift; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --workload $WL --steps 40 --warmup 10 --no-cpu-baseline --no-strict-fp32 --sustain 0 "$@" > $R/gpurun_out/${TAG}_under_rocprof.json 2> /dev/null; echo rocprof $TAG rc $?
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --workload $WL --steps 40 --warmup 10 --no-cpu-baseline --no-strict-fp32 --sustain 0 "$@" > $R/gpurun_out/${TAG}_bench_line.json 2> /dev/null; echo rocprof $TAG rc $?
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 t=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1)
 if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv; fi
 if [ -n "$t" ]; then
-python3 - "$t" > $R/gpurun_out/${TAG}_kernels_from_trace.json <<'PY'
+python3 - "$t" > $R/gpurun_out/${TAG}_kernels.json <<'PY'
 import csv, json, sys, re, collections
 csv.field_size_limit(1 << 30)
 rows = list(csv.DictReader(open(sys.argv[1])))
