@@ -376,6 +376,11 @@ int sgc_scatter_rows(const float *rows, const int32_t *idx, const int32_t *idx2_
  *   from the full-resolution map: they are never materialised.                                     */
 int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, int Ws,
                           int H, int W, int step, sgc_stream_t stream);
+/* Its adjoint (training, round 5): dst [N, C, Hd, Wd] (NCHW, the whole plane written) from channels-last rows src [N, H*W, C]:
+ * dst[n][c][h][w] = src[n][h*W + w][c] inside the H x W crop, 0 outside (Hd >= H, Wd >= W).  The gradient of the rows the path
+ * samples w.r.t. the map the 2D stage holds (TU/transformer.py:151-170 flatten / permute; AdaptiveSparseHead.py:53-59 crop),
+ * which autograd otherwise builds from two strided copies per level.                                                        */
+int sgc_nhwc_to_nchw_pad(const float *src, float *dst, int N, int C, int H, int W, int Hd, int Wd, sgc_stream_t stream);
 
 /* Coarse-to-fine glue of AdaptiveSparseHead on channels-last volumes (AdaptiveSparseHead.py:64-82):
  *   up [8*ix*iy*iz, C] = trilinear x2 upsample of vol [ix*iy*iz, C] (F.interpolate, align_corners=False);

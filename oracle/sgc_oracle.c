@@ -946,6 +946,19 @@ int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C, int Hs, in
   return SGC_OK;
 }
 
+/* adjoint of the crop + transpose: dst [N, C, Hd, Wd] <- src [N, H*W, C], zero outside the H x W crop */
+int sgc_nhwc_to_nchw_pad(const float *src, float *dst, int N, int C, int H, int W, int Hd, int Wd, sgc_stream_t stream) {
+  (void)stream;
+  if (!src || !dst) return fail(SGC_EINVAL, "null pointer");
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Hd < H || Wd < W) return fail(SGC_EINVAL, "bad sizes");
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (int h = 0; h < Hd; ++h)
+        for (int w = 0; w < Wd; ++w)
+          dst[(((int64_t)n * C + c) * Hd + h) * Wd + w] = (h < H && w < W) ? src[(((int64_t)n * H + h) * W + w) * C + c] : 0.f;
+  return SGC_OK;
+}
+
 /* ---- 7. dense 3D convolution, channels-last (naive loops; semantics of nn.Conv3d(k,s,pad=k/2) /
  * nn.ConvTranspose3d(2,2) + folded BatchNorm + residual + ReLU as chained in necks/imvoxelnet.py) ---- */
 int sgc_conv3d_cl_f32(const float *x, const float *wt, const float *scale, const float *shift,

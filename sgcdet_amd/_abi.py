@@ -36,6 +36,7 @@ SIGNATURES = {
     "sgc_view_attend_pq": [_p] * 5 + [_i] * 4 + [_p, _i] + [_p],
     "sgc_scatter_rows": [_p] * 4 + [_p, _i, _i, _p],
     "sgc_nchw_to_nhwc_crop": [_p, _p] + [_i] * 7 + [_p],
+    "sgc_nhwc_to_nchw_pad": [_p, _p] + [_i] * 6 + [_p],
     "sgc_conv3d_cl_f32": [_p] * 6 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3_masked": [_p] * 8 + [_i] * 6 + [_p, C.c_int64] + [_p],

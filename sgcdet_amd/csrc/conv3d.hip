@@ -1095,8 +1095,8 @@ static int halo_small_grid(int gx, int gy, int gz, int Cout) {
   return 0;
 }
 
-int g_tune_halo_wave_fix = 1;  // latency geometry only: one more split when the workgroups of a launch overflow the CUs by a small
-                               // remainder (cfg3: 288 workgroups on 256 CUs took two full rounds)
+int g_tune_halo_wave_fix = 1;  // 1: latency geometry only -- one more split when the workgroups of a launch overflow the CUs by a small
+                               // remainder (cfg3: 288 workgroups on 256 CUs took two full rounds); 2: in the throughput geometry too (A/B)
 
 static int halo_splitk(int bricks, int nb, int nchunks) {
   int splitk = 1;
@@ -1108,7 +1108,7 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   // the LATENCY geometry (halo_split_target >= 192): with scenes in flight the other streams fill the idle CUs of the second round and
   // what counts is CU-time, which a split only raises.  Cost model: 13.6 us fixed + 24.2 us per slice
   // (profiles/r04_halo_fixed_cost.txt), + 20 us for the workspace round trip of a split.
-  if (g_tune_halo_wave_fix && g_tune_halo_split_target >= 192 && splitk == 1 && nchunks >= 2) {
+  if (g_tune_halo_wave_fix && (g_tune_halo_split_target >= 192 || g_tune_halo_wave_fix == 2) && splitk == 1 && nchunks >= 2) {
     const int cus = 256;
     const int64_t w1 = (int64_t)bricks * nb, w2 = 2 * w1;
     const double t1 = (double)((w1 + cus - 1) / cus) * (13.6 + 24.2 * nchunks);

@@ -478,6 +478,33 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 }
 
 
+// Adjoint of the crop + transpose above (training: the gradient of the channels-last rows w.r.t. the NCHW map the producer holds):
+// dst[n][c][h][w] = src[n][h * W + w][c] for h < H, w < W, written for the WHOLE [Hd, Wd] plane of dst (zero outside the crop when
+// Hd > H or Wd > W).  32 x 32 tiles through LDS: 128-byte reads along c, 128-byte writes along the destination pixels.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int C, int H, int W, int Hd, int Wd) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32;                          // destination pixel tile over Hd * Wd
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int HWd = Hd * Wd;
+  for (int j = ty; j < 32; j += 8) {                       // pixel p0 + j, channel c0 + tx
+    const int pd = p0 + j, c = c0 + tx;
+    float v = 0.f;
+    if (pd < HWd && c < C) {
+      const int h = pd / Wd, w = pd - h * Wd;
+      if (h < H && w < W) v = src[((int64_t)n * H * W + (int64_t)h * W + w) * C + c];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {                       // channel c0 + j, pixel p0 + tx
+    const int c = c0 + j, pd = p0 + tx;
+    if (c < C && pd < HWd) dst[((int64_t)n * C + c) * HWd + pd] = tile[tx][j];
+  }
+}
+
 // Trilinear x2 upsample of a channels-last volume fused with the occupancy head:
 //   up[v', :] = F.interpolate(vol, scale_factor=2, mode='trilinear', align_corners=False)   (AdaptiveSparseHead.py:64-69)
 //   occ[v']   = sigmoid(dot(up[v', :], w) + b)                                               (:71, Sequential(Linear(C,1), Sigmoid))
@@ -718,6 +745,15 @@ extern "C" int sgc_nchw_to_nhwc_crop(const float *src, float *dst, int N, int C,
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(H * W, 32), ceil_div(C, 32), N), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, Hs, Ws, H, W, step);
   return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sgc_nhwc_to_nchw_pad(const float *src, float *dst, int N, int C, int H, int W, int Hd, int Wd, sgc_stream_t stream) {
+  if (!src || !dst) return set_error(SGC_EINVAL, "sgc_nhwc_to_nchw_pad: null pointer");
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || Hd < H || Wd < W) return set_error(SGC_EINVAL, "sgc_nhwc_to_nchw_pad: bad sizes");
+  if (N > 65535) return set_error(SGC_EUNSUP, "sgc_nhwc_to_nchw_pad: N > 65535");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ceil_div(Hd * Wd, 32), ceil_div(C, 32), N), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     C, H, W, Hd, Wd);
+  return check_launch("nhwc_to_nchw_kernel");
 }
 
 extern "C" int sgc_upsample2x_occ(const float *vol, const float *w_or_null, const float *b_or_null, float *up,

@@ -142,6 +142,24 @@ def _require_bf16_planes(who):
                            "pack bfloat16 weight planes; switch to 'bf16x3' / 'bf16' or run under torch.no_grad()")
 
 
+class NchwToRowsFunction(Function):
+    """[N, C, h, w] map (any strides: the crop view of AdaptiveSparseHead.py:58-59) -> channels-last rows [N, h*w, C]
+    (TU/transformer.py:151-170 ``flatten(2).permute``) with the transpose on the HIP kernels in both directions: forward
+    ``sgc_nchw_to_nhwc_crop``, backward ``sgc_nhwc_to_nchw_pad`` (a contiguous NCHW gradient).  Autograd's own chain for
+    ``flatten / permute / contiguous`` is two strided copies per level (0.26 ms each at config 2's finest level)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[2], x.shape[3])
+        return ext.ops().nchw_to_nhwc_crop(x.detach().float(), x.shape[2], x.shape[3])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_rows):
+        h, w = ctx.hw
+        return ext.ops().nhwc_to_nchw_pad(grad_rows.float().contiguous(), h, w)
+
+
 def _pad_cols(t, mult):
     """[rows, C] -> [rows, ceil(C / mult) * mult] with zero columns (a view when nothing is added)."""
     c = t.shape[-1]

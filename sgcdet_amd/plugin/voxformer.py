@@ -1027,8 +1027,14 @@ class PerceptionTransformer_DFA3D(BaseModule):
                     f_rows = _channels_last_rows(feat[0], h, w) if feat.dtype == torch.float32 else None
                     feats.append(f_rows if f_rows is not None else ops.nchw_to_nhwc_crop(feat[0].float(), h, w))
             elif torch.is_grad_enabled() and (feat.requires_grad or dpt.requires_grad):
-                feats.append(feat[0].flatten(2).permute(0, 2, 1))
-                dists.append(dpt[0].flatten(2).permute(0, 2, 1))
+                if feat.is_cuda and feat.dtype == torch.float32 and dpt.dtype == torch.float32:
+                    # training: the transposes of both directions on the HIP kernels (functions.NchwToRowsFunction)
+                    from ..functions import NchwToRowsFunction
+                    feats.append(NchwToRowsFunction.apply(feat[0]))
+                    dists.append(NchwToRowsFunction.apply(dpt[0]))
+                else:
+                    feats.append(feat[0].flatten(2).permute(0, 2, 1))
+                    dists.append(dpt[0].flatten(2).permute(0, 2, 1))
             else:   # channels-last producers: no copy; otherwise one crop+transpose launch each
                 f_rows = _channels_last_rows(feat[0], h, w) if feat.dtype == torch.float32 else None
                 d_rows = _channels_last_rows(dpt[0], h, w) if dpt.dtype == torch.float32 else None

@@ -504,6 +504,19 @@ class TensorOps:
         self._call("sgc_nchw_to_nhwc_crop", src, dst, N, Cc, Hs, Ws, H, W, step)
         return dst
 
+    def nhwc_to_nchw_pad(self, rows, H, W, Hd=None, Wd=None):
+        """rows [N, H*W, C] -> [N, C, Hd, Wd] (contiguous NCHW; zero outside the H x W crop): the adjoint of
+        ``nchw_to_nhwc_crop`` (``sgc_nhwc_to_nchw_pad``)."""
+        self._check(rows=rows)
+        self._f32(rows=rows)
+        N, S, Cc = rows.shape
+        Hd, Wd = H if Hd is None else Hd, W if Wd is None else Wd
+        if S != H * W or Hd < H or Wd < W:
+            raise RuntimeError("nhwc_to_nchw_pad: inconsistent shapes")
+        dst = torch.empty((N, Cc, Hd, Wd), dtype=torch.float32, device=rows.device)
+        self._call("sgc_nhwc_to_nchw_pad", rows, dst, N, Cc, H, W, Hd, Wd)
+        return dst
+
     # ---- 7. channels-last 3D convolution -----------------------------------------------
     @staticmethod
     def split_bf16(w):

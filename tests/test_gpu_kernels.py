@@ -1003,3 +1003,28 @@ def test_linear_rows_with_the_zero_row_behind_the_result(rows, cin, cout, oracle
     assert torch.equal(tail, torch.zeros_like(tail))
     want = oracle_ops.linear_rows_bf16x3(x.cpu(), hi.cpu(), lo.cpu(), b.cpu(), zero_tail=True)
     assert (y[:rows - 5].cpu() - want[:rows - 5]).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("N,C,Hs,Ws,H,W", [(5, 256, 64, 80, 64, 80), (3, 12, 60, 80, 59, 80), (2, 40, 17, 23, 15, 20), (1, 7, 9, 9, 9, 9)])
+def test_rows_transpose_and_its_adjoint(N, C, Hs, Ws, H, W, oracle_ops, gpu_ops):
+    """sgc_nhwc_to_nchw_pad is the adjoint of sgc_nchw_to_nhwc_crop (pure data movement: bit-exact against the oracle and
+    against torch), and functions.NchwToRowsFunction gives the crop view of a map exactly the gradient autograd's
+    flatten / permute / contiguous chain gives it (AdaptiveSparseHead.py:58-59, TU/transformer.py:151-170)."""
+    from sgcdet_amd.functions import NchwToRowsFunction
+    g = torch.Generator().manual_seed(N * C + H)
+    rows = torch.randn(N, H * W, C, generator=g)
+    want = oracle_ops.nhwc_to_nchw_pad(rows, H, W, Hs, Ws)
+    got = gpu_ops.nhwc_to_nchw_pad(rows.cuda(), H, W, Hs, Ws)
+    assert torch.equal(got.cpu(), want)
+    ref = torch.zeros(N, C, Hs, Ws)
+    ref[:, :, :H, :W] = rows.view(N, H, W, C).permute(0, 3, 1, 2)
+    assert torch.equal(want, ref)
+    x = torch.randn(1, N, C, Hs, Ws, generator=g).cuda()
+    gy = torch.randn(N, H * W, C, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    ya = NchwToRowsFunction.apply(xa[:, :, :, :H, :W][0])
+    ya.backward(gy)
+    xb = x.clone().requires_grad_(True)
+    yb = xb[:, :, :, :H, :W][0].flatten(2).permute(0, 2, 1).contiguous()
+    yb.backward(gy)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
