@@ -125,7 +125,7 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 # entry points whose launches the eager pass brackets with events: the gathers (HBM roofline) and every GEMM-shaped launch
 # (MFMA roofline); together they are the work the whole-path floor of `path_roofline` is made of
 PATH_KERNELS = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_pairs_geometry_sample", "sgc_conv3d_cl_bf16x3",
-                "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_bf16x3_act", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3",
+                "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_bf16x3_act", "sgc_conv3d_winograd_z_bf16x3", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3",
                 "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3"}
 
 
@@ -498,6 +498,8 @@ def main():
     # ---- second object: the MFMA-bound kernel that takes the most time, the largest 3x3x3 convolution of the neck ----
     roofline_mfma = None
     cv = per_kernel.get("sgc_conv3d_cl_bf16x3" if args.conv_mode != "f32" else "sgc_conv3d_cl_f32", [])
+    if args.conv_mode != "f32":
+        cv = cv + per_kernel.get("sgc_conv3d_winograd_z_bf16x3", [])      # the same layers through the Winograd-z form (2/3 of the MACs issued)
     cv = [(t, m) for t, m in cv if m.get("taps") == 27]
     if cv:
         flops = lambda m: 2.0 * m["taps"] * m["Cin"] * m["Cout"] * m["OV"]      # noqa: E731
@@ -507,11 +509,15 @@ def main():
         bf = args.conv_mode != "f32"
         nprod = 3 if args.conv_mode == "bf16x3" else 1
         peak = 2500.0 if bf else 157.0      # dense bf16 / fp32 MFMA peak (MI355X_MICROARCH.md)
-        issued = top * nprod / t_c / 1e12
         m0 = big_c[0][1]
+        mac_frac = m0.get("mac_frac", 1.0)                 # Winograd F(2,3) along z issues 18 of the 27 tap-GEMMs
+        issued = top * mac_frac * nprod / t_c / 1e12
         roofline_mfma = dict(bound="mfma", achieved=round(issued, 1), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
-                             kernel=("sgc::conv3d_halo_bf16x3_kernel" if bf else "sgc::conv3d_igemm_f32_kernel") +
+                             kernel=(("sgc_conv3d_winograd_z_bf16x3 = input transform + sgc::conv3d_halo_bf16x3_kernel (2-D form, 4 positions) + "
+                                      "output transform, all three launches inside the bracket" if mac_frac < 1.0 else
+                                      "sgc::conv3d_halo_bf16x3_kernel") if bf else "sgc::conv3d_igemm_f32_kernel") +
                                     f" ({m0['Cin']}->{m0['Cout']} ch, 3x3x3, {m0['OV']} voxels)",
+                             mac_frac_issued=round(mac_frac, 4),
                              algorithmic_gflop=round(top / 1e9, 1), fp32_equivalent_tflops=round(top / t_c / 1e12, 1),
                              fp32_equivalent_note=("algorithmic fp32 FLOPs / time; it can exceed the 157 TFLOP/s fp32 MFMA peak "
                                                    "because the work runs as three bf16 products on the bf16 pipe" if bf else None),
@@ -529,6 +535,9 @@ def main():
         #  its structurally non-zero fraction `useful`: the zero blocks are launch geometry, not work the path has to do)
         gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0)
                    for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
+        # multiply-adds actually issued: the Winograd-z layers issue 2/3 of their algorithmic count (`mac_frac`)
+        gemm_issued = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0) * m.get("mac_frac", 1.0)
+                          for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
         gbytes = 0.0
         for name, items in per_kernel.items():
             for _, m in items:
@@ -540,7 +549,7 @@ def main():
                     gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * (12 + m["C"] * 4)
         gbytes /= n_e
         bf = args.conv_mode != "f32"
-        issued = gemm * (3 if args.conv_mode == "bf16x3" else 1)
+        issued = gemm_issued * (3 if args.conv_mode == "bf16x3" else 1)
         floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         # the same floor with the matrix pipe priced at what it SUSTAINS under the package power limit on non-zero data
         # (1847 TFLOP/s at 1.89 GHz / 1.31 kW, tools/probe/mfma_power.hip, profiles/r04_mfma_power.txt; the 2.5 PFLOP/s of

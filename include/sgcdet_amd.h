@@ -495,6 +495,19 @@ int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_
                              int ix, int iy, int iz, int Cin, int Cout, int relu, int act_c0, int act_c1,
                              const float *act_scale_dev, float *workspace_or_null, int64_t workspace_floats,
                              sgc_stream_t stream);
+/* The 3x3x3 stride-1 convolution through a Winograd F(2,3) transform ALONG Z (round 5): 18 instead of 27 tap-GEMMs per output --
+ * fewer multiply-adds is the lever left on layers that run at the package power limit.  Same operator as sgc_conv3d_cl_bf16x3
+ * (ksize 3, stride 1; nn.Conv3d + folded BatchNorm + residual + ReLU of necks/imvoxelnet.py:36-64,146-173), same epilogue; the sums
+ * are associated differently (tests bound the difference at 2e-5 of the tensor scale).
+ *   wg_hi / wg_lo: bf16 hi / lo planes of the TRANSFORMED weights [4][9][Cout][Cin]: for the (dx, dy) tap t = dx*3 + dy and the z taps
+ *   w0, w1, w2 of the module's weight: G[0][t] = w0, G[1][t] = (w0 + w1 + w2) / 2, G[2][t] = (w0 - w1 + w2) / 2, G[3][t] = w2.
+ *   workspace: >= sgc_conv3d_winograd_z_workspace_floats() floats (the transform-domain input and output stacks).
+ *   Supported (sgc_conv3d_winograd_z_supported): iz % 8 == 0, Cin % 32 == 0, Cout % 4 == 0, Cout > 64.                       */
+int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_hi, const uint16_t *wg_lo, const float *scale,
+                                 const float *shift, const float *residual_or_null, float *y, int ix, int iy, int iz,
+                                 int Cin, int Cout, int relu, float *workspace, int64_t workspace_floats, sgc_stream_t stream);
+int sgc_conv3d_winograd_z_supported(int ix, int iy, int iz, int Cin, int Cout);
+int64_t sgc_conv3d_winograd_z_workspace_floats(int ix, int iy, int iz, int Cin, int Cout);
 /* mask_out = 3x3x3 dilation of mask_in ([X*Y*Z] uint8 {0,1}, flat index (x*Y + y)*Z + z); must not alias. */
 int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream);
 /* Head valid mask of scale `factor` (1, 2, 4): nn.Upsample(size, mode='trilinear')(valid.float()).round().bool()

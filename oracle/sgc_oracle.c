@@ -1171,6 +1171,64 @@ int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_
   return SGC_OK;
 }
 
+/* Winograd F(2,3) along z, restated literally (see the header): transform-domain products in double from the TRANSFORMED weights
+ * the caller passes (hi + lo), output transform, then the dense entry point's epilogue.  The test that pins it compares with
+ * sgc_conv3d_cl_bf16x3 on the ORIGINAL weights. */
+int sgc_conv3d_winograd_z_supported(int ix, int iy, int iz, int Cin, int Cout) {
+  return ix > 0 && iy > 0 && iz >= 2 && iz % 2 == 0 && Cin > 0 && Cout > 0;
+}
+int64_t sgc_conv3d_winograd_z_workspace_floats(int ix, int iy, int iz, int Cin, int Cout) {
+  return (int64_t)2 * ix * iy * iz * ((int64_t)Cin + Cout);
+}
+static float bf16_bits_to_f32(uint16_t b) { union { uint32_t u; float f; } c; c.u = (uint32_t)b << 16; return c.f; }
+int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_hi, const uint16_t *wg_lo, const float *scale,
+                                 const float *shift, const float *residual_or_null, float *y, int ix, int iy, int iz,
+                                 int Cin, int Cout, int relu, float *workspace, int64_t workspace_floats, sgc_stream_t stream) {
+  (void)stream; (void)workspace; (void)workspace_floats;
+  if (!x || !wg_hi || !wg_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  if (iz % 2) return fail(SGC_EUNSUP, "iz must be even");
+  const int J = iz / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int xx = 0; xx < ix; ++xx)
+    for (int yy = 0; yy < iy; ++yy) {
+      double *m = (double *)malloc(sizeof(double) * 4 * (size_t)Cout);
+      for (int j = 0; j < J; ++j) {
+        for (int i = 0; i < 4 * Cout; ++i) m[i] = 0.0;
+        for (int dx = 0; dx < 3; ++dx)
+          for (int dy = 0; dy < 3; ++dy) {
+            const int sx = xx + dx - 1, sy = yy + dy - 1;
+            if (sx < 0 || sx >= ix || sy < 0 || sy >= iy) continue;
+            const float *col = x + (((int64_t)sx * iy + sy) * iz) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) {
+              const float d0 = 2 * j - 1 >= 0 ? col[(int64_t)(2 * j - 1) * Cin + ci] : 0.f, d1 = col[(int64_t)(2 * j) * Cin + ci];
+              const float d2 = col[(int64_t)(2 * j + 1) * Cin + ci], d3 = 2 * j + 2 < iz ? col[(int64_t)(2 * j + 2) * Cin + ci] : 0.f;
+              const float t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};          /* one fp32 rounding each, as on the GPU */
+              for (int k = 0; k < 4; ++k) {
+                if (t[k] == 0.f) continue;
+                const int64_t wb = (((int64_t)k * 9 + dx * 3 + dy) * Cout) * Cin + ci;
+                for (int co = 0; co < Cout; ++co) {
+                  const int64_t wi = wb + (int64_t)co * Cin;
+                  m[k * Cout + co] += (double)t[k] * ((double)bf16_bits_to_f32(wg_hi[wi]) + (double)bf16_bits_to_f32(wg_lo[wi]));
+                }
+              }
+            }
+          }
+        for (int q = 0; q < 2; ++q)
+          for (int co = 0; co < Cout; ++co) {
+            const double a = q == 0 ? m[co] + m[Cout + co] + m[2 * Cout + co] : m[Cout + co] - m[2 * Cout + co] - m[3 * Cout + co];
+            const int64_t o = (((int64_t)xx * iy + yy) * iz + 2 * j + q) * Cout + co;
+            float v = (float)a * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+            if (relu == 2) v = v > 0.f ? v : 0.f;
+            if (residual_or_null) v += residual_or_null[o];
+            if (relu == 1) v = v > 0.f ? v : 0.f;
+            y[o] = v;
+          }
+      }
+      free(m);
+    }
+  return SGC_OK;
+}
+
 int sgc_mask_dilate3(const uint8_t *mask_in, uint8_t *mask_out, int X, int Y, int Z, sgc_stream_t stream) {
   (void)stream;
   if (!mask_in || !mask_out || mask_in == mask_out) return fail(SGC_EINVAL, "null or aliased pointers");

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sgc_conv3d_cl_bf16x3": [_p] * 7 + [_i] * 9 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3_masked": [_p] * 8 + [_i] * 6 + [_p, C.c_int64] + [_p],
     "sgc_conv3d_cl_bf16x3_act": [_p] * 8 + [_i] * 8 + [_p, _p, C.c_int64] + [_p],
+    "sgc_conv3d_winograd_z_bf16x3": [_p] * 7 + [_i] * 6 + [_p, C.c_int64] + [_p],
     "sgc_conv2d_nhwc_bf16x3": [_p] * 7 + [_i] * 7 + [_p],
     "sgc_conv3d_wgrad_bf16x3": [_p] * 3 + [_i] * 7 + [_p, C.c_int64] + [_p],
     "sgc_mask_dilate3": [_p, _p, _i, _i, _i, _p],
@@ -77,6 +78,8 @@ INTROSPECTION = {
     "sgc_topk_select_workspace_bytes": (C.c_int64, [_i]),
     "sgc_level_tail_supported": (C.c_int, [_i] * 2),
     "sgc_view_attend_pq_supported": (C.c_int, [_i] * 3),
+    "sgc_conv3d_winograd_z_supported": (C.c_int, [_i] * 5),
+    "sgc_conv3d_winograd_z_workspace_floats": (C.c_int64, [_i] * 5),
     "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
 }

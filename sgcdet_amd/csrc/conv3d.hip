@@ -39,7 +39,8 @@ int g_tune_igemm_xcd = 0;    // tile implicit GEMM, XCD deal of the split / tran
 int g_tune_conv_waves = 8;   // implicit-GEMM kernel: 4 or 8 waves per 128x128 tile
 int g_tune_conv_halo = 1;    // 3x3x3 stride-1 layers: 0 per-tap kernel, 1 halo-resident kernel
 int g_tune_halo_split_target = 192;   // halo kernel: channel slices are split over workgroups until a launch has this many
-int g_tune_halo_2d = 1;      // 3x3 layers of sgc_conv2d_nhwc_bf16x3: 1 the 2-D form of the halo kernel, 0 the tile kernel
+int g_tune_halo_2d = 1;      // 3x3 layers of sgc_conv2d_nhwc_bf16x3: 1 the 2-D form of the halo kernel (16 x 16 pixel bricks), 2 bricks of 4 images x 8 x 8
+                             // where they tile the stack, 0 the tile kernel
 int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4x8x8, 2: force 8x8x4, 3: the round-2 rule (4x4x16 at depth >= 16).
                                   // Round 3, interleaved A/B of the three shapes on the 40x40x16 and 80x80x32 layers (bit-identical
                                   // results): 8x8x4 is 1.5 - 2.5 % faster than 4x4x16 (236 vs 241 us, 129.5 vs 133, 534 vs 546;
@@ -92,6 +93,8 @@ struct ConvParams {
   int xcd_deal;           // tile kernel: how workgroups are dealt to the 8 XCDs (hardware: linear id % 8).  0 = as launched;
                           // 1 = consecutive ROW tiles of one (column tile, split) on one XCD (they share a weight slab);
                           // 2 = consecutive COLUMN tiles of one (row tile, split) on one XCD (they share the gathered rows)
+  int w_group_images;     // 2-D form only, > 0: the image stack is made of groups of this many images, group g convolves with the
+                          // weight set w + g * taps * Cout * Cin (the four transform-domain positions of sgc_conv3d_winograd_z_bf16x3)
   float *zero_row;        // optional: Cout floats this launch sets to zero (workgroup (0, 0, 0); sgc_linear_rows_zrow_bf16x3)
   const float *act_scale; // optional: columns [act_c0, act_c1) leave as expf(v * *act_scale) -- the head's `exp(scale(reg))` (dense_heads/
   int act_c0, act_c1;     // imvoxel_head_v2.py:79,110: mmcv Scale then torch.exp) applied last in the epilogue (sgc_conv3d_cl_bf16x3_act)
@@ -749,8 +752,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
   const int w_bytes = (int)(unsigned)((int64_t)NTAP * p.Cout * p.Cin * 2);
-  const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi), 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo), 0, w_bytes, 0x00020000);
+  // weight set of this brick: one for the whole launch, or -- 2-D form with image groups -- that of the group its images belong to
+  const int64_t w_set = (TD && p.w_group_images > 0) ? (int64_t)(X0 / p.w_group_images) * NTAP * p.Cout * p.Cin : 0;
+  const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi + w_set), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo + w_set), 0, w_bytes, 0x00020000);
   unsigned aoff[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -1194,6 +1199,78 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2,3) along z for the 3x3x3 stride-1 layers (round 5).  With four scenes in flight the package sits at its power
+// limit and the bf16 x 3 products of these layers are about half of a scene's joules: the only lever left on them
+// is fewer multiply-adds.  Per (dx, dy) the z direction is a 1-D 3-tap convolution; for an output pair (z = 2j, 2j + 1) with the
+// inputs d_k = x[.., 2j - 1 + k], k = 0..3 (zero outside the grid):
+//     t0 = d0 - d2,  t1 = d1 + d2,  t2 = d2 - d1,  t3 = d1 - d3                    (input transform)
+//     G0 = w0,  G1 = (w0 + w1 + w2) / 2,  G2 = (w0 - w1 + w2) / 2,  G3 = w2        (weight transform, once per module)
+//     m_k = sum over (dx, dy, ci) of t_k G_k                                        (four 3 x 3 convolutions over (x, y))
+//     y[2j] = m0 + m1 + m2,   y[2j + 1] = m1 - m2 - m3                              (output transform)
+// 18 instead of 27 tap-GEMMs per output.  Three launches: the input transform writes the four transform-domain volumes as a stack
+// of 4 * Z/2 "images" of X x Y pixels (position-major), the halo kernel's 2-D form convolves the stack with one weight set per
+// position (bricks of 4 images x 8 x 8 pixels: no halo along the image axis), the output transform combines and applies the
+// epilogue (scale / shift / relu / residual / activation -- the direct kernel's expressions in the direct kernel's order).
+// The fused form does not fit: four accumulators per output pair and four weight tiles per tap need 164 - 189 KB of LDS.
+// Entries 0, +-1, +-1/2: every transform is exact up to one fp32 rounding per element; measured error against the direct form
+// in tests/test_gpu_conv3d.py.  Deterministic (no atomics, fixed order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void winograd_z_in_kernel(const float4 *__restrict__ x, float4 *__restrict__ t, int X, int Y, int Z, int C4) {
+  const int J = Z >> 1;
+  const int64_t total = (int64_t)X * Y * J * C4, plane = (int64_t)X * Y * C4;        // one image of the stack
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int j = (int)(r % J); r /= J;
+    const int yy = (int)(r % Y), xx = (int)(r / Y);
+    const float4 *col = x + (((int64_t)xx * Y + yy) * Z) * C4 + c;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 d0 = 2 * j - 1 >= 0 ? col[(int64_t)(2 * j - 1) * C4] : z4;
+    const float4 d1 = col[(int64_t)(2 * j) * C4], d2 = col[(int64_t)(2 * j + 1) * C4];
+    const float4 d3 = 2 * j + 2 < Z ? col[(int64_t)(2 * j + 2) * C4] : z4;
+    float4 *o = t + ((int64_t)j * X + xx) * Y * C4 + (int64_t)yy * C4 + c;
+    o[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+    o[(int64_t)J * plane] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+    o[(int64_t)2 * J * plane] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+    o[(int64_t)3 * J * plane] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void winograd_z_out_kernel(const float4 *__restrict__ m, float4 *__restrict__ y,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const float4 *__restrict__ residual, int X, int Y, int Z, int C4, int relu,
+                                                             const float *__restrict__ act_scale, int act_c0, int act_c1) {
+  const int J = Z >> 1;
+  const int64_t total = (int64_t)X * Y * J * C4, plane = (int64_t)X * Y * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int j = (int)(r % J); r /= J;
+    const int yy = (int)(r % Y), xx = (int)(r / Y);
+    const float4 *mi = m + ((int64_t)j * X + xx) * Y * C4 + (int64_t)yy * C4 + c;
+    const float4 m0 = mi[0], m1 = mi[(int64_t)J * plane], m2 = mi[(int64_t)2 * J * plane], m3 = mi[(int64_t)3 * J * plane];
+    float4 v[2] = {make_float4((m0.x + m1.x) + m2.x, (m0.y + m1.y) + m2.y, (m0.z + m1.z) + m2.z, (m0.w + m1.w) + m2.w),
+                   make_float4((m1.x - m2.x) - m3.x, (m1.y - m2.y) - m3.y, (m1.z - m2.z) - m3.z, (m1.w - m2.w) - m3.w)};
+    const float4 sc = scale ? reinterpret_cast<const float4 *>(scale)[c] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? reinterpret_cast<const float4 *>(shift)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t o0 = (((int64_t)xx * Y + yy) * Z + 2 * j) * C4 + c;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float4 w = v[q];
+      w.x = w.x * sc.x + sh.x; w.y = w.y * sc.y + sh.y; w.z = w.z * sc.z + sh.z; w.w = w.w * sc.w + sh.w;
+      if (relu == 2) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+      if (residual) {
+        const float4 rr = residual[o0 + (int64_t)q * C4];
+        w.x += rr.x; w.y += rr.y; w.z += rr.z; w.w += rr.w;
+      }
+      if (relu == 1) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+      if (act_scale) w = act_col4(w, c * 4, act_c0, act_c1, *act_scale);
+      y[o0 + (int64_t)q * C4] = w;
+    }
+  }
+}
+
 }  // namespace sgc
 
 using namespace sgc;
@@ -1324,10 +1401,11 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                          int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
                          const uint8_t *out_mask_or_null, sgc_stream_t stream, int two_d = 0,
-                         const float *act_scale = nullptr, int act_c0 = 0, int act_c1 = 0) {
+                         const float *act_scale = nullptr, int act_c0 = 0, int act_c1 = 0, int w_group_images = 0) {
   ConvParamsB p = {};
   p.out_mask = out_mask_or_null;
   p.two_d = two_d;
+  p.w_group_images = w_group_images;
   p.act_scale = act_c1 > act_c0 ? act_scale : nullptr; p.act_c0 = act_c0; p.act_c1 = act_c1;
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
@@ -1365,10 +1443,17 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   if (g_tune_conv_halo && g_tune_halo_2d && p.two_d && ksize == 3 && stride == 1 && Cout >= g_tune_halo_min_cout &&
       p.M >= g_tune_halo_min_m && p.gy >= 8 && p.gz >= 8) {
     const bool narrow_n = g_tune_halo_narrow && Cout <= 64;
+    // bricks of 4 images x 8 x 8 pixels -- no halo along the image axis, 400 staged rows per 256 outputs: the geometry of the
+    // transform-domain convolutions of sgc_conv3d_winograd_z_bf16x3 (image groups = positions); halo_2d = 2 selects it for any stack
+    if ((g_tune_halo_2d == 2 || p.w_group_images > 0) && !narrow_n && p.gx % 4 == 0 && (p.w_group_images == 0 || p.w_group_images % 4 == 0))
+      rc = launch_halo<4, 8, 8, 128, true>(p, OV, st);
+    else if (p.w_group_images > 0) return set_error(SGC_EUNSUP, "conv: grouped 2-D form needs groups of a multiple of 4 images and > 64 output channels");
+    else
     rc = narrow_n ? launch_halo<1, 16, 16, 64, true>(p, OV, st) : launch_halo<1, 16, 16, 128, true>(p, OV, st);
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
+  if (p.w_group_images > 0) return set_error(SGC_EUNSUP, "conv: the grouped 2-D form runs on the halo kernel only (stack too small?)");
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
@@ -2205,6 +2290,45 @@ extern "C" int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, co
     return set_error(SGC_EINVAL, "sgc_conv3d_cl_bf16x3_act: needs 0 <= act_c0 < act_c1 <= Cout and a scale pointer");
   return conv3d_bf16x3(x, w_hi, w_lo, scale, shift, residual_or_null, y, ix, iy, iz, Cin, Cout, 3, 1, 0, relu,
                        workspace_or_null, workspace_floats, out_mask_or_null, stream, 0, act_scale_dev, act_c0, act_c1);
+}
+
+extern "C" int sgc_conv3d_winograd_z_supported(int ix, int iy, int iz, int Cin, int Cout) {
+  return ix > 0 && iy > 0 && iz >= 8 && iz % 8 == 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 ? 1 : 0;     // Z/2 images per position, in bricks of 4
+}
+extern "C" int64_t sgc_conv3d_winograd_z_workspace_floats(int ix, int iy, int iz, int Cin, int Cout) {
+  return sgc_conv3d_winograd_z_supported(ix, iy, iz, Cin, Cout) ? (int64_t)2 * ix * iy * iz * ((int64_t)Cin + Cout) : 0;
+}
+
+// 3x3x3 stride-1 convolution through the Winograd F(2,3) transform along z (see the kernels above): wg_hi / wg_lo are the bf16 hi / lo
+// planes of the TRANSFORMED weights [4][9][Cout][Cin] (position, (dx, dy) tap); workspace >= 2 V (Cin + Cout) floats.
+extern "C" int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_hi, const uint16_t *wg_lo, const float *scale,
+                                            const float *shift, const float *residual_or_null, float *y, int ix, int iy, int iz,
+                                            int Cin, int Cout, int relu, float *workspace, int64_t workspace_floats,
+                                            sgc_stream_t stream) {
+  if (!x || !wg_hi || !wg_lo || !y || !workspace) return set_error(SGC_EINVAL, "sgc_conv3d_winograd_z_bf16x3: null pointer");
+  if (!sgc_conv3d_winograd_z_supported(ix, iy, iz, Cin, Cout))
+    return set_error(SGC_EUNSUP, "sgc_conv3d_winograd_z_bf16x3: needs iz %% 8 == 0, Cin %% 32 == 0, Cout %% 4 == 0, Cout > 64");
+  if (workspace_floats < sgc_conv3d_winograd_z_workspace_floats(ix, iy, iz, Cin, Cout))
+    return set_error(SGC_EINVAL, "sgc_conv3d_winograd_z_bf16x3: workspace too small");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)residual_or_null | (uintptr_t)scale | (uintptr_t)shift) & 15)
+    return set_error(SGC_EINVAL, "sgc_conv3d_winograd_z_bf16x3: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t V = (int64_t)ix * iy * iz;
+  const int J = iz / 2;
+  float *t = workspace, *m = workspace + 2 * V * Cin;
+  const int64_t n_in = V / 2 * (Cin / 4), n_out = V / 2 * (Cout / 4);
+  hipLaunchKernelGGL(winograd_z_in_kernel, dim3((unsigned)std::min<int64_t>((n_in + 255) / 256, 65536)), dim3(256), 0, st,
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(t), ix, iy, iz, Cin / 4);
+  int rc = check_launch("winograd_z_in_kernel");
+  if (rc) return rc;
+  // four 3 x 3 convolutions over (x, y) as ONE launch of the halo kernel's 2-D form: 4 J images, weight set = image / J
+  rc = conv3d_bf16x3(t, wg_hi, wg_lo, nullptr, nullptr, nullptr, m, 4 * J, ix, iy, Cin, Cout, 3, 1, 0, 0, nullptr, 0, nullptr, stream, 1,
+                     nullptr, 0, 0, J);
+  if (rc) return rc;
+  hipLaunchKernelGGL(winograd_z_out_kernel, dim3((unsigned)std::min<int64_t>((n_out + 255) / 256, 65536)), dim3(256), 0, st,
+                     reinterpret_cast<const float4 *>(m), reinterpret_cast<float4 *>(y), scale, shift,
+                     reinterpret_cast<const float4 *>(residual_or_null), ix, iy, iz, Cout / 4, relu, nullptr, 0, 0);
+  return check_launch("winograd_z_out_kernel");
 }
 
 // 3x3x3 dilation of a {0,1} voxel mask (what a 3x3x3 convolution must produce so that its consumer is exact on `in`)

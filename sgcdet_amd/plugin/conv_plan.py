@@ -36,6 +36,24 @@ def set_conv_mode(mode):
         ext.ops().lib.call("sgc_set_conv_products", CONV_PRODUCTS)
 
 
+# Winograd F(2,3) along z for the wide 3x3x3 stride-1 layers (sgc_conv3d_winograd_z_bf16x3): 2/3 of the multiply-adds of
+# the layers that hold the chip at its power limit, at the price of a transform pass on either side.  "auto" = wherever the entry
+# point supports the shape (z extent a multiple of 8, x / y multiples of 8 so that the 8 x 8 pixel bricks tile the slices) and the
+# layer has at least WINOGRAD_Z_MIN_CH input channels; False = never.  Results differ from the direct kernel by summation order
+# (<= 2e-5 of the tensor scale, tested); each choice is deterministic.  Set before the first forward: plans are cached.
+WINOGRAD_Z = {"0": False, "1": True}.get(os.environ.get("SGC_WINOGRAD_Z", ""), "auto")
+WINOGRAD_Z_MIN_CH = int(os.environ.get("SGC_WINOGRAD_Z_MIN_CH", "256"))
+
+
+def set_winograd_z(mode, min_channels=None):
+    global WINOGRAD_Z, WINOGRAD_Z_MIN_CH
+    if mode not in ("auto", True, False):
+        raise ValueError(mode)
+    WINOGRAD_Z = mode
+    if min_channels is not None:
+        WINOGRAD_Z_MIN_CH = int(min_channels)
+
+
 def _pad_to(n, m=_PAD):
     return (n + m - 1) // m * m
 
@@ -67,12 +85,28 @@ class ConvSpec:
         self.w_hi, self.w_lo = ext.ops().split_operand(self.wt) if w.is_cuda else (None, None)
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.ksize, self.stride, self.transposed = ksize, stride, transposed
+        self._wino = None                    # (g_hi, g_lo): transformed weight planes, built on first use
+
+    def _winograd_planes(self, grid):
+        """The transformed weight planes when this call should take the Winograd-z form, else None."""
+        if (WINOGRAD_Z is False or self.ksize != 3 or self.stride != 1 or self.transposed or CONV_MODE != "bf16x3"
+                or (WINOGRAD_Z == "auto" and self.cin_p < WINOGRAD_Z_MIN_CH) or grid[0] % 8 or grid[1] % 8):
+            return None
+        ops = ext.ops()
+        if not ops.conv3d_winograd_z_supported(grid, self.cin_p, self.cout_p):
+            return None
+        if self._wino is None:
+            self._wino = ops.split_operand(ops.winograd_z_weights(self.wt))
+        return self._wino
 
     def __call__(self, x, grid, residual=None, relu=0, out_mask=None, act=None):
         """``out_mask`` (uint8 [OV], bf16x3 mode, 3x3x3 stride-1 layers): only rows with 1 are needed downstream.
         ``act`` = (c0, c1, scale tensor): columns [c0, c1) leave as exp(v * scale) (bf16x3 mode; the caller applies it itself in
         the strict-fp32 mode -- ``supports_act``)."""
         if CONV_MODE == "bf16x3":
+            wino = self._winograd_planes(grid) if out_mask is None and act is None else None
+            if wino is not None:
+                return ext.ops().conv3d_winograd_z(x, wino[0], wino[1], grid, self.scale, self.shift, residual, relu)
             return ext.ops().conv3d_cl_bf16x3(x, self.w_hi, self.w_lo, grid, self.ksize, self.stride,
                                               self.transposed, self.scale, self.shift, residual, relu, out_mask=out_mask, act=act)
         if act is not None:

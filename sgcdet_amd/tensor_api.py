@@ -586,6 +586,42 @@ class TensorOps:
         return y, og
 
     @staticmethod
+    def winograd_z_weights(wt):
+        """[27, Cout, Cin] fp32 (tap = (dx*3 + dy)*3 + dz) -> [4, 9, Cout, Cin] fp32: the F(2,3)-along-z transform of the z taps
+        (G0 = w0, G1 = (w0 + w1 + w2) / 2, G2 = (w0 - w1 + w2) / 2, G3 = w2), composed in float64."""
+        t, cout, cin = wt.shape
+        if t != 27:
+            raise RuntimeError("winograd_z_weights: a 3x3x3 kernel expected")
+        w = wt.double().view(9, 3, cout, cin)
+        g = torch.stack([w[:, 0], (w[:, 0] + w[:, 1] + w[:, 2]) / 2, (w[:, 0] - w[:, 1] + w[:, 2]) / 2, w[:, 2]])
+        return g.float().contiguous()
+
+    def conv3d_winograd_z_supported(self, grid, Cin, Cout):
+        return bool(self.lib._dll.sgc_conv3d_winograd_z_supported(int(grid[0]), int(grid[1]), int(grid[2]), int(Cin), int(Cout)))
+
+    def conv3d_winograd_z(self, x, g_hi, g_lo, grid, scale=None, shift=None, residual=None, relu=False, out=None):
+        """3x3x3 stride-1 convolution through the Winograd F(2,3) transform along z (``sgc_conv3d_winograd_z_bf16x3``):
+        g_hi / g_lo = the split of ``winograd_z_weights`` ([4, 9, Cout, Cin] bf16).  Same operator and epilogue as
+        ``conv3d_cl_bf16x3(ksize=3)``; 2/3 of its multiply-adds."""
+        self._check(x=x, g_hi=g_hi, g_lo=g_lo, scale=scale, shift=shift, residual=residual, out=out)
+        self._f32(x=x, scale=scale, shift=shift, residual=residual, out=out)
+        if g_hi.dtype != torch.bfloat16 or g_lo.dtype != torch.bfloat16 or g_hi.shape != g_lo.shape or g_hi.dim() != 4:
+            raise RuntimeError("conv3d_winograd_z: g_hi / g_lo must be bfloat16 [4, 9, Cout, Cin]")
+        ix, iy, iz = grid
+        V, Cin = x.shape
+        _, _, Cout, Cin2 = g_hi.shape
+        if V != ix * iy * iz or Cin2 != Cin or g_hi.shape[:2] != (4, 9):
+            raise RuntimeError("conv3d_winograd_z: inconsistent shapes")
+        y = out if out is not None else torch.empty((V, Cout), dtype=torch.float32, device=x.device)
+        if y.shape != (V, Cout) or (residual is not None and residual.shape != y.shape):
+            raise RuntimeError("conv3d_winograd_z: bad `out` / residual shape")
+        n = int(self.lib._dll.sgc_conv3d_winograd_z_workspace_floats(ix, iy, iz, Cin, Cout))
+        ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
+        self._call("sgc_conv3d_winograd_z_bf16x3", x, g_hi, g_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, int(relu), ws, n,
+                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=27, OV=V, mac_frac=2.0 / 3.0))
+        return y, tuple(grid)
+
+    @staticmethod
     def pack_b_fragments(w):
         """[..., N, K] (N % 32 == 0, K % 16 == 0) -> the fragment-packed layout [N/32, K/16, 64, 8] of ``sgc_level_tail``:
         packed[b, kk, l, j] = w[32 b + (l & 31), 16 kk + 8 (l >> 5) + j]."""

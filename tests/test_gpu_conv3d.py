@@ -552,3 +552,68 @@ def test_32_column_tiles_are_bit_identical_to_the_64_column_form(grid, cin, cout
     assert torch.isfinite(outs[1][1]).all() and torch.equal(outs[1][1][live], outs[64][0][live])
     want, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
     assert (outs[1][0].cpu() - want).abs().max() < 1e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("grid,cin,cout,relu,res", [((16, 16, 16), 64, 128, 1, True), ((40, 40, 16), 256, 256, 1, True), ((8, 24, 8), 96, 160, 2, True),
+                                                     ((16, 8, 32), 32, 72, 0, False)])
+def test_winograd_z_convolution_against_the_direct_form(grid, cin, cout, relu, res, oracle_ops, gpu_ops):
+    """sgc_conv3d_winograd_z_bf16x3 (F(2,3) along z: 18 of the 27 tap-GEMMs) is the same operator as the direct 3x3x3 kernel:
+    against the ORACLE's direct convolution on the original weights and against the GPU's direct kernel, 2e-5 of the tensor scale
+    (the bound the round-4 review set); against its own oracle twin 1e-5; borders in z (the zero rows d0 / d3 of the first / last
+    pair), residual and both relu modes; repeated launches bit-identical; unsupported shapes refused."""
+    g = torch.Generator().manual_seed(sum(grid) + cin)
+    V = grid[0] * grid[1] * grid[2]
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(27, cout, cin, generator=g) * (1.0 / (27 * cin) ** 0.5)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    residual = torch.randn(V, cout, generator=g) if res else None
+    hi, lo = gpu_ops.split_bf16(w)
+    ghi, glo = gpu_ops.split_bf16(gpu_ops.winograd_z_weights(w))
+    cu = lambda t: None if t is None else t.cuda()
+    assert gpu_ops.conv3d_winograd_z_supported(grid, cin, cout)
+    got, _ = gpu_ops.conv3d_winograd_z(cu(x), cu(ghi), cu(glo), grid, cu(scale), cu(shift), cu(residual), relu)
+    again, _ = gpu_ops.conv3d_winograd_z(cu(x), cu(ghi), cu(glo), grid, cu(scale), cu(shift), cu(residual), relu)
+    assert torch.equal(got, again)
+    direct_gpu, _ = gpu_ops.conv3d_cl_bf16x3(cu(x), cu(hi), cu(lo), grid, 3, 1, False, cu(scale), cu(shift), cu(residual), relu)
+    want, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, 3, 1, False, scale, shift, residual, relu)
+    sc = max(1.0, float(want.abs().max()))
+    assert (got.cpu() - want).abs().max() < 2e-5 * sc, float((got.cpu() - want).abs().max()) / sc
+    assert (got - direct_gpu).abs().max() < 2e-5 * sc
+    if V * cin * cout <= 16 * 16 * 16 * 64 * 128:                   # the literal Winograd restatement of the oracle (slow loops)
+        twin, _ = oracle_ops.conv3d_winograd_z(x, ghi, glo, grid, scale, shift, residual, relu)
+        assert (got.cpu() - twin).abs().max() < 1e-5 * sc
+    assert not gpu_ops.conv3d_winograd_z_supported((16, 16, 12), cin, cout) and not gpu_ops.conv3d_winograd_z_supported(grid, cin, 64)
+
+
+def test_winograd_z_through_the_neck_keeps_parity():
+    """conv_plan.WINOGRAD_Z on / off through the whole neck + head on one volume: every head tensor within 1e-4 of its scale of the
+    direct form (twelve chained convolutions), and the form under test really ran."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd import ext
+    from sgcdet_amd.mmcv_lite import build_detector
+    from sgcdet_amd.plugin import conv_plan
+    from sgcdet_amd.scene import model_config, workload
+    w = workload("cfg2_scannet")
+    torch.manual_seed(2)
+    det = build_detector(model_config(w)).eval().cuda()
+    det.use_graph = det.scene_graph = False
+    vol = torch.randn(1, w["embed_dims"], *w["n_voxels_list"][-1], device="cuda")
+    outs = {}
+    ops = ext.ops()
+    try:
+        for mode in (False, True):
+            conv_plan.set_winograd_z(mode, min_channels=256)
+            det.neck_3d.__dict__.pop("_hip_plan", None)
+            ops.event_log, ops.event_names = [], {"sgc_conv3d_winograd_z_bf16x3"}
+            with torch.no_grad():
+                o = det._neck_head_eager(vol)
+            torch.cuda.synchronize()
+            n_w = len(ops.event_log)
+            ops.event_log, ops.event_names = None, None
+            assert (n_w == 4) == bool(mode), n_w            # the three 256 -> 256 and the 256 -> 128 layer of the 40 x 40 x 16 scale
+            outs[mode] = [t.clone() for part in o for t in part]
+    finally:
+        conv_plan.set_winograd_z("auto", min_channels=256)
+        det.neck_3d.__dict__.pop("_hip_plan", None)
+    for a, b in zip(outs[True], outs[False]):
+        assert (a - b).abs().max() <= 1e-4 * max(1.0, float(b.abs().max()))

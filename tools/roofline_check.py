@@ -27,7 +27,8 @@ def check_line(d, name="line"):
     if m:
         near(m["frac"], m["achieved"] / m["peak"], 2e-3, "roofline_mfma.frac vs achieved / peak")
         nprod = 3 if m["peak"] > 1000 and "three bf16 products" in m.get("note", "") else 1
-        near(m["achieved"], m["algorithmic_gflop"] * nprod / (m["avg_launch_us"] * 1e-6) / 1e3, 1e-2, "roofline_mfma.achieved vs issued GFLOP / avg_launch_us")
+        near(m["achieved"], m["algorithmic_gflop"] * m.get("mac_frac_issued", 1.0) * nprod / (m["avg_launch_us"] * 1e-6) / 1e3, 1e-2,
+             "roofline_mfma.achieved vs issued GFLOP / avg_launch_us")
     p = d.get("path_roofline")
     if p:
         near(p["frac"], p["floor_ms_per_scene"] / (d["ms_per_step"] / spp) * d["n_gpus"], 5e-3, "path_roofline.frac vs floor / ms per scene")
