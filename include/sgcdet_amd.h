@@ -502,7 +502,7 @@ int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, const uint16_
  *   wg_hi / wg_lo: bf16 hi / lo planes of the TRANSFORMED weights [4][9][Cout][Cin]: for the (dx, dy) tap t = dx*3 + dy and the z taps
  *   w0, w1, w2 of the module's weight: G[0][t] = w0, G[1][t] = (w0 + w1 + w2) / 2, G[2][t] = (w0 - w1 + w2) / 2, G[3][t] = w2.
  *   workspace: >= sgc_conv3d_winograd_z_workspace_floats() floats (the transform-domain input and output stacks).
- *   Supported (sgc_conv3d_winograd_z_supported): iz % 8 == 0, Cin % 32 == 0, Cout % 4 == 0, Cout > 64.                       */
+ *   Supported (sgc_conv3d_winograd_z_supported): ix, iy >= 8, iz % 8 == 0, Cin % 32 == 0, Cout % 4 == 0, Cout > 64, 2 * ix * iy * iz >= 2048. */
 int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_hi, const uint16_t *wg_lo, const float *scale,
                                  const float *shift, const float *residual_or_null, float *y, int ix, int iy, int iz,
                                  int Cin, int Cout, int relu, float *workspace, int64_t workspace_floats, sgc_stream_t stream);

@@ -93,6 +93,7 @@ struct ConvParams {
   int xcd_deal;           // tile kernel: how workgroups are dealt to the 8 XCDs (hardware: linear id % 8).  0 = as launched;
                           // 1 = consecutive ROW tiles of one (column tile, split) on one XCD (they share a weight slab);
                           // 2 = consecutive COLUMN tiles of one (row tile, split) on one XCD (they share the gathered rows)
+  int wz_Z;               // WZ kernels: z extent of the raw volume behind the virtual image stack (J = wz_Z / 2 pairs per position)
   int w_group_images;     // 2-D form only, > 0: the image stack is made of groups of this many images, group g convolves with the
                           // weight set w + g * taps * Cout * Cin (the four transform-domain positions of sgc_conv3d_winograd_z_bf16x3)
   float *zero_row;        // optional: Cout floats this launch sets to zero (workgroup (0, 0, 0); sgc_linear_rows_zrow_bf16x3)
@@ -610,8 +611,12 @@ __host__ __device__ constexpr size_t halo_tab_offset(int lrows, int mrows = 256,
 // operands of BOTH k-halves are in registers before the MFMAs that use them are reached, the weight tile is written a
 // half-tap before the barrier that publishes it, and nothing but wave skew is left at the barrier.  Every accumulator still
 // sees (tap, k-half, product) in the same order: bit-identical to the lockstep form.
-template <int BX, int BY, int BZ, int BNV = 128, int NP = 3, bool TD = false, bool STG = true>
+// WZ (2-D form only): the image stack is VIRTUAL -- image k * J + j, pixel (xx, yy) is the Winograd F(2,3)-along-z input transform
+// t_k of the raw volume p.x [rows][cols][Z = 2 J][Cin] at the output pair j (sgc_conv3d_winograd_z_bf16x3): every staged chunk is
+// loaded from TWO voxel rows and combined (a - b, or a + b for k = 1) in front of the hi / lo split; no transformed copy exists.
+template <int BX, int BY, int BZ, int BNV = 128, int NP = 3, bool TD = false, bool STG = true, bool WZ = false>
 __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParamsB p) {
+  static_assert(!WZ || TD, "the virtual Winograd stack is a 2-D form");
   constexpr int NTAP = TD ? 9 : 27, XO = TD ? 0 : 1;    // taps; halo width along x
   // MFMA rows of the brick: 256 for the standard bricks; a brick with another voxel count (a whole small grid: 10 x 10 x 4, the
   // coarsest config-2 scale) is padded to a multiple of 128 rows (4 wave rows x 32) -- pad rows work on voxel 0 and are dropped
@@ -743,20 +748,20 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
   SGC_HALO_STAMP(0);
 
-  float4 ra[NA];
+  float4 ra[NA], rw[WZ ? NA : 1];      // rw: the second voxel row of a Winograd transform chunk
   uint4 rbh, rbl;
   // Addressing is fixed per thread for the whole kernel (the halo rows a thread stages and its weight row do not depend on the
   // channel slice or the tap): one 32-bit byte offset per chunk, 0xfffffff0 = "outside the volume / padding slot", computed once;
   // a slice / a tap then only moves a uniform offset.  Buffer loads return zeros past the tensor, so the loads carry no branch.
   constexpr unsigned OOB = 0xfffffff0u;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)p.ix * p.iy * p.iz * p.Cin * 4), 0x00020000);
+      const_cast<float *>(p.x), 0, (int)(unsigned)((int64_t)(WZ ? p.wz_Z : p.ix) * p.iy * p.iz * p.Cin * 4), 0x00020000);
   const int w_bytes = (int)(unsigned)((int64_t)NTAP * p.Cout * p.Cin * 2);
   // weight set of this brick: one for the whole launch, or -- 2-D form with image groups -- that of the group its images belong to
   const int64_t w_set = (TD && p.w_group_images > 0) ? (int64_t)(X0 / p.w_group_images) * NTAP * p.Cout * p.Cin : 0;
   const __amdgpu_buffer_rsrc_t whr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_hi + w_set), 0, w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wlr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.w_lo + w_set), 0, w_bytes, 0x00020000);
-  unsigned aoff[NA];
+  unsigned aoff[NA], aoffb[WZ ? NA : 1];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int idx = i * NT + tid;
@@ -764,8 +769,19 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     const int hz = row % HZ, hy = (row / HZ) % HY, hx = row / (HZ * HY);
     const int gx = X0 + hx - XO, gy = Y0 + hy - 1, gz = Z0 + hz - 1;
     const bool in = row < HROWS && gx >= 0 && gx < p.ix && gy >= 0 && gy < p.iy && gz >= 0 && gz < p.iz;
-    aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+    if constexpr (WZ) {
+      // image gx = kpos * J + j: the two voxel rows of the raw volume [iy][iz][Z] whose combination is this transform row
+      const int J = p.wz_Z >> 1, kpos = X0 / J, j = gx - kpos * J;       // a brick's images belong to one position (J % BX == 0)
+      const int za = kpos == 0 ? 2 * j - 1 : kpos == 2 ? 2 * j + 1 : 2 * j;
+      const int zb = kpos <= 1 ? 2 * j + 1 : kpos == 2 ? 2 * j : 2 * j + 2;
+      const unsigned col = (unsigned)((gy * p.iz + gz) * p.wz_Z);
+      aoff[i] = in && za >= 0 ? ((col + (unsigned)za) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+      aoffb[i] = in && zb < p.wz_Z ? ((col + (unsigned)zb) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+    } else {
+      aoff[i] = in ? ((unsigned)((gx * p.iy + gy) * p.iz + gz) * (unsigned)p.Cin + c4 * 4) * 4u : OOB;
+    }
   }
+  const float wz_sign = WZ && (X0 / max(p.wz_Z >> 1, 1)) == 1 ? 1.f : -1.f;      // t1 = d1 + d2; t0, t2, t3 are differences
   const unsigned boff = bn_ok ? (unsigned)((n0 + bn) * p.Cin + bc * 8) * 2u : OOB;
   auto load_A = [&](int cc) {
     const int soff = __builtin_amdgcn_readfirstlane(cc * (BK * 4));
@@ -773,6 +789,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     for (int i = 0; i < NA; ++i) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff, 0);
       ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      if constexpr (WZ) {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffb[i], soff, 0);
+        rw[i] = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+      }
     }
   };
   // the split of a loaded halo chunk, in place: ra[i] = (hi.xy, hi.zw, lo.xy, lo.zw) as packed bf16 pairs.  Called under the
@@ -782,7 +802,10 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   auto split_A = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      if constexpr (WZ) {                       // the input transform: one fp32 rounding per element (sign * b is exact)
+        v[0] += wz_sign * rw[i].x; v[1] += wz_sign * rw[i].y; v[2] += wz_sign * rw[i].z; v[3] += wz_sign * rw[i].w;
+      }
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1126,7 +1149,7 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
 
 int g_tune_halo_stagger = 1;   // halo kernel: 1 software-pipelined schedule with the barrier at mid-tap (see the kernel), 0 lockstep form
 
-template <int BX, int BY, int BZ, int BNV, int NP, bool TD, bool STG>
+template <int BX, int BY, int BZ, int BNV, int NP, bool TD, bool STG, bool WZ = false>
 static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
 #if defined(SGC_HALO_STAMPS)
   p.stamps = g_halo_stamp_buf;
@@ -1137,7 +1160,7 @@ static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
   const size_t smem = halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t);   // table + 8 x 32 scratch
   static_assert(halo_tab_offset(LROWS, MROWS, MROWS > 256 ? BNV : 128) + (MROWS + 256) * sizeof(uint16_t) <= 160 * 1024, "brick does not fit the LDS");
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG>, (int)smem, attr_done);
+  ensure_dynamic_lds((const void *)conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG, WZ>, (int)smem, attr_done);
   const int bricks = ceil_div(p.gx, BX) * ceil_div(p.gy, BY) * ceil_div(p.gz, BZ);
   const int nb = ceil_div(p.Cout, BNV);
   const int nchunks = p.Cin / BK;
@@ -1155,14 +1178,15 @@ static int launch_halo_k(ConvParamsB &p, int64_t OV, hipStream_t st) {
       if (rcz) return rcz;
     }
   }
-  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv3d_halo_bf16x3_kernel<BX, BY, BZ, BNV, NP, TD, STG, WZ>), dim3(bricks, nb, splitk), dim3(512), smem, st, p);
   return check_launch("conv3d_halo_bf16x3_kernel");
 }
 
-template <int BX, int BY, int BZ, int BNV = 128, bool TD = false>
+template <int BX, int BY, int BZ, int BNV = 128, bool TD = false, bool WZ = false>
 static int launch_halo(ConvParamsB &p, int64_t OV, hipStream_t st) {
-  if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true>(p, OV, st);
-  if (g_conv_products == 2) return launch_halo_k<BX, BY, BZ, BNV, 2, TD, true>(p, OV, st);
+  if (g_conv_products == 1) return launch_halo_k<BX, BY, BZ, BNV, 1, TD, true, WZ>(p, OV, st);
+  if (g_conv_products == 2) return launch_halo_k<BX, BY, BZ, BNV, 2, TD, true, WZ>(p, OV, st);
+  if constexpr (WZ) return launch_halo_k<BX, BY, BZ, BNV, 3, TD, true, true>(p, OV, st);
   // the lockstep form is kept for the fp32-faithful mode only: it is the reference of the schedule's bit-identity test, and the
   // form of the whole-grid bricks (four row tiles per wave: the unrolled pipelined loop spills 600 registers there)
   if (!g_tune_halo_stagger || BX * BY * BZ > 256) return launch_halo_k<BX, BY, BZ, BNV, 3, TD, false>(p, OV, st);
@@ -1208,35 +1232,15 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 //     G0 = w0,  G1 = (w0 + w1 + w2) / 2,  G2 = (w0 - w1 + w2) / 2,  G3 = w2        (weight transform, once per module)
 //     m_k = sum over (dx, dy, ci) of t_k G_k                                        (four 3 x 3 convolutions over (x, y))
 //     y[2j] = m0 + m1 + m2,   y[2j + 1] = m1 - m2 - m3                              (output transform)
-// 18 instead of 27 tap-GEMMs per output.  Three launches: the input transform writes the four transform-domain volumes as a stack
-// of 4 * Z/2 "images" of X x Y pixels (position-major), the halo kernel's 2-D form convolves the stack with one weight set per
-// position (bricks of 4 images x 8 x 8 pixels: no halo along the image axis), the output transform combines and applies the
-// epilogue (scale / shift / relu / residual / activation -- the direct kernel's expressions in the direct kernel's order).
+// 18 instead of 27 tap-GEMMs per output.  Two launches: the halo kernel's 2-D form convolves a VIRTUAL stack of 4 * Z/2 "images" of
+// X x Y pixels (position-major; bricks of 4 images x 8 x 8 pixels, no halo along the image axis) with one weight set per position --
+// the input transform is applied while the halo rows are staged (template flag WZ: two voxel rows per chunk, one add, then the
+// hi / lo split; a transformed copy of the input never exists) -- and the output transform combines the four results and applies
+// the epilogue (scale / shift / relu / residual -- the direct kernel's expressions in the direct kernel's order).
 // The fused form does not fit: four accumulators per output pair and four weight tiles per tap need 164 - 189 KB of LDS.
 // Entries 0, +-1, +-1/2: every transform is exact up to one fp32 rounding per element; measured error against the direct form
 // in tests/test_gpu_conv3d.py.  Deterministic (no atomics, fixed order).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void winograd_z_in_kernel(const float4 *__restrict__ x, float4 *__restrict__ t, int X, int Y, int Z, int C4) {
-  const int J = Z >> 1;
-  const int64_t total = (int64_t)X * Y * J * C4, plane = (int64_t)X * Y * C4;        // one image of the stack
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    int64_t r = i / C4;
-    const int j = (int)(r % J); r /= J;
-    const int yy = (int)(r % Y), xx = (int)(r / Y);
-    const float4 *col = x + (((int64_t)xx * Y + yy) * Z) * C4 + c;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 d0 = 2 * j - 1 >= 0 ? col[(int64_t)(2 * j - 1) * C4] : z4;
-    const float4 d1 = col[(int64_t)(2 * j) * C4], d2 = col[(int64_t)(2 * j + 1) * C4];
-    const float4 d3 = 2 * j + 2 < Z ? col[(int64_t)(2 * j + 2) * C4] : z4;
-    float4 *o = t + ((int64_t)j * X + xx) * Y * C4 + (int64_t)yy * C4 + c;
-    o[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-    o[(int64_t)J * plane] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-    o[(int64_t)2 * J * plane] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-    o[(int64_t)3 * J * plane] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
-  }
-}
-
 __global__ __launch_bounds__(256) void winograd_z_out_kernel(const float4 *__restrict__ m, float4 *__restrict__ y,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
                                                              const float4 *__restrict__ residual, int X, int Y, int Z, int C4, int relu,
@@ -1401,11 +1405,12 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
                          int ix, int iy, int iz, int Cin, int Cout, int ksize, int stride,
                          int transposed, int relu, float *workspace_or_null, int64_t workspace_floats,
                          const uint8_t *out_mask_or_null, sgc_stream_t stream, int two_d = 0,
-                         const float *act_scale = nullptr, int act_c0 = 0, int act_c1 = 0, int w_group_images = 0) {
+                         const float *act_scale = nullptr, int act_c0 = 0, int act_c1 = 0, int w_group_images = 0, int wz_Z = 0) {
   ConvParamsB p = {};
   p.out_mask = out_mask_or_null;
   p.two_d = two_d;
   p.w_group_images = w_group_images;
+  p.wz_Z = wz_Z;
   p.act_scale = act_c1 > act_c0 ? act_scale : nullptr; p.act_c0 = act_c0; p.act_c1 = act_c1;
   int ox, oy, oz;
   int rc = conv_setup(p, "sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, y, ix, iy, iz, Cin, Cout, ksize, stride, transposed, relu, ox, oy, oz);
@@ -1445,7 +1450,10 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     const bool narrow_n = g_tune_halo_narrow && Cout <= 64;
     // bricks of 4 images x 8 x 8 pixels -- no halo along the image axis, 400 staged rows per 256 outputs: the geometry of the
     // transform-domain convolutions of sgc_conv3d_winograd_z_bf16x3 (image groups = positions); halo_2d = 2 selects it for any stack
-    if ((g_tune_halo_2d == 2 || p.w_group_images > 0) && !narrow_n && p.gx % 4 == 0 && (p.w_group_images == 0 || p.w_group_images % 4 == 0))
+    if (p.wz_Z > 0 && !narrow_n && p.w_group_images == p.wz_Z / 2 && p.w_group_images % 4 == 0 && p.gx == 2 * p.wz_Z)
+      rc = launch_halo<4, 8, 8, 128, true, true>(p, OV, st);
+    else if (p.wz_Z > 0) return set_error(SGC_EUNSUP, "conv: the virtual Winograd stack needs Z / 2 a multiple of 4 and > 64 output channels");
+    else if ((g_tune_halo_2d == 2 || p.w_group_images > 0) && !narrow_n && p.gx % 4 == 0 && (p.w_group_images == 0 || p.w_group_images % 4 == 0))
       rc = launch_halo<4, 8, 8, 128, true>(p, OV, st);
     else if (p.w_group_images > 0) return set_error(SGC_EUNSUP, "conv: grouped 2-D form needs groups of a multiple of 4 images and > 64 output channels");
     else
@@ -1453,7 +1461,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
     if (rc) return rc;
     return conv_finish(p, OV, st);
   }
-  if (p.w_group_images > 0) return set_error(SGC_EUNSUP, "conv: the grouped 2-D form runs on the halo kernel only (stack too small?)");
+  if (p.w_group_images > 0 || p.wz_Z > 0) return set_error(SGC_EUNSUP, "conv: the grouped 2-D form runs on the halo kernel only (stack too small?)");
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
@@ -2293,10 +2301,14 @@ extern "C" int sgc_conv3d_cl_bf16x3_act(const float *x, const uint16_t *w_hi, co
 }
 
 extern "C" int sgc_conv3d_winograd_z_supported(int ix, int iy, int iz, int Cin, int Cout) {
-  return ix > 0 && iy > 0 && iz >= 8 && iz % 8 == 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 ? 1 : 0;     // Z/2 images per position, in bricks of 4
+  // Z/2 images per position, in bricks of 4; the 2-D halo form wants slices of at least 8 x 8 pixels and g_tune_halo_min_m rows in the stack
+  return ix >= 8 && iy >= 8 && iz >= 8 && iz % 8 == 0 && Cin % 32 == 0 && Cout % 4 == 0 && Cout > 64 && Cout >= g_tune_halo_min_cout &&
+                 (int64_t)2 * iz * ix * iy >= g_tune_halo_min_m && g_tune_conv_halo && g_tune_halo_2d
+             ? 1 : 0;
 }
 extern "C" int64_t sgc_conv3d_winograd_z_workspace_floats(int ix, int iy, int iz, int Cin, int Cout) {
-  return sgc_conv3d_winograd_z_supported(ix, iy, iz, Cin, Cout) ? (int64_t)2 * ix * iy * iz * ((int64_t)Cin + Cout) : 0;
+  (void)Cin;
+  return sgc_conv3d_winograd_z_supported(ix, iy, iz, Cin, Cout) ? (int64_t)2 * ix * iy * iz * Cout : 0;    // the four transform-domain outputs
 }
 
 // 3x3x3 stride-1 convolution through the Winograd F(2,3) transform along z (see the kernels above): wg_hi / wg_lo are the bf16 hi / lo
@@ -2307,7 +2319,7 @@ extern "C" int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_h
                                             sgc_stream_t stream) {
   if (!x || !wg_hi || !wg_lo || !y || !workspace) return set_error(SGC_EINVAL, "sgc_conv3d_winograd_z_bf16x3: null pointer");
   if (!sgc_conv3d_winograd_z_supported(ix, iy, iz, Cin, Cout))
-    return set_error(SGC_EUNSUP, "sgc_conv3d_winograd_z_bf16x3: needs iz %% 8 == 0, Cin %% 32 == 0, Cout %% 4 == 0, Cout > 64");
+    return set_error(SGC_EUNSUP, "sgc_conv3d_winograd_z_bf16x3: needs ix, iy >= 8, iz %% 8 == 0, Cin %% 32 == 0, Cout %% 4 == 0, Cout > 64, >= 2048 stack rows");
   if (workspace_floats < sgc_conv3d_winograd_z_workspace_floats(ix, iy, iz, Cin, Cout))
     return set_error(SGC_EINVAL, "sgc_conv3d_winograd_z_bf16x3: workspace too small");
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)residual_or_null | (uintptr_t)scale | (uintptr_t)shift) & 15)
@@ -2315,15 +2327,12 @@ extern "C" int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_h
   hipStream_t st = (hipStream_t)stream;
   const int64_t V = (int64_t)ix * iy * iz;
   const int J = iz / 2;
-  float *t = workspace, *m = workspace + 2 * V * Cin;
-  const int64_t n_in = V / 2 * (Cin / 4), n_out = V / 2 * (Cout / 4);
-  hipLaunchKernelGGL(winograd_z_in_kernel, dim3((unsigned)std::min<int64_t>((n_in + 255) / 256, 65536)), dim3(256), 0, st,
-                     reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(t), ix, iy, iz, Cin / 4);
-  int rc = check_launch("winograd_z_in_kernel");
-  if (rc) return rc;
-  // four 3 x 3 convolutions over (x, y) as ONE launch of the halo kernel's 2-D form: 4 J images, weight set = image / J
-  rc = conv3d_bf16x3(t, wg_hi, wg_lo, nullptr, nullptr, nullptr, m, 4 * J, ix, iy, Cin, Cout, 3, 1, 0, 0, nullptr, 0, nullptr, stream, 1,
-                     nullptr, 0, 0, J);
+  float *m = workspace;
+  const int64_t n_out = V / 2 * (Cout / 4);
+  // four 3 x 3 convolutions over (x, y) as ONE launch of the halo kernel's 2-D form on the VIRTUAL stack of 4 J images (the input
+  // transform happens while the halo rows are staged: template flag WZ), weight set = image / J
+  int rc = conv3d_bf16x3(x, wg_hi, wg_lo, nullptr, nullptr, nullptr, m, 4 * J, ix, iy, Cin, Cout, 3, 1, 0, 0, nullptr, 0, nullptr, stream, 1,
+                         nullptr, 0, 0, J, iz);
   if (rc) return rc;
   hipLaunchKernelGGL(winograd_z_out_kernel, dim3((unsigned)std::min<int64_t>((n_out + 255) / 256, 65536)), dim3(256), 0, st,
                      reinterpret_cast<const float4 *>(m), reinterpret_cast<float4 *>(y), scale, shift,

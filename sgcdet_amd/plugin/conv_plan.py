@@ -43,6 +43,7 @@ def set_conv_mode(mode):
 # (<= 2e-5 of the tensor scale, tested); each choice is deterministic.  Set before the first forward: plans are cached.
 WINOGRAD_Z = {"0": False, "1": True}.get(os.environ.get("SGC_WINOGRAD_Z", ""), "auto")
 WINOGRAD_Z_MIN_CH = int(os.environ.get("SGC_WINOGRAD_Z_MIN_CH", "256"))
+WINOGRAD_Z_RAGGED = os.environ.get("SGC_WINOGRAD_Z_RAGGED", "1") != "0"     # also slices the 8 x 8 pixel bricks do not tile exactly (20 x 20)
 
 
 def set_winograd_z(mode, min_channels=None):
@@ -90,7 +91,8 @@ class ConvSpec:
     def _winograd_planes(self, grid):
         """The transformed weight planes when this call should take the Winograd-z form, else None."""
         if (WINOGRAD_Z is False or self.ksize != 3 or self.stride != 1 or self.transposed or CONV_MODE != "bf16x3"
-                or (WINOGRAD_Z == "auto" and self.cin_p < WINOGRAD_Z_MIN_CH) or grid[0] % 8 or grid[1] % 8):
+                or (WINOGRAD_Z == "auto" and self.cin_p < WINOGRAD_Z_MIN_CH)
+                or (not WINOGRAD_Z_RAGGED and (grid[0] % 8 or grid[1] % 8))):
             return None
         ops = ext.ops()
         if not ops.conv3d_winograd_z_supported(grid, self.cin_p, self.cout_p):

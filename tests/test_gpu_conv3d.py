@@ -555,7 +555,7 @@ def test_32_column_tiles_are_bit_identical_to_the_64_column_form(grid, cin, cout
 
 
 @pytest.mark.parametrize("grid,cin,cout,relu,res", [((16, 16, 16), 64, 128, 1, True), ((40, 40, 16), 256, 256, 1, True), ((8, 24, 8), 96, 160, 2, True),
-                                                     ((16, 8, 32), 32, 72, 0, False)])
+                                                     ((16, 8, 32), 32, 72, 0, False), ((20, 20, 8), 512, 512, 1, True), ((13, 11, 8), 64, 96, 0, False)])
 def test_winograd_z_convolution_against_the_direct_form(grid, cin, cout, relu, res, oracle_ops, gpu_ops):
     """sgc_conv3d_winograd_z_bf16x3 (F(2,3) along z: 18 of the 27 tap-GEMMs) is the same operator as the direct 3x3x3 kernel:
     against the ORACLE's direct convolution on the original weights and against the GPU's direct kernel, 2e-5 of the tensor scale
@@ -583,6 +583,7 @@ def test_winograd_z_convolution_against_the_direct_form(grid, cin, cout, relu, r
         twin, _ = oracle_ops.conv3d_winograd_z(x, ghi, glo, grid, scale, shift, residual, relu)
         assert (got.cpu() - twin).abs().max() < 1e-5 * sc
     assert not gpu_ops.conv3d_winograd_z_supported((16, 16, 12), cin, cout) and not gpu_ops.conv3d_winograd_z_supported(grid, cin, 64)
+    assert not gpu_ops.conv3d_winograd_z_supported((13, 9, 8), cin, cout)          # fewer than 2048 rows in the stack: the direct kernel
 
 
 def test_winograd_z_through_the_neck_keeps_parity():
@@ -610,7 +611,7 @@ def test_winograd_z_through_the_neck_keeps_parity():
             torch.cuda.synchronize()
             n_w = len(ops.event_log)
             ops.event_log, ops.event_names = None, None
-            assert (n_w == 4) == bool(mode), n_w            # the three 256 -> 256 and the 256 -> 128 layer of the 40 x 40 x 16 scale
+            assert (n_w == 7) == bool(mode), n_w            # 40 x 40 x 16: three 256 -> 256, one 256 -> 128; 20 x 20 x 8: two 512 -> 512, one 512 -> 128
             outs[mode] = [t.clone() for part in o for t in part]
     finally:
         conv_plan.set_winograd_z("auto", min_channels=256)
