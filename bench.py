@@ -533,10 +533,14 @@ def main():
         n_e = max(6, min(n_timed, 20))
         # (a block-diagonal Linear run as a dense GEMM -- the per-voxel V projection of the projected-query attention -- counts with
         #  its structurally non-zero fraction `useful`: the zero blocks are launch geometry, not work the path has to do)
-        gemm = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0)
+        # (ConvTranspose3d(2, 2): every OUTPUT voxel receives exactly one of the 8 taps -- 2 Cin Cout per output voxel, SURVEY.md 8d;
+        #  `flop_taps` = 1.  Rounds 3 - 4 multiplied by the 8 taps of the weight tensor and overstated the path's GEMM work by 70 GF
+        #  (11 %) at config 2: floors / `path_roofline.frac` of those rounds are that much too high.)
+        ftaps = lambda m: m.get("flop_taps", m.get("taps") or 1)      # noqa: E731
+        gemm = sum(2.0 * ftaps(m) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0)
                    for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
         # multiply-adds actually issued: the Winograd-z layers issue 2/3 of their algorithmic count (`mac_frac`)
-        gemm_issued = sum(2.0 * (m.get("taps") or 1) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0) * m.get("mac_frac", 1.0)
+        gemm_issued = sum(2.0 * ftaps(m) * m["Cin"] * m["Cout"] * (m.get("OV") or m["V"]) * m.get("useful", 1.0) * m.get("mac_frac", 1.0)
                           for items in per_kernel.values() for _, m in items if "Cin" in m) / n_e
         gbytes = 0.0
         for name, items in per_kernel.items():
@@ -577,7 +581,7 @@ def main():
             n_eager = max(6, min(n_timed, 20))
             for key, (cnt, tt) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]:
                 V, Cin, Cout, taps, OV = key
-                gf = 2.0 * (taps or 1) * Cin * Cout * (OV or V) / 1e9
+                gf = 2.0 * (1 if taps == 8 else (taps or 1)) * Cin * Cout * (OV or V) / 1e9       # taps = 8: ConvTranspose3d(2, 2), one tap per output voxel
                 print(f"      V={V:7d} Cin={Cin:5d} Cout={Cout:5d} taps={taps:3d} -> {cnt / n_eager:4.1f}/scene {tt / cnt * 1e6:8.1f} us  "
                       f"{gf:7.1f} GF  {gf / (tt / cnt) / 1e3:7.1f} TF-equiv", file=sys.stderr)
 

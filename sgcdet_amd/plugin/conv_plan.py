@@ -97,6 +97,13 @@ class ConvSpec:
         ops = ext.ops()
         if not ops.conv3d_winograd_z_supported(grid, self.cin_p, self.cout_p):
             return None
+        # The transform-domain launch has Z/8 x ceil(X/8) x ceil(Y/8) bricks per position x 4 positions x ceil(Cout/128) column tiles
+        # and no reduction split.  A layer ALONE needs enough of them to fill the chip (512 -> 128 @ 20x20x8: 36 workgroups, 154 us
+        # against 55 us direct); with scenes in flight the other streams fill it and the saved multiply-adds count (+2 % at config 2).
+        if WINOGRAD_Z == "auto" and not THROUGHPUT_GEOMETRY:
+            wgs = (grid[2] // 8) * -(-grid[0] // 8) * -(-grid[1] // 8) * 4 * -(-self.cout_p // 128)
+            if wgs < 192:
+                return None
         if self._wino is None:
             self._wino = ops.split_operand(ops.winograd_z_weights(self.wt))
         return self._wino
@@ -123,6 +130,9 @@ TRAIN_CONV = os.environ.get("SGC_TRAIN_CONV", "hip")
 BN_ON_HIP = os.environ.get("SGC_BN_HIP", "1") != "0"      # training-mode BatchNorm of the neck on sgc_bn_rows_* (0: torch's kernels)
 
 
+THROUGHPUT_GEOMETRY = False      # set_throughput_mode(True): scenes in flight, kernels sized for CU-time (read by ConvSpec._winograd_planes)
+
+
 def set_throughput_mode(on):
     """Launch geometry for several scenes in flight (one hipGraph per scene on its own stream, bench.py).  With four scenes
     overlapping the chip is CU-time bound -- the sum of workgroup residency of all kernels, not any kernel's latency, sets the
@@ -136,6 +146,8 @@ def set_throughput_mode(on):
         deterministic and bit-identical between graph replays and eager launches.
     Together +3.5 % scenes/s (alternated runs).  Off = the latency-optimal geometry (one scene at a time, the default of the
     library).  Call it before the first scene: captured graphs keep the geometry they were captured with."""
+    global THROUGHPUT_GEOMETRY
+    THROUGHPUT_GEOMETRY = bool(on)
     from .. import ext
     lib = ext.ops().lib
     explicit = os.environ.get("SGC_TUNE", "")

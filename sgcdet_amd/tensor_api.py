@@ -582,7 +582,7 @@ class TensorOps:
             return y, og
         self._call("sgc_conv3d_cl_bf16x3", x, w_hi, w_lo, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize,
                    stride, 1 if transposed else 0, int(relu), ws, ws_n,
-                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
+                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0], flop_taps=1 if transposed else taps))
         return y, og
 
     @staticmethod
@@ -965,7 +965,7 @@ class TensorOps:
         ws, ws_n = self._conv_workspace(x.device, ix, iy, iz, Cin, Cout, ksize, stride, transposed, 0)
         self._call("sgc_conv3d_cl_f32", x, wt, scale, shift, residual, y, ix, iy, iz, Cin, Cout, ksize, stride,
                    1 if transposed else 0, int(relu), ws, ws_n,
-                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0]))
+                   _meta=dict(V=V, Cin=Cin, Cout=Cout, taps=taps, OV=y.shape[0], flop_taps=1 if transposed else taps))
         return y, og
 
     # ---- coarse-to-fine glue -------------------------------------------------------------

@@ -603,7 +603,7 @@ def test_winograd_z_through_the_neck_keeps_parity():
     ops = ext.ops()
     try:
         for mode in (False, True):
-            conv_plan.set_winograd_z(mode, min_channels=256)
+            conv_plan.set_winograd_z(mode, min_channels=256)       # True (not "auto"): also the layers a lone scene would leave direct
             det.neck_3d.__dict__.pop("_hip_plan", None)
             ops.event_log, ops.event_names = [], {"sgc_conv3d_winograd_z_bf16x3"}
             with torch.no_grad():
