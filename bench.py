@@ -90,6 +90,9 @@ def parse():
                          "headline) or a seeded SURFACE-CLUSTERED override (sgcdet_amd.scene.clustered_occupancy; SURVEY.md 8d "
                          "allows a controlled mask): the workload on which --masked-tail can skip bricks.  Its own line, never "
                          "the headline")
+    ap.add_argument("--winograd", default="auto", choices=["auto", "off"],
+                    help="auto (default): the wide 3x3x3 stride-1 layers run through the Winograd F(2,3)-along-z form (2/3 of their "
+                         "multiply-adds; <= 2e-5 of the tensor scale from the direct form, tested); off: every layer on the direct kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of the extra `sustained` leg (same configuration, back to back; 0 = skip)")
@@ -284,6 +287,9 @@ def main():
     from sgcdet_amd import ext
     from sgcdet_amd.plugin.conv_plan import set_conv_mode
     set_conv_mode(args.conv_mode)
+    if args.winograd == "off":
+        from sgcdet_amd.plugin import conv_plan as _cp
+        _cp.set_winograd_z(False)
     w = workload(args.workload)
     n_views = args.views or w["n_views"]
     det = build_path(w, device)
@@ -625,6 +631,8 @@ def main():
             tail_stats = dict(voxels=dict(valid=round(float(v.mean()), 3), dilate1=round(float(d1.mean()), 3), dilate2=round(float(d2.mean()), 3)),
                               live_bricks={"brick": "x".join(map(str, bshape)), "head_conv(valid)": live(v),
                                            "out_block_0(dilate1)": live(d1), "up_block_1(dilate2)": live(d2)})
+    from sgcdet_amd.plugin import conv_plan
+    winograd_on = conv_plan.WINOGRAD_Z is not False and args.conv_mode != "f32"
     if rank == 0:
         out = {
             "metric": "scenes/sec (40-view ScanNet volume) at 1/2/4/8 MI355X; mAP@0.25 parity",
@@ -648,7 +656,10 @@ def main():
                       "; NOT parity-exact, not the headline)" if args.conv_mode == "fp16" else
                       "bf16 storage (value map and depth maps of the deformable gather in bfloat16, fp32 accumulate and outputs; opt-in, not parity-exact)"
                       if args.storage == "bf16" else
-                      "f32" if args.conv_mode == "f32" else "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32)"),
+                      "f32" if args.conv_mode == "f32" else
+                      "f32 (neck/head conv: 3xbf16-split MFMA, fp32 accumulate, ~1e-5 of fp32" +
+                      ("; wide 3x3x3 stride-1 layers through a Winograd F(2,3) transform along z: <= 2e-5 of the tensor scale per layer against "
+                       "the direct fp32 convolution" if winograd_on else "") + ")"),
             "data": "synthetic",
             "config": {"workload": f"{w['name']}: {n_views} views x {w['embed_dims']} ch, images "
                                    f"{'x'.join(str(v) for v in scenes[0][2][0]['img_shape'][:2])}, FPN maps "
@@ -658,6 +669,8 @@ def main():
                        "occupancy": ("predicted" if args.occupancy == "predicted" else
                                      "clustered override (seeded floor + two walls + a box shell; top-k ranks the distance to them)"),
                        "masked_tail": bool(det.masked_tail), "masked_tail_stats": tail_stats,
+                       "winograd_z": (f"auto: 3x3x3 stride-1 layers with >= {conv_plan.WINOGRAD_Z_MIN_CH} input channels and a z extent that is a "
+                                      "multiple of 8 (sgc_conv3d_winograd_z_bf16x3)" if winograd_on else "off"),
                        "input_layout": args.input_layout, "scenes_per_step_per_gpu": spp, "scenes_in_flight_per_gpu": args.streams, "prewarm_s": args.prewarm,
                        "launch_geometry": ("throughput (row GEMMs on half the CUs; fewer reduction splits in the layers with few voxels; "
                                             "conv_plan.set_throughput_mode)"
