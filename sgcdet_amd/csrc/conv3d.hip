@@ -1238,6 +1238,12 @@ __global__ void conv_epilogue_kernel(float *__restrict__ y, const float *__restr
 // hi / lo split; a transformed copy of the input never exists) -- and the output transform combines the four results and applies
 // the epilogue (scale / shift / relu / residual -- the direct kernel's expressions in the direct kernel's order).
 // The fused form does not fit: four accumulators per output pair and four weight tiles per tap need 164 - 189 KB of LDS.
+// (The output transform in the TAIL of the convolution launch -- tiles to the scratch with sc1 stores, an arrival counter per brick, the
+//  last of a brick's four position workgroups reads the four tiles back behind an agent-scope acquire and stores the output -- was
+//  built, bit-identical, and measured: the convolution launch grows from 200-209 to 230-237 us, more than the 12.5 us launch it
+//  removes; 557-560 against 563-572 scenes/s with four scenes in flight, 384-388 against 395-400 with one
+//  (profiles/r05_wzfuse_ab.txt, also with the four positions adjacent on one XCD).  One CU moves the 1.25 MB of a brick's tiles,
+//  residual and output at 50-100 GB/s; 256 CUs in a separate launch do it at the chip's rate.)
 // Entries 0, +-1, +-1/2: every transform is exact up to one fp32 rounding per element; measured error against the direct form
 // in tests/test_gpu_conv3d.py.  Deterministic (no atomics, fixed order).
 // ---------------------------------------------------------------------------------------------
