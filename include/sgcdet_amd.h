@@ -611,6 +611,20 @@ int sgc_pack_conv_weight(const float *w, uint16_t *w_hi, uint16_t *w_lo, int A, 
                          int flip, sgc_stream_t stream);
 int sgc_unpack_conv_wgrad(const float *dw_trc, float *dw, int A, int B, int T, int R, int C, int transpose, int flip,
                           sgc_stream_t stream);
+/* (round 5) sgc_pack_conv_weight for a LIST of parameters in one launch -- a training step packs every parameter of the path in
+ * two forms (forward and input-gradient layout), ~100 launches of mostly a few microseconds of work; the host side keeps the
+ * planes and the item list across steps and repacks all of them at once when the parameters have changed.
+ *   items: n_items descriptors in DEVICE memory (host memory for the oracle); block_start ascending from 0, item i owning
+ *   sgc_pack_conv_weight_blocks(A, B, T, transpose) workgroups; total_blocks = their sum; max_T = the largest T.
+ *   The padding of the planes (R, C beyond the matrix) is NOT written: allocate them zeroed, once. */
+typedef struct sgc_pack_item {
+  const float *w;                 /* parameter [A][B][T] */
+  uint16_t *hi, *lo;              /* planes [T][R][C] */
+  int32_t A, B, T, R, C, transpose, flip, block_start;
+  int32_t reserved[2];
+} sgc_pack_item;                  /* 64 bytes */
+int sgc_pack_conv_weight_blocks(int A, int B, int T, int transpose);
+int sgc_pack_conv_weight_batch(const void *items, int n_items, int total_blocks, int max_T, sgc_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * 8. Post-processing

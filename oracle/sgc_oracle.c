@@ -1501,6 +1501,32 @@ int sgc_pack_conv_weight(const float *w, uint16_t *w_hi, uint16_t *w_lo, int A, 
   return SGC_OK;
 }
 
+/* the batch form: the same map per item (include/sgcdet_amd.h: sgc_pack_item); padding is left as the caller zeroed it */
+int sgc_pack_conv_weight_blocks(int A, int B, int T, int transpose) {
+  if (A <= 0 || B <= 0 || T <= 0) return 0;
+  return transpose ? ((B + 7) / 8) * ((A + 31) / 32) : ((B + 31) / 32) * ((A + 7) / 8);
+}
+int sgc_pack_conv_weight_batch(const void *items, int n_items, int total_blocks, int max_T, sgc_stream_t stream) {
+  (void)stream; (void)max_T;
+  if (!items || n_items <= 0 || total_blocks <= 0) return fail(SGC_EINVAL, "bad arguments");
+  const sgc_pack_item *it = (const sgc_pack_item *)items;
+  for (int i = 0; i < n_items; ++i) {
+    const int A = it[i].A, B = it[i].B, T = it[i].T, R = it[i].R, C = it[i].C, tr = it[i].transpose, fl = it[i].flip;
+    if (!it[i].w || !it[i].hi || !it[i].lo || A <= 0 || B <= 0 || T <= 0 || R < (tr ? B : A) || C < (tr ? A : B)) return fail(SGC_EINVAL, "bad item");
+    for (int t = 0; t < T; ++t)
+      for (int a = 0; a < A; ++a)
+        for (int b = 0; b < B; ++b) {
+          const int r = tr ? b : a, c = tr ? a : b;
+          const float v = it[i].w[((int64_t)a * B + b) * T + (fl ? T - 1 - t : t)];
+          const uint16_t hb = f32_to_bf16_rne(v);
+          const int64_t o = ((int64_t)t * R + r) * C + c;
+          it[i].hi[o] = hb;
+          it[i].lo[o] = f32_to_bf16_rne(v - bf16_to_f32(hb));
+        }
+  }
+  return SGC_OK;
+}
+
 int sgc_unpack_conv_wgrad(const float *dw_trc, float *dw, int A, int B, int T, int R, int C, int transpose, int flip,
                           sgc_stream_t stream) {
   (void)stream;

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sgc_set_conv_products": [_i],
     "sgc_pack_conv_weight": [_p] * 3 + [_i] * 7 + [_p],
     "sgc_unpack_conv_wgrad": [_p] * 2 + [_i] * 7 + [_p],
+    "sgc_pack_conv_weight_batch": [_p] + [_i] * 3 + [_p],
 }
 
 INTROSPECTION = {
@@ -79,6 +80,7 @@ INTROSPECTION = {
     "sgc_level_tail_supported": (C.c_int, [_i] * 2),
     "sgc_view_attend_pq_supported": (C.c_int, [_i] * 3),
     "sgc_conv3d_winograd_z_supported": (C.c_int, [_i] * 5),
+    "sgc_pack_conv_weight_blocks": (C.c_int, [_i] * 4),
     "sgc_conv3d_winograd_z_workspace_floats": (C.c_int64, [_i] * 5),
     "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),

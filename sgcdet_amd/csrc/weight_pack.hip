@@ -6,6 +6,10 @@
 //                           gradient of a 3x3x3 convolution walks the taps backwards) and zero-padded (R, C up to multiples the
 //                           kernels need).
 //   sgc_unpack_conv_wgrad   the weight-gradient kernel's [T][R][C] fp32 result -> the parameter's [A][B][T] layout.
+//   sgc_pack_conv_weight_batch   (round 5) the pack of MANY parameters in one launch: a training step packs ~100 parameters (two
+//                           forms each: forward and input-gradient layout), most of them a few microseconds of work -- 96 launches
+//                           were 1.2 ms of device time and 2.2 ms of wall per config-2 step (the host could not keep the GPU fed:
+//                           tools/trace_gaps.py); the batch moves the same bytes in one launch at the rate of the large layers.
 //
 // In round 2 these were torch ops per layer and per pass (permute + contiguous: an uncoalesced strided copy of up to 113 MB;
 // then to(bfloat16), subtract, to(bfloat16) for the split): 3.5 ms of strided copies + 1.4 ms of conversion kernels per
@@ -32,11 +36,11 @@ constexpr int PK = 32;
 // the transposed one -> 32 a x 8 b.  27.6 KB of LDS at 27 taps: five workgroups per CU (the first version moved 32 x 32 x T
 // blocks, 110 KB and one 8-wave workgroup per CU, through one barrier: 0.5 TB/s, 2.4 ms per training step).
 template <int PA, int PB>
-__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const PackParams p) {
+__device__ __forceinline__ void pack_block(const PackParams &p, int bx, int by) {
   extern __shared__ float pk_lds[];                 // [PA a][PB b][T] (+1 pad per a-row)
   constexpr bool TR = PA == 32;                     // the transposed layout (c = a)
   const int T = p.T, run = PB * T, pitch = run + 1;
-  const int a0 = blockIdx.y * PA, b0 = blockIdx.x * PB;
+  const int a0 = by * PA, b0 = bx * PB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // load: for every a of the block the run [b0, b0 + PB) x T is contiguous in w; a wave takes whole runs
   const int nvalid_b = (p.B - b0 < PB ? p.B - b0 : PB) * T;
@@ -71,6 +75,38 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const PackParams 
       for (int j = 0; j < 8 && gc + j < p.C; ++j) { p.hi[o + j] = h[j]; p.lo[o + j] = l[j]; }
     }
   }
+}
+
+template <int PA, int PB>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const PackParams p) { pack_block<PA, PB>(p, blockIdx.x, blockIdx.y); }
+
+// One launch for a list of parameters (sgc_pack_conv_weight_batch): block -> item by binary search over the items' first blocks,
+// then the single-parameter block above.  The item list lives in device memory (the host side builds it once per model).
+struct PackItem {                 // = sgc_pack_item of include/sgcdet_amd.h (64 bytes)
+  const float *w;
+  uint16_t *hi, *lo;
+  int A, B, T, R, C, transpose, flip, block_start;
+  int pad_[2];
+};
+static_assert(sizeof(PackItem) == 64, "sgc_pack_item is 64 bytes");
+__device__ __host__ inline int pack_blocks_x(int B, int transpose) { return transpose ? (B + 7) / 8 : (B + 31) / 32; }
+__device__ __host__ inline int pack_blocks_y(int A, int transpose) { return transpose ? (A + 31) / 32 : (A + 7) / 8; }
+
+__global__ __launch_bounds__(256) void pack_conv_weight_batch_kernel(const PackItem *__restrict__ items, int n) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;                           // last item with block_start <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackItem it = items[lo];
+  PackParams p = {};
+  p.w = it.w; p.hi = reinterpret_cast<__bf16 *>(it.hi); p.lo = reinterpret_cast<__bf16 *>(it.lo);
+  p.A = it.A; p.B = it.B; p.T = it.T; p.R = it.R; p.C = it.C; p.transpose = it.transpose; p.flip = it.flip;
+  const int local = b - it.block_start, gx = pack_blocks_x(it.B, it.transpose);
+  if (local >= gx * pack_blocks_y(it.A, it.transpose)) return;
+  if (it.transpose) pack_block<32, 8>(p, local % gx, local / gx);
+  else pack_block<8, 32>(p, local % gx, local / gx);
 }
 
 __global__ __launch_bounds__(512) void unpack_conv_wgrad_kernel(const PackParams p) {
@@ -150,6 +186,24 @@ extern "C" int sgc_pack_conv_weight(const float *w, uint16_t *w_hi, uint16_t *w_
       return set_error(SGC_ELAUNCH, "sgc_pack_conv_weight: memset failed");
   }
   return pack_launch(false, p, st);
+}
+
+extern "C" int sgc_pack_conv_weight_blocks(int A, int B, int T, int transpose) {
+  if (A <= 0 || B <= 0 || T <= 0) return 0;
+  return pack_blocks_x(B, transpose) * pack_blocks_y(A, transpose);
+}
+
+// items_dev: n_items descriptors in DEVICE memory, block_start ascending from 0 with item i owning sgc_pack_conv_weight_blocks()
+// blocks; total_blocks = their sum; max_T = the largest tap count among them (sizes the LDS block).  The padding rows / columns of
+// the planes (R, C beyond the matrix) are NOT written: the caller allocates the planes zeroed, once.
+extern "C" int sgc_pack_conv_weight_batch(const void *items_dev, int n_items, int total_blocks, int max_T, sgc_stream_t stream) {
+  if (!items_dev) return set_error(SGC_EINVAL, "sgc_pack_conv_weight_batch: null pointer");
+  if (n_items <= 0 || total_blocks <= 0 || max_T <= 0) return set_error(SGC_EINVAL, "sgc_pack_conv_weight_batch: bad size");
+  const size_t smem = (size_t)8 * 32 * max_T * sizeof(float) + 32 * sizeof(float);
+  if (smem > 64 * 1024) return set_error(SGC_EUNSUP, "sgc_pack_conv_weight_batch: %d taps do not fit the block in LDS", max_T);
+  hipLaunchKernelGGL(pack_conv_weight_batch_kernel, dim3(total_blocks), dim3(256), smem, (hipStream_t)stream,
+                     reinterpret_cast<const PackItem *>(items_dev), n_items);
+  return check_launch("pack_conv_weight_batch_kernel");
 }
 
 extern "C" int sgc_unpack_conv_wgrad(const float *dw_trc, float *dw, int A, int B, int T, int R, int C, int transpose, int flip,

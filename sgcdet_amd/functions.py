@@ -21,6 +21,8 @@ Differences, all behind the same call signature:
   SURVEY.md section 0 fact 2); they are aliases of the fp32 Functions here, which is what
   ``custom_fwd(cast_inputs=torch.float32)`` amounts to.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -142,6 +144,85 @@ def _require_bf16_planes(who):
                            "pack bfloat16 weight planes; switch to 'bf16x3' / 'bf16' or run under torch.no_grad()")
 
 
+class TrainWeightPlanes:
+    """The bf16 hi | lo planes the training Functions multiply with, kept across steps and repacked TOGETHER.
+
+    Every pass of a training step needs each parameter in the kernels' layout: [taps, Cout, Cin] for the forward, [taps, Cin, Cout]
+    with mirrored taps for the input gradient (cuDNN does the same internally, necks/imvoxelnet.py:36-64).  Packing them where they
+    are used is ~100 launches per config-2 step, most of them a few microseconds of work.  Here a plane pair is allocated the first
+    time a (parameter storage, shape, form) is asked for and is registered; ``begin_step()`` -- the detector calls it at the start
+    of every training forward -- repacks ALL registered planes in one launch (``sgc_pack_conv_weight_batch``): the same bytes in one
+    launch instead of a hundred.  A plane is never served stale: ``get`` compares the version counter the parameter shares with
+    the alias kept here (an in-place update between ``begin_step`` and the use repacks); edits through ``.data`` do not move
+    that counter, which is why ``begin_step`` repacks unconditionally.  Entries are keyed by storage address + shape, so the
+    per-step views of a fused parameter (``in_proj_weight[:C]``) map to one entry; an entry no ``get`` has asked for during two
+    steps is dropped (its parameter is gone or has moved).  ``SGC_TRAIN_PACK_BATCH=0`` restores the pack-per-use form."""
+
+    def __init__(self):
+        self.entries = {}          # (data_ptr, shape, transpose, flip, pad_rows, pad_cols) -> dict
+        self.plans = None          # per device: (entries, launch plan)
+        self.enabled = os.environ.get("SGC_TRAIN_PACK_BATCH", "1") != "0"
+        self.launches = 0          # batched launches so far (tests)
+        self.step = 0
+
+    def get(self, weight, transpose=False, flip=False, pad_rows=1, pad_cols=1):
+        ops = ext.ops()
+        if not self.enabled or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
+            return ops.pack_conv_weight(weight.detach().float(), transpose=transpose, flip=flip, pad_rows=pad_rows, pad_cols=pad_cols)
+        key = (weight.data_ptr(), weight.shape, transpose, flip, pad_rows, pad_cols)
+        e = self.entries.get(key)
+        if e is None:
+            shape = ops.packed_shape(weight.shape, transpose, pad_rows, pad_cols)
+            hi = torch.zeros(shape, dtype=torch.bfloat16, device=weight.device)
+            lo = torch.zeros_like(hi)
+            w = weight.detach()                        # an alias: keeps the storage where it is, shares the version counter
+            ops.pack_conv_weight(w, transpose=transpose, flip=flip, pad_rows=pad_rows, pad_cols=pad_cols, out=(hi, lo))
+            self.entries[key] = dict(w=w, hi=hi, lo=lo, version=w._version, transpose=bool(transpose), flip=bool(flip), used=self.step)
+            self.plans = None
+            return hi, lo
+        e["used"] = self.step
+        if e["version"] != weight._version:
+            self.repack()
+        return e["hi"], e["lo"]
+
+    def repack(self):
+        """One launch per device over every registered plane pair."""
+        if self.plans is None:
+            by_dev = {}
+            for e in self.entries.values():
+                by_dev.setdefault(e["hi"].device, []).append(e)
+            ops = ext.ops()
+            self.plans = [(es, ops.pack_conv_weight_plan([(e["w"], e["hi"], e["lo"], e["transpose"], e["flip"]) for e in es]))
+                          for es in by_dev.values()]
+        for es, plan in self.plans:
+            ext.ops().run_pack_plan(plan)
+            self.launches += 1
+            for e in es:
+                e["version"] = e["w"]._version
+
+    def begin_step(self):
+        if not self.enabled or not self.entries:
+            return
+        self.step += 1
+        stale = [k for k, e in self.entries.items() if e["used"] < self.step - 2]
+        for k in stale:
+            del self.entries[k]
+        if stale:
+            self.plans = None
+        if self.entries:
+            self.repack()
+
+    def clear(self):
+        self.entries, self.plans = {}, None
+
+
+_TRAIN_PLANES = TrainWeightPlanes()
+
+
+def train_weight_planes():
+    return _TRAIN_PLANES
+
+
 class NchwToRowsFunction(Function):
     """[N, C, h, w] map (any strides: the crop view of AdaptiveSparseHead.py:58-59) -> channels-last rows [N, h*w, C]
     (TU/transformer.py:151-170 ``flatten(2).permute``) with the transpose on the HIP kernels in both directions: forward
@@ -188,7 +269,7 @@ class ChannelsLastConv3dFunction(Function):
         ops = ext.ops()
         cout, cin = weight.shape[:2]
         # parameter [Cout, Cin, k, k, k] -> the kernel's [taps, Cout (multiple of 4), Cin] bf16 hi / lo planes in ONE launch
-        hi, lo = ops.pack_conv_weight(weight.detach().float(), pad_rows=4)
+        hi, lo = _TRAIN_PLANES.get(weight, pad_rows=4)
         x = x.float().contiguous()
         y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, ksize, stride)
         ctx.save_for_backward(x, weight)
@@ -207,7 +288,7 @@ class ChannelsLastConv3dFunction(Function):
         if ctx.needs_input_grad[0]:
             # dx[i] = sum_d dy[(i - d + pad) / stride] W[d]^T: a stride-1 convolution of (zero-interleaved) dy with the
             # mirrored taps; its "input channels" are Cout, padded to the kernel's multiple of 32
-            hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True, flip=True, pad_cols=32)
+            hi, lo = _TRAIN_PLANES.get(weight, transpose=True, flip=True, pad_cols=32)
             g = _pad_cols(dy, 32)
             if stride == 2:
                 up = torch.zeros((grid[0], grid[1], grid[2], g.shape[1]), dtype=torch.float32, device=dy.device)
@@ -234,7 +315,7 @@ class ChannelsLastConvTranspose3dFunction(Function):
         _require_bf16_planes("ChannelsLastConvTranspose3dFunction")
         ops = ext.ops()
         cin, cout = weight.shape[:2]
-        hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True)            # [Cin, Cout, 8] -> [8, Cout, Cin]
+        hi, lo = _TRAIN_PLANES.get(weight, transpose=True)            # [Cin, Cout, 8] -> [8, Cout, Cin]
         x = x.float().contiguous()
         y, og = ops.conv3d_cl_bf16x3(x, hi, lo, grid, 2, 2, True)
         ctx.save_for_backward(x, weight)
@@ -251,7 +332,7 @@ class ChannelsLastConvTranspose3dFunction(Function):
         dy = dy.float().contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            hi, lo = ops.pack_conv_weight(weight.detach().float())                        # [Cin, Cout, 8] -> [8, Cin, Cout]
+            hi, lo = _TRAIN_PLANES.get(weight)                        # [Cin, Cout, 8] -> [8, Cin, Cout]
             dx, _ = ops.conv3d_cl_bf16x3(dy, hi, lo, og, 2, 2)                  # dx[x] = sum_p dy[2x + p] W[:, :, p]^T
         if ctx.needs_input_grad[1]:
             dwk = ops.conv3d_wgrad_bf16x3(dy, x, og, 2, 2)                      # [8, cin, cout]
@@ -293,7 +374,7 @@ class LinearRowsFunction(Function):
         ops = ext.ops()
         cout, cin = weight.shape
         x = x.float().contiguous()
-        hi, lo = ops.pack_conv_weight(weight.detach().float(), pad_rows=4)            # [1, Cout (multiple of 4), Cin]
+        hi, lo = _TRAIN_PLANES.get(weight, pad_rows=4)            # [1, Cout (multiple of 4), Cin]
         shift = None if bias is None else _pad_cols(bias.detach().float().view(1, -1), 4).view(-1).contiguous()
         y = ops.linear_rows_bf16x3(x, hi, lo, shift)
         ctx.save_for_backward(x, weight)
@@ -309,7 +390,7 @@ class LinearRowsFunction(Function):
         dy = dy.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            hi, lo = ops.pack_conv_weight(weight.detach().float(), transpose=True, pad_cols=32)   # [1, Cin, Cout -> mult of 32]: dx = dy @ W
+            hi, lo = _TRAIN_PLANES.get(weight, transpose=True, pad_cols=32)   # [1, Cin, Cout -> mult of 32]: dx = dy @ W
             dx = ops.linear_rows_bf16x3(_pad_cols(dy, 32).contiguous(), hi, lo, None)
         if ctx.needs_input_grad[1]:
             dwk = ops.conv3d_wgrad_bf16x3(x, _pad_cols(dy, 4).contiguous(), (x.shape[0], 1, 1), 1, 1)     # [1, cout_p, cin]

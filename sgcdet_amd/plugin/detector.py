@@ -85,6 +85,10 @@ class SGCDet(nn.Module):
         return volume, valid, dpt_dist, occ
 
     def build_volume_from_features(self, x, img_metas, dpt_dist):
+        if self.training and torch.is_grad_enabled():
+            # a training step begins: every weight plane the HIP training Functions have registered is repacked in ONE launch
+            from ..functions import train_weight_planes
+            train_weight_planes().begin_step()
         volume, valid, occ = self.voxel_head(x, img_metas[0], self.depth_pyramid(dpt_dist))
         if valid is None:
             _, _, vh, vw, vz = volume.shape

@@ -469,11 +469,21 @@ class DeformCrossAttention_DFA3D(BaseModule):
         from ..functions import PairListDeformAttnFunction
         C = self.embed_dims
         N, Nq = mask.shape
-        cam, q = mask.nonzero(as_tuple=True)                         # camera-major, ascending query: the pair list
-        n_pairs = cam.shape[0]
         da = self.deformable_attention
         M, L, P = da.num_heads, da.num_levels, da.num_points
         S = feat.shape[1]
+        value = None
+        if self.deformable_attn:
+            # issued BEFORE the host syncs below: the value projection depends on the maps only, and its ~140 us of GPU work (config 2)
+            # run while the host waits for the pair count and issues what follows
+            from ..functions import linear_rows                    # the Linears' three passes on the MFMA kernels
+            value = linear_rows(da.value_proj, feat).view(N, S, M, C // M)
+        # the two data-dependent sizes of the level, read back to back: the second `nonzero` used to sit behind the gathers and
+        # Linears below and drained the queue a second time (the GPU then idles until the host has issued the rest of the level)
+        cam, q = mask.nonzero(as_tuple=True)                         # camera-major, ascending query: the pair list
+        count = mask.sum(0)
+        valid_index = count.nonzero()[:, 0]
+        n_pairs = cam.shape[0]
         shapes3 = da.get_spatial_shape_3D(spatial_shapes, dist.shape[-1])
         ref = ref_cam[cam, q]                                          # [n_pairs, 3]
         item = cam.to(torch.int32)
@@ -482,8 +492,6 @@ class DeformCrossAttention_DFA3D(BaseModule):
                                                if L > 1 else ref.view(n_pairs, 1, 1, 1, 3),
                                                torch.ones((n_pairs, 1, L, 1), dtype=feat.dtype, device=feat.device), item)
         if self.deformable_attn:
-            from ..functions import linear_rows                    # the Linears' three passes on the MFMA kernels
-            value = linear_rows(da.value_proj, feat).view(N, S, M, C // M)
             off_uv = linear_rows(da.sampling_offsets, geo).view(n_pairs, M, L, P, 2)
             off_d = (geo.new_zeros((n_pairs, M, L, P, 1)) if isinstance(da.sampling_offsets_depth, _ZeroLinear)
                      else linear_rows(da.sampling_offsets_depth, geo).view(n_pairs, M, L, P, 1))
@@ -495,8 +503,6 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 per_pair = per_pair + geo
         else:
             per_pair = geo
-        count = mask.sum(0)
-        valid_index = count.nonzero()[:, 0]
         from .conv_plan import TRAIN_CONV
         if TRAIN_CONV == "hip" and C % 32 == 0:
             # inter-view aggregation on the pair list as well: no dense [N, L, C] slots (262 MB at config 2), K/V in-projected

@@ -710,21 +710,61 @@ class TensorOps:
                    _meta=dict(V=rows, Cin=Cin, Cout=Cout, taps=taps, OV=rows))
         return y
 
-    def pack_conv_weight(self, w, transpose=False, flip=False, pad_rows=1, pad_cols=1):
+    def pack_conv_weight(self, w, transpose=False, flip=False, pad_rows=1, pad_cols=1, out=None):
         """Module parameter [A, B, *taps] (Conv3d [Cout, Cin, k, k, k], ConvTranspose3d [Cin, Cout, 2, 2, 2], Linear [Cout, Cin])
         -> (hi, lo) bf16 [T, R, C] in the kernels' layout: rows = A (or B with ``transpose``), taps mirrored with ``flip``,
-        R / C zero-padded to multiples of ``pad_rows`` / ``pad_cols`` (``sgc_pack_conv_weight``)."""
+        R / C zero-padded to multiples of ``pad_rows`` / ``pad_cols`` (``sgc_pack_conv_weight``).  ``out`` = (hi, lo) to fill."""
         self._check(w=w)
         self._f32(w=w)
         w = w.contiguous()
+        T, R, Cc = self.packed_shape(w.shape, transpose, pad_rows, pad_cols)
         A, B = w.shape[0], w.shape[1]
-        T = w.numel() // (A * B)
-        rows, cols = (B, A) if transpose else (A, B)
-        R, Cc = -(-rows // pad_rows) * pad_rows, -(-cols // pad_cols) * pad_cols
-        hi = torch.empty((T, R, Cc), dtype=torch.bfloat16, device=w.device)
-        lo = torch.empty_like(hi)
+        if out is None:
+            hi = torch.empty((T, R, Cc), dtype=torch.bfloat16, device=w.device)
+            lo = torch.empty_like(hi)
+        else:
+            hi, lo = out
+            if any(t.shape != (T, R, Cc) or t.dtype != torch.bfloat16 or not t.is_contiguous() or t.device != w.device for t in out):
+                raise RuntimeError("pack_conv_weight: `out` must be two contiguous bfloat16 [T, R, C] tensors on the parameter's device")
         self._call("sgc_pack_conv_weight", w, hi, lo, A, B, T, R, Cc, int(bool(transpose)), int(bool(flip)))
         return hi, lo
+
+    @staticmethod
+    def packed_shape(wshape, transpose=False, pad_rows=1, pad_cols=1):
+        """(T, R, C) of the planes ``pack_conv_weight`` makes of a parameter of shape ``wshape``."""
+        A, B = wshape[0], wshape[1]
+        T = 1
+        for d in wshape[2:]:
+            T *= d
+        rows, cols = (B, A) if transpose else (A, B)
+        return T, -(-rows // pad_rows) * pad_rows, -(-cols // pad_cols) * pad_cols
+
+    def pack_conv_weight_plan(self, entries):
+        """The launch plan of ``sgc_pack_conv_weight_batch`` for ``entries`` = [(w, hi, lo, transpose, flip), ...] (the planes keep
+        their zero padding: allocate them with ``torch.zeros``): the device item list + counts, valid for as long as those tensors
+        stay where they are.  ``run_pack_plan(plan)`` repacks all of them in ONE launch."""
+        import struct
+        if not entries:
+            return None
+        total, max_t, blob = 0, 1, b""
+        for w, hi, lo, transpose, flip in entries:
+            self._check(w=w, hi=hi, lo=lo)
+            self._f32(w=w)
+            A, B = w.shape[0], w.shape[1]
+            T, R, Cc = hi.shape
+            if (not w.is_contiguous() or w.numel() != A * B * T or hi.shape != lo.shape or hi.dtype != torch.bfloat16 or lo.dtype != torch.bfloat16
+                    or R < (B if transpose else A) or Cc < (A if transpose else B) or not hi.is_contiguous() or not lo.is_contiguous()):
+                raise RuntimeError("pack_conv_weight_plan: inconsistent entry")
+            nb = int(self.lib._dll.sgc_pack_conv_weight_blocks(A, B, T, int(bool(transpose))))
+            blob += struct.pack("<QQQ10i", w.data_ptr(), hi.data_ptr(), lo.data_ptr(), A, B, T, R, Cc, int(bool(transpose)), int(bool(flip)), total, 0, 0)
+            total += nb
+            max_t = max(max_t, T)
+        items = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(entries[0][0].device)
+        return items, len(entries), total, max_t
+
+    def run_pack_plan(self, plan):
+        if plan is not None:
+            self._call("sgc_pack_conv_weight_batch", *plan)
 
     def unpack_conv_wgrad(self, dw_trc, shape, transpose=False, flip=False):
         """[T, R, C] fp32 (``conv3d_wgrad_bf16x3``) -> the parameter's layout ``shape`` = [A, B, *taps] (``sgc_unpack_conv_wgrad``)."""

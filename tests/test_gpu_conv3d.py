@@ -466,6 +466,76 @@ def test_weight_pack_and_unpack_equal_their_torch_formulation(shape, oracle_ops,
             assert torch.equal(back.cpu(), w), (transpose, flip, dev)
 
 
+def test_batched_weight_pack_is_the_single_pack(oracle_ops, gpu_ops):
+    """sgc_pack_conv_weight_batch (every parameter of a training step in one launch) writes, per item, the bits of
+    sgc_pack_conv_weight -- ragged shapes, all four forms, 27 / 8 / 1 taps in one list; the padding of the planes stays as
+    allocated (zero); the oracle's batch twin agrees."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(96, 64, 27), (70, 33, 27), (64, 128, 8), (130, 256, 1), (28, 128, 27), (256, 256, 27), (8, 8, 1), (33, 7, 8)]
+    forms = ((False, False, 4, 1), (True, True, 1, 32), (True, False, 1, 1), (False, False, 1, 32))
+    for ops, dev in ((gpu_ops, "cuda"), (oracle_ops, "cpu")):
+        entries, want = [], []
+        for i, shp in enumerate(shapes):
+            w = torch.randn(*shp, generator=g).to(dev)
+            for transpose, flip, pr, pc in (forms[i % 4], forms[(i + 1) % 4]):
+                T, R, C = ops.packed_shape(shp, transpose, pr, pc)
+                hi = torch.zeros(T, R, C, dtype=torch.bfloat16, device=dev)
+                lo = torch.zeros_like(hi)
+                entries.append((w, hi, lo, transpose, flip))
+                want.append(ops.pack_conv_weight(w, transpose=transpose, flip=flip, pad_rows=pr, pad_cols=pc))
+        plan = ops.pack_conv_weight_plan(entries)
+        ops.run_pack_plan(plan)
+        for (w, hi, lo, transpose, flip), (whi, wlo) in zip(entries, want):
+            assert torch.equal(hi.view(torch.int16), whi.view(torch.int16)) and torch.equal(lo.view(torch.int16), wlo.view(torch.int16)), (tuple(w.shape), transpose, flip, dev)
+        for w, *_ in entries:                          # new values, same storage: the plan is reusable
+            w.mul_(1.5)
+        ops.run_pack_plan(plan)
+        w, hi, lo, transpose, flip = entries[3]
+        T, R, C = hi.shape
+        again = ops.pack_conv_weight(w, transpose=transpose, flip=flip, pad_rows=R if R > 1 else 1, pad_cols=C if C > 1 else 1)
+        assert torch.equal(hi.view(torch.int16), again[0].view(torch.int16)) and torch.equal(lo.view(torch.int16), again[1].view(torch.int16))
+
+
+def test_train_weight_planes_repack_once_per_step_and_never_serve_stale():
+    """functions.TrainWeightPlanes: planes are registered on first use, `begin_step` repacks all of them in one launch, an in-place
+    update of a parameter between `begin_step` and the use is seen (version counter), per-step views of one parameter share an
+    entry, a parameter that moved gets new planes and the entry of its old storage is dropped after two unused steps."""
+    from sgcdet_amd import ext
+    from sgcdet_amd.functions import TrainWeightPlanes
+    ops = ext.ops()
+    tp = TrainWeightPlanes()
+    ws = [torch.nn.Parameter(torch.randn(64, 32, 3, 3, 3, device="cuda")), torch.nn.Parameter(torch.randn(120, 96, device="cuda"))]
+    same = lambda a, b: all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(a, b))   # noqa: E731
+    fresh = lambda w, **kw: ops.pack_conv_weight(w.detach(), **kw)                                         # noqa: E731
+    forms = [dict(pad_rows=4), dict(transpose=True, flip=True, pad_cols=32)]
+    for w in ws:
+        for kw in forms:
+            assert same(tp.get(w, **kw), fresh(w, **kw))
+    assert same(tp.get(ws[1][40:80], **forms[0]), fresh(ws[1][40:80], **forms[0]))       # a view (in_proj_weight[C:2C])
+    assert tp.launches == 0 and len(tp.entries) == 5
+    with torch.no_grad():
+        for w in ws:
+            w.add_(1.0)                                # an optimizer step
+    tp.begin_step()
+    assert tp.launches == 1
+    for w in ws:
+        for kw in forms:
+            assert same(tp.get(w, **kw), fresh(w, **kw))
+    assert same(tp.get(ws[1][40:80], **forms[0]), fresh(ws[1][40:80], **forms[0]))       # a NEW view object, the same entry
+    assert tp.launches == 1 and len(tp.entries) == 5   # all served from the batch
+    with torch.no_grad():
+        ws[0].mul_(0.5)                                # changed after begin_step: the version counter catches it
+    assert same(tp.get(ws[0], **forms[0]), fresh(ws[0], **forms[0])) and tp.launches == 2
+    ws[1].data = ws[1].data.clone()                    # the parameter moved: new planes, the plan is rebuilt
+    assert same(tp.get(ws[1], **forms[1]), fresh(ws[1], **forms[1])) and len(tp.entries) == 6
+    for _ in range(4):
+        tp.begin_step()
+        assert same(tp.get(ws[1], **forms[1]), fresh(ws[1], **forms[1]))
+    assert len(tp.entries) == 1                        # everything not asked for during two steps is gone
+    hi, lo = tp.get(ws[1], **forms[1])
+    assert hi.shape[2] == 128 and not hi[:, :, 120:].any()        # the zero padding of the planes survives the batch
+
+
 @pytest.mark.parametrize("cin,cout,grid,k,s,tr", [(64, 128, (8, 8, 8), 3, 2, False), (128, 256, (10, 10, 4), 3, 1, False),
                                                   (512, 128, (8, 8, 4), 2, 2, True), (96, 192, (13, 7, 5), 3, 2, False)])
 def test_tile_kernel_options_are_bit_identical(cin, cout, grid, k, s, tr, oracle_ops, gpu_ops):

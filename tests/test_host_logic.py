@@ -294,3 +294,21 @@ def test_dense_head_flat_tag_follows_the_content_not_the_move():
     assert not valid_tag(head.vox_coords)                  # ... and the move must not re-assert "flat"
     assert enc._coords_are_flat(head.vox_coords) is False  # one host check of the loaded content
     assert valid_tag(head.vox_coords) and head.vox_coords._sgc_flat[1] is False
+
+
+def test_oracle_batched_weight_pack_is_its_single_pack(oracle_ops):
+    """The CPU twin of sgc_pack_conv_weight_batch (host item list, same 64-byte sgc_pack_item) == sgc_pack_conv_weight per item;
+    the GPU comparison is tests/test_gpu_conv3d.py::test_batched_weight_pack_is_the_single_pack."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    entries, want = [], []
+    for shp, (transpose, flip, pr, pc) in (((12, 7, 27), (False, False, 4, 1)), ((12, 7, 27), (True, True, 1, 32)), ((9, 40, 1), (True, False, 1, 32)),
+                                           ((16, 8, 8), (False, False, 1, 1))):
+        w = torch.randn(*shp, generator=g)
+        T, R, C = oracle_ops.packed_shape(shp, transpose, pr, pc)
+        hi = torch.zeros(T, R, C, dtype=torch.bfloat16)
+        entries.append((w, hi, torch.zeros_like(hi), transpose, flip))
+        want.append(oracle_ops.pack_conv_weight(w, transpose=transpose, flip=flip, pad_rows=pr, pad_cols=pc))
+    oracle_ops.run_pack_plan(oracle_ops.pack_conv_weight_plan(entries))
+    for (w, hi, lo, *_), (whi, wlo) in zip(entries, want):
+        assert torch.equal(hi.view(torch.int16), whi.view(torch.int16)) and torch.equal(lo.view(torch.int16), wlo.view(torch.int16))
