@@ -10,6 +10,9 @@
 //                           forms each: forward and input-gradient layout), most of them a few microseconds of work -- 96 launches
 //                           were 1.2 ms of device time and 2.2 ms of wall per config-2 step (the host could not keep the GPU fed:
 //                           tools/trace_gaps.py); the batch moves the same bytes in one launch at the rate of the large layers.
+// (Summing the weight gradient's split slabs inside the unpack pass -- one launch and one HBM round trip of the gradient less per
+//  layer -- was built, bit-identical, and is slower: the unpack kernel holds a 110-KB block per CU and reads each slab at a fraction of
+//  the rate of the streaming reduce kernel it replaces: 0.72 + 0.39 ms against 0.31 + 0.51 ms per config-2 step.)
 //
 // In round 2 these were torch ops per layer and per pass (permute + contiguous: an uncoalesced strided copy of up to 113 MB;
 // then to(bfloat16), subtract, to(bfloat16) for the split): 3.5 ms of strided copies + 1.4 ms of conversion kernels per
@@ -44,10 +47,40 @@ __device__ __forceinline__ void pack_block(const PackParams &p, int bx, int by) 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // load: for every a of the block the run [b0, b0 + PB) x T is contiguous in w; a wave takes whole runs
   const int nvalid_b = (p.B - b0 < PB ? p.B - b0 : PB) * T;
-  for (int a = wid; a < PA; a += 4) {
-    const int nvalid = a0 + a < p.A ? nvalid_b : 0;
-    const float *wrow = p.w + ((int64_t)(a0 + a) * p.B + b0) * T;
-    for (int i = lane; i < run; i += 64) pk_lds[a * pitch + i] = i < nvalid ? wrow[i] : 0.f;
+  if ((((int64_t)p.B * T) & 3) == 0 && ((uintptr_t)p.w & 15) == 0) {
+    // 16-byte loads, four in flight per thread (round 5: with 4-byte loads one wave kept 256 bytes in flight per instruction and the
+    // batch kernel moved 2 TB/s); run = PB * T is a multiple of 8, a row starts on a 16-byte boundary
+    const int r4 = run >> 2, total4 = PA * r4;
+    for (int base = tid; base < total4; base += 256 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = base + 256 * k;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < total4) {
+          const int a = e / r4, i = (e - a * r4) * 4;
+          const int nvalid = a0 + a < p.A ? nvalid_b : 0;
+          const float *src = p.w + ((int64_t)(a0 + a) * p.B + b0) * T + i;
+          if (i + 3 < nvalid) v[k] = *reinterpret_cast<const float4 *>(src);
+          else if (i < nvalid) { v[k].x = src[0]; if (i + 1 < nvalid) v[k].y = src[1]; if (i + 2 < nvalid) v[k].z = src[2]; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = base + 256 * k;
+        if (e < total4) {
+          const int a = e / r4, i = (e - a * r4) * 4;
+          float *d = pk_lds + a * pitch + i;
+          d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+      }
+    }
+  } else {
+    for (int a = wid; a < PA; a += 4) {
+      const int nvalid = a0 + a < p.A ? nvalid_b : 0;
+      const float *wrow = p.w + ((int64_t)(a0 + a) * p.B + b0) * T;
+      for (int i = lane; i < run; i += 64) pk_lds[a * pitch + i] = i < nvalid ? wrow[i] : 0.f;
+    }
   }
   __syncthreads();
   // store: units of 8 consecutive c of one (t, r): 16-byte hi and lo stores, the 4 units of a 32-column row segment on 4 lanes
