@@ -364,6 +364,7 @@ extern int g_tune_halo_stagger;
 extern int g_tune_halo_small;
 extern int g_tune_wgrad_halo;
 extern int g_tune_view_group;
+extern int g_tune_pq_depth;         // view_pool.hip
 extern int g_tune_halo_wave_fix;     // conv3d.hip
 extern int g_tune_compact2;          // project.hip: two-launch segment form of sgc_compact_pairs
 extern int g_tune_halo_narrow;
@@ -553,6 +554,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "halo_small")) { g_tune_halo_small = value; return SGC_OK; }
   if (!strcmp(key, "wgrad_halo")) { g_tune_wgrad_halo = value; return SGC_OK; }
   if (!strcmp(key, "view_group")) { g_tune_view_group = value; return SGC_OK; }
+  if (!strcmp(key, "view_depth")) { g_tune_pq_depth = value; return SGC_OK; }
   if (!strcmp(key, "compact2")) { g_tune_compact2 = value; return SGC_OK; }
   if (!strcmp(key, "halo_wave_fix")) { g_tune_halo_wave_fix = value; return SGC_OK; }
   if (!strcmp(key, "halo_narrow")) { g_tune_halo_narrow = value; return SGC_OK; }

@@ -8,6 +8,8 @@
 
 namespace sgc {
 
+int g_tune_pq_depth = 4;      // knob view_depth: pair rows in flight per lane in view_attend_pq_kernel (1 | 2 | 4 | 8) and in the
+                               // group kernels of view_mean / view_attend (>= 4: four, else one) -- A/B; results identical
 int g_tune_view_group = 1;     // 0: the per-camera loops of rounds 1-2 in view_mean / view_attend (A/B; results identical)
 
 // mean over the cameras that see voxel valid_index[i]; C/4 lanes per voxel (float4 rows)
@@ -15,7 +17,7 @@ int g_tune_view_group = 1;     // 0: the per-camera loops of rounds 1-2 in view_
 // 32 / 64 cameras at a time with ONE load per lane, and walks only the visible cameras (ballot + shuffle), with the next
 // camera's row requested before the current one is added -- instead of one dependent slot load per camera (28 of config 2's 40
 // cameras do not see a voxel) followed by a dependent row load.  Same cameras in the same order, same sums: bit-identical.
-template <int LG>
+template <int LG, int PD = 4>
 __global__ __launch_bounds__(256) void view_mean_group_kernel(const float *__restrict__ feat, const int32_t *__restrict__ slot,
                                                               const int32_t *__restrict__ valid_index, float *__restrict__ mean,
                                                               int N, int Nq, int n_valid, const int32_t *__restrict__ n_dev) {
@@ -34,21 +36,32 @@ __global__ __launch_bounds__(256) void view_mean_group_kernel(const float *__res
       unsigned long long m = __ballot(pl >= 0);
       if (LG == 32) m = (m >> gbase) & 0xffffffffull;
       if (!m) continue;
-      int p = __shfl(pl, gbase + __builtin_ctzll(m));
-      float4 v = reinterpret_cast<const float4 *>(feat + (int64_t)p * C)[gl];
-      m &= m - 1;
-      while (true) {
-        float4 vn = v;
-        const bool more = m != 0;
-        if (more) {
+      // PD rows in flight per lane (round 5; one row ahead left the kernel a chain of dependent loads): r[k] holds the row of the
+      // (j0 + k)-th visible camera, refilled with the row PD cameras later as soon as it has been added.  Same order, same sums.
+      const int nvis = __popcll(m);
+      float4 r[PD];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m) {
           const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
-          vn = reinterpret_cast<const float4 *>(feat + (int64_t)pn * C)[gl];
           m &= m - 1;
+          r[k] = reinterpret_cast<const float4 *>(feat + (int64_t)pn * C)[gl];
         }
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        ++cnt;
-        if (!more) break;
-        v = vn;
+      }
+      for (int j0 = 0; j0 < nvis; j0 += PD) {
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+          if (j0 + k >= nvis) break;
+          const float4 v = r[k];
+          if (m) {
+            const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
+            m &= m - 1;
+            r[k] = reinterpret_cast<const float4 *>(feat + (int64_t)pn * C)[gl];
+          }
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          ++cnt;
+        }
       }
     }
     if (live) {
@@ -108,7 +121,7 @@ __global__ void view_mean_scalar_kernel(const float *__restrict__ feat, const in
 // column comes in with one load per lane, only the visible cameras are walked, and the next camera's k | v row is requested
 // before the current one enters the online softmax (see view_mean_group_kernel).  Same cameras, same order, same arithmetic as
 // the generic kernel below: bit-identical.
-template <int LG>
+template <int LG, int PD = 4>
 __global__ __launch_bounds__(256) void view_attend_group_kernel(const float *__restrict__ q, const float *__restrict__ kv,
                                                                 const int32_t *__restrict__ slot,
                                                                 const int32_t *__restrict__ valid_index, float *__restrict__ ctx,
@@ -134,33 +147,43 @@ __global__ __launch_bounds__(256) void view_attend_group_kernel(const float *__r
       unsigned long long m = __ballot(pl >= 0);
       if (LG == 32) m = (m >> gbase) & 0xffffffffull;
       if (!m) continue;
-      int p = __shfl(pl, gbase + __builtin_ctzll(m));
-      m &= m - 1;
-      float4 k4 = *reinterpret_cast<const float4 *>(kv + (int64_t)p * 2 * C + c0);
-      float4 v4 = *reinterpret_cast<const float4 *>(kv + (int64_t)p * 2 * C + C + c0);
-      while (true) {
-        float4 kn = k4, vn = v4;
-        const bool more = m != 0;
-        if (more) {
+      // PD k | v rows in flight per lane (see view_mean_group_kernel)
+      const int nvis = __popcll(m);
+      float4 rk[PD], rv[PD];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+        rk[k] = rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m) {
           const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
           m &= m - 1;
-          kn = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + c0);
-          vn = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + C + c0);
+          rk[k] = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + c0);
+          rv[k] = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + C + c0);
         }
-        const float kx[4] = {k4.x, k4.y, k4.z, k4.w}, vx[4] = {v4.x, v4.y, v4.z, v4.w};
-        float d = 0.f;
+      }
+      for (int j0 = 0; j0 < nvis; j0 += PD) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) d += qv[v] * kx[v];
-        for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
-        const float nm = fmaxf(mx, d);
-        const float corr = expf(mx - nm);
-        const float e = expf(d - nm);
-        sum = sum * corr + e;
+        for (int k = 0; k < PD; ++k) {
+          if (j0 + k >= nvis) break;
+          const float4 k4 = rk[k], v4 = rv[k];
+          if (m) {
+            const int pn = __shfl(pl, gbase + __builtin_ctzll(m));
+            m &= m - 1;
+            rk[k] = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + c0);
+            rv[k] = *reinterpret_cast<const float4 *>(kv + (int64_t)pn * 2 * C + C + c0);
+          }
+          const float kx[4] = {k4.x, k4.y, k4.z, k4.w}, vx[4] = {v4.x, v4.y, v4.z, v4.w};
+          float d = 0.f;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = acc[v] * corr + e * vx[v];
-        mx = nm;
-        if (!more) break;
-        k4 = kn; v4 = vn;
+          for (int v = 0; v < 4; ++v) d += qv[v] * kx[v];
+          for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o);
+          const float nm = fmaxf(mx, d);
+          const float corr = expf(mx - nm);
+          const float e = expf(d - nm);
+          sum = sum * corr + e;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = acc[v] * corr + e * vx[v];
+          mx = nm;
+        }
       }
     }
     if (live) *reinterpret_cast<float4 *>(ctx + (int64_t)i * C + c0) = make_float4(acc[0] / sum, acc[1] / sum, acc[2] / sum, acc[3] / sum);
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(256) void view_attend_group_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 constexpr int kPqHeads = 8, kPqMaxViews = 128;
 
-template <int LG>
+template <int LG, int PD = 4>
 __global__ __launch_bounds__(256) void view_attend_pq_kernel(const float *__restrict__ qp, const float *__restrict__ x,
                                                              const int32_t *__restrict__ slot,
                                                              const int32_t *__restrict__ valid_index, float *__restrict__ s,
@@ -229,11 +252,19 @@ __global__ __launch_bounds__(256) void view_attend_pq_kernel(const float *__rest
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS operations complete in order
     __builtin_amdgcn_wave_barrier();
     // ---- pass 1: scores ----
-    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cnt > 0) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[0] * C + gl * 4);
-    for (int j = 0; j < cnt; ++j) {
-      const float4 xv = xn;
-      if (j + 1 < cnt) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + 1] * C + gl * 4);
+    // PD pair rows in flight per lane (round 5: with one row ahead the kernel ran at a third of the HBM rate -- a chain of ~30 dependent
+    // loads per voxel -- although it issues ~170 instructions per pair): the rows of cameras j .. j + PD - 1 sit in xr[]
+    float4 xr[PD];
+#pragma unroll
+    for (int k = 0; k < PD; ++k)
+      xr[k] = k < cnt ? *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[k] * C + gl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < cnt; j0 += PD) {
+#pragma unroll
+     for (int k = 0; k < PD; ++k) {
+      const int j = j0 + k;
+      if (j >= cnt) break;
+      const float4 xv = xr[k];
+      if (j + PD < cnt) xr[k] = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + PD] * C + gl * 4);
       float v[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) v[h] = ((q[h].x * xv.x + q[h].y * xv.y) + q[h].z * xv.z) + q[h].w * xv.w;
@@ -246,6 +277,7 @@ __global__ __launch_bounds__(256) void view_attend_pq_kernel(const float *__rest
 #pragma unroll
       for (int o = 8; o < LG; o <<= 1) d += __shfl_xor(d, o);
       if (gl < 8) my_sc[j][hm] = d;
+     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -273,16 +305,23 @@ __global__ __launch_bounds__(256) void view_attend_pq_kernel(const float *__rest
     float4 acc[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cnt > 0) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[0] * C + gl * 4);
-    for (int j = 0; j < cnt; ++j) {
-      const float4 xv = xn;
-      if (j + 1 < cnt) xn = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + 1] * C + gl * 4);
+#pragma unroll
+    for (int k = 0; k < PD; ++k)
+      if (k < cnt) xr[k] = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[k] * C + gl * 4);
+    for (int j0 = 0; j0 < cnt; j0 += PD) {
+#pragma unroll
+     for (int k = 0; k < PD; ++k) {
+      const int j = j0 + k;
+      if (j >= cnt) break;
+      const float4 xv = xr[k];
+      if (j + PD < cnt) xr[k] = *reinterpret_cast<const float4 *>(x + (int64_t)my_pl[j + PD] * C + gl * 4);
       const float4 a0 = *reinterpret_cast<const float4 *>(&my_sc[j][0]), a1 = *reinterpret_cast<const float4 *>(&my_sc[j][4]);
       const float a[H] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         acc[h].x += a[h] * xv.x; acc[h].y += a[h] * xv.y; acc[h].z += a[h] * xv.z; acc[h].w += a[h] * xv.w;
       }
+     }
     }
     if (live) {
 #pragma unroll
@@ -599,11 +638,18 @@ extern "C" int sgc_view_mean(const float *feat, const int32_t *slot, const int32
   if (!feat || !slot || !valid_index || !mean) return set_error(SGC_EINVAL, "sgc_view_mean: null pointer");
   if (n_valid <= 0) return SGC_OK;
   const bool al16 = !((uintptr_t)feat & 15) && !((uintptr_t)mean & 15);
-  if (C == 256 && al16 && g_tune_view_group)
-    hipLaunchKernelGGL(view_mean_group_kernel<64>, dim3(grid_for((int64_t)n_valid * 64, 256)), dim3(256), 0,
+  const bool deep = g_tune_pq_depth >= 4;            // rows in flight per lane: 4 (default) | 1 (the round-3 form, A/B)
+  if (C == 256 && al16 && g_tune_view_group && deep)
+    hipLaunchKernelGGL((view_mean_group_kernel<64, 4>), dim3(grid_for((int64_t)n_valid * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
+  else if (C == 256 && al16 && g_tune_view_group)
+    hipLaunchKernelGGL((view_mean_group_kernel<64, 1>), dim3(grid_for((int64_t)n_valid * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
+  else if (C == 128 && al16 && g_tune_view_group && deep)
+    hipLaunchKernelGGL((view_mean_group_kernel<32, 4>), dim3(grid_for((int64_t)n_valid * 32, 256)), dim3(256), 0,
                        (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
   else if (C == 128 && al16 && g_tune_view_group)
-    hipLaunchKernelGGL(view_mean_group_kernel<32>, dim3(grid_for((int64_t)n_valid * 32, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((view_mean_group_kernel<32, 1>), dim3(grid_for((int64_t)n_valid * 32, 256)), dim3(256), 0,
                        (hipStream_t)stream, feat, slot, valid_index, mean, N, Nq, n_valid, n_dev);
   else if (C % 4 == 0 && al16)
     hipLaunchKernelGGL(view_mean_kernel, dim3(grid_for((int64_t)n_valid * (C / 4), 256)), dim3(256), 0,
@@ -629,11 +675,18 @@ extern "C" int sgc_view_attend(const float *q, const float *kv, const int32_t *s
   if (hd % 4 || (G & (G - 1)) || G > 64 || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15)) { vec = 1; G = hd; }
   if ((G & (G - 1)) || G > 64) return set_error(SGC_EUNSUP, "sgc_view_attend: head_dim %d not supported", hd);
   const int64_t work = (int64_t)n_valid * heads * G;
-  if (vec == 4 && heads * G == 64 && g_tune_view_group)
-    hipLaunchKernelGGL(view_attend_group_kernel<64>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+  const bool deep = g_tune_pq_depth >= 4;
+  if (vec == 4 && heads * G == 64 && g_tune_view_group && deep)
+    hipLaunchKernelGGL((view_attend_group_kernel<64, 4>), dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
+  else if (vec == 4 && heads * G == 64 && g_tune_view_group)
+    hipLaunchKernelGGL((view_attend_group_kernel<64, 1>), dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+                       slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
+  else if (vec == 4 && heads * G == 32 && g_tune_view_group && deep)
+    hipLaunchKernelGGL((view_attend_group_kernel<32, 4>), dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
                        slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
   else if (vec == 4 && heads * G == 32 && g_tune_view_group)
-    hipLaunchKernelGGL(view_attend_group_kernel<32>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
+    hipLaunchKernelGGL((view_attend_group_kernel<32, 1>), dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
                        slot, valid_index, ctx, N, Nq, heads, n_valid, scale, n_dev);
   else if (vec == 4)
     hipLaunchKernelGGL(view_attend_kernel<4>, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, q, kv,
@@ -654,15 +707,16 @@ extern "C" int sgc_view_attend_pq(const float *qp, const float *x, const int32_t
   if (((uintptr_t)qp | (uintptr_t)x | (uintptr_t)s) & 15) return set_error(SGC_EINVAL, "sgc_view_attend_pq: pointers must be 16-byte aligned");
   if (n_valid <= 0) return SGC_OK;
   hipStream_t st = (hipStream_t)stream;
+  const int gpb = C == 256 ? 4 : 8;                                    // voxel groups per block
+  const dim3 grid((unsigned)std::min<int64_t>(((int64_t)n_valid + gpb - 1) / gpb, 256 * 16));
+#define SGC_PQ_LAUNCH(LG, PD) hipLaunchKernelGGL((view_attend_pq_kernel<LG, PD>), grid, dim3(256), 0, st, qp, x, slot, valid_index, s, N, Nq, n_valid, n_valid_dev_or_null)
+  const int pd = g_tune_pq_depth;
   if (C == 256) {
-    const int groups_per_block = 4;
-    const int grid = (int)std::min<int64_t>(((int64_t)n_valid + groups_per_block - 1) / groups_per_block, 256 * 16);
-    hipLaunchKernelGGL(view_attend_pq_kernel<64>, dim3(grid), dim3(256), 0, st, qp, x, slot, valid_index, s, N, Nq, n_valid, n_valid_dev_or_null);
+    if (pd >= 8) SGC_PQ_LAUNCH(64, 8); else if (pd >= 4) SGC_PQ_LAUNCH(64, 4); else if (pd >= 2) SGC_PQ_LAUNCH(64, 2); else SGC_PQ_LAUNCH(64, 1);
   } else {
-    const int groups_per_block = 8;
-    const int grid = (int)std::min<int64_t>(((int64_t)n_valid + groups_per_block - 1) / groups_per_block, 256 * 16);
-    hipLaunchKernelGGL(view_attend_pq_kernel<32>, dim3(grid), dim3(256), 0, st, qp, x, slot, valid_index, s, N, Nq, n_valid, n_valid_dev_or_null);
+    if (pd >= 8) SGC_PQ_LAUNCH(32, 8); else if (pd >= 4) SGC_PQ_LAUNCH(32, 4); else if (pd >= 2) SGC_PQ_LAUNCH(32, 2); else SGC_PQ_LAUNCH(32, 1);
   }
+#undef SGC_PQ_LAUNCH
   return check_launch("view_attend_pq_kernel");
 }
 
