@@ -661,8 +661,10 @@ def test_scene_graph_with_fresh_input_buffers_falls_back_to_copies():
     torch.manual_seed(3)
     det = build_detector(model_config(w)).eval().cuda()
     det.scene_graph_capacity = 2
+    keep = []                # the earlier scenes stay alive: a NEW address set every scene whatever the caching allocator would recycle
     for s in range(6):
         feats, dpt, meta = make_scene(4, w["embed_dims"], kind=w["kind"], seed=90 + s, device="cuda")   # new tensors
+        keep.append((feats, dpt))
         with torch.no_grad():
             det.scene_graph, det.use_graph = False, False
             want = det.forward_features(feats, [meta], dpt)

@@ -10,6 +10,7 @@ timeout 600 python bench.py --workload cfg3_arkit --no-cpu-baseline > gpurun_out
 timeout 600 python bench.py --workload cfg4_scannet200_large --no-cpu-baseline > gpurun_out/r05_bench_cfg4.json 2>/dev/null; echo cfg4 rc $?
 timeout 600 python bench.py --workload cfg5_arkit_large --no-cpu-baseline > gpurun_out/r05_bench_cfg5.json 2>/dev/null; echo cfg5 rc $?
 timeout 600 python bench.py --input-layout nhwc --no-cpu-baseline > gpurun_out/r05_bench_cfg2_nhwc.json 2>/dev/null; echo nhwc rc $?
+timeout 600 python bench.py --winograd off --no-cpu-baseline > gpurun_out/r05_bench_cfg2_direct.json 2>/dev/null; echo direct rc $?
 timeout 600 python bench.py --conv-mode f32 --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r05_bench_cfg2_f32.json 2>/dev/null; echo f32 rc $?
 timeout 600 python bench.py --conv-mode fp16 --storage bf16 --no-cpu-baseline > gpurun_out/r05_bench_cfg2_fp16_bf16maps.json 2>/dev/null; echo fp16+storage rc $?
 # per-layer tables: kernel-alone times in the geometry of the timed region (throughput) and at the latency-optimal splits
@@ -39,11 +40,13 @@ out = dict(kernel="sgc::dfa3d_fwd_tile_kernel, finest level of config 2 (tools/j
            note="FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B), WRITE_SIZE as read; separate --pmc passes")
 print(json.dumps(out, indent=1))
 PY
-timeout 600 python tools/train_step_bench.py --steps 10 --profile > gpurun_out/r05_train_step.json 2> gpurun_out/r05_train_step_kernels.raw; echo train rc $?
+timeout 600 python tools/train_step_bench.py --steps 40 2>/dev/null | tail -1 > gpurun_out/r05_train_step.json
+SGC_TRAIN_PACK_BATCH=0 timeout 600 python tools/train_step_bench.py --steps 40 2>/dev/null | tail -1 >> gpurun_out/r05_train_step.json
+timeout 600 python tools/train_step_bench.py --steps 10 --profile >> gpurun_out/r05_train_step.json 2> gpurun_out/r05_train_step_kernels.raw; echo train rc $?
 grep -v "amdgpu.ids\|warn\|Warning" gpurun_out/r05_train_step_kernels.raw | cut -c1-200 > gpurun_out/r05_train_step_kernels.txt; rm -f gpurun_out/r05_train_step_kernels.raw
 python - <<'PY'
 import json
-for n in ("cfg2", "cfg2_driver_cmd", "cfg3", "cfg4", "cfg5", "cfg2_nhwc", "cfg2_f32", "cfg2_fp16_bf16maps"):
+for n in ("cfg2", "cfg2_driver_cmd", "cfg3", "cfg4", "cfg5", "cfg2_nhwc", "cfg2_direct", "cfg2_f32", "cfg2_fp16_bf16maps"):
     try:
         d = json.loads(open(f"gpurun_out/r05_bench_{n}.json").readline())
         print(n, d["value"], d["ms_per_scene"], "gather", d["roofline"]["frac"], d["roofline"]["avg_launch_us"], "mfma", (d.get("roofline_mfma") or {}).get("frac"), (d.get("roofline_mfma") or {}).get("avg_launch_us"),
