@@ -580,6 +580,18 @@ int sgc_bn_rows_forward(const float *x, const float *weight, const float *bias, 
 int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, const float *invstd, const float *weight,
                          float *dx, float *dweight, float *dbias, float *workspace, int64_t workspace_floats, int rows,
                          int C, sgc_stream_t stream);
+/* (round 5) The same passes with the elementwise tail of the neck's blocks inside them: y = relu?(bn(x) + residual?) -- `relu(norm(conv))`
+ * and the ResBlock tail `relu(norm2(conv2) + identity)` (necks/imvoxelnet.py:36-64) -- instead of one or two more elementwise kernels per
+ * layer and pass.  Backward: the incoming gradient counts where y > 0 (y_relu_or_null = the forward's output when relu was set; torch's
+ * threshold_backward), then the plain BatchNorm backward; dresidual_or_null receives the gradient of the added identity (= the masked
+ * incoming gradient).  Same statistics, same reduction order as the plain entry points. */
+int sgc_bn_rows_act_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                            float *running_var_or_null, float momentum, float eps, const float *residual_or_null, int relu,
+                            float *y, float *mean_out, float *invstd_out, float *workspace, int64_t workspace_floats,
+                            int rows, int C, sgc_stream_t stream);
+int sgc_bn_rows_act_backward(const float *x, const float *dy, const float *y_relu_or_null, const float *mean, const float *invstd,
+                             const float *weight, float *dx, float *dweight, float *dbias, float *dresidual_or_null,
+                             float *workspace, int64_t workspace_floats, int rows, int C, sgc_stream_t stream);
 
 /* The tail of a VoxFormer level in one launch: for every voxel q of the level
  *     x0 = out_proj(ctx[row_of[q]]) if row_of[q] >= 0 else 0      (nn.MultiheadAttention.out_proj + the slot scatter,

@@ -1415,6 +1415,35 @@ int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, con
   return SGC_OK;
 }
 
+/* y = relu?(bn(x) + residual?) and its backward, restated: the plain passes above around the elementwise steps (float, as torch does them) */
+int sgc_bn_rows_act_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                            float *running_var_or_null, float momentum, float eps, const float *residual_or_null, int relu,
+                            float *y, float *mean_out, float *invstd_out, float *workspace, int64_t workspace_floats,
+                            int rows, int C, sgc_stream_t stream) {
+  const int rc = sgc_bn_rows_forward(x, weight, bias, running_mean_or_null, running_var_or_null, momentum, eps, y, mean_out, invstd_out,
+                                     workspace, workspace_floats, rows, C, stream);
+  if (rc) return rc;
+  for (int64_t i = 0; i < (int64_t)rows * C; ++i) {
+    float v = y[i];
+    if (residual_or_null) v += residual_or_null[i];
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[i] = v;
+  }
+  return SGC_OK;
+}
+int sgc_bn_rows_act_backward(const float *x, const float *dy, const float *y_relu_or_null, const float *mean, const float *invstd,
+                             const float *weight, float *dx, float *dweight, float *dbias, float *dresidual_or_null,
+                             float *workspace, int64_t workspace_floats, int rows, int C, sgc_stream_t stream) {
+  if (!dy) return fail(SGC_EINVAL, "sgc_bn_rows_act_backward: null pointer");
+  const int64_t n = (int64_t)rows * C;
+  float *g = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  for (int64_t i = 0; i < n; ++i) g[i] = (!y_relu_or_null || y_relu_or_null[i] > 0.f) ? dy[i] : 0.f;
+  if (dresidual_or_null) memcpy(dresidual_or_null, g, sizeof(float) * (size_t)n);
+  const int rc = sgc_bn_rows_backward(x, g, mean, invstd, weight, dx, dweight, dbias, workspace, workspace_floats, rows, C, stream);
+  free(g);
+  return rc;
+}
+
 int sgc_layer_norm_rows(const float *x, const float *gamma, const float *beta, float eps, float *y,
                         const int32_t *rows_dev_or_null, int rows_cap, int C, sgc_stream_t stream) {
   (void)stream;

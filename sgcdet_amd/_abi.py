@@ -54,6 +54,8 @@ SIGNATURES = {
     "sgc_layer_norm_rows": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
     "sgc_bn_rows_forward": [_p] * 5 + [_f, _f] + [_p] * 4 + [C.c_int64, _i, _i, _p],
     "sgc_bn_rows_backward": [_p] * 9 + [C.c_int64, _i, _i, _p],
+    "sgc_bn_rows_act_forward": [_p] * 5 + [_f, _f] + [_p, _i] + [_p] * 4 + [C.c_int64, _i, _i, _p],
+    "sgc_bn_rows_act_backward": [_p] * 11 + [C.c_int64, _i, _i, _p],
     "sgc_aligned_nms3d": [_p] * 3 + [_f] + [_p] * 3 + [_i] + [_p],
     "sgc_nms_rotated_bev": [_p] * 3 + [_f] + [_p] * 3 + [_i, _i] + [_p],
     "sgc_box_iou_rotated": [_p] * 3 + [_i, _i] + [_p],

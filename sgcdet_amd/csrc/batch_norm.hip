@@ -106,9 +106,11 @@ __global__ __launch_bounds__(BN_T) void bn_stats_final_kernel(const float *__res
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (rows > 1 ? Ma / (float)(rows - 1) : var);
 }
 
+// residual / relu (round 5, sgc_bn_rows_act_forward): y = relu?(bn(x) + residual?) -- the ResBlock tail `relu(norm2(conv2) + identity)` and the
+// `relu(norm(conv))` pairs of the neck (necks/imvoxelnet.py:36-64) in the normalisation pass instead of two more elementwise kernels
 __global__ __launch_bounds__(BN_T) void bn_apply_kernel(const float4 *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ invstd,
                                                         const float *__restrict__ w, const float *__restrict__ b, float4 *__restrict__ y,
-                                                        int64_t total4, int C4) {
+                                                        int64_t total4, int C4, const float4 *__restrict__ residual, int relu) {
   for (int64_t i = (int64_t)blockIdx.x * BN_T + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BN_T) {
     const int c = (int)(i % C4) * 4;
     const float4 v = x[i];
@@ -117,14 +119,17 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(const float4 *__restrict
     float4 o;
     o.x = (v.x - m.x) * s.x * ww.x + bb.x; o.y = (v.y - m.y) * s.y * ww.y + bb.y;
     o.z = (v.z - m.z) * s.z * ww.z + bb.z; o.w = (v.w - m.w) * s.w * ww.w + bb.w;
+    if (residual) { const float4 r = residual[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     y[i] = o;
   }
 }
 
 // partial sums of slab g: ws[(g * 2 + 0) * C + c] = sum dy, ws[(g * 2 + 1) * C + c] = sum dy * xhat
+// y_or_null: the forward's output when it ended in a ReLU -- the incoming gradient counts only where y > 0 (torch's threshold_backward)
 __global__ __launch_bounds__(BN_T) void bn_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mean,
                                                               const float *__restrict__ invstd, float *__restrict__ ws, int rows, int C,
-                                                              int rows_per_slab) {
+                                                              int rows_per_slab, const float *__restrict__ y_or_null) {
   extern __shared__ float bn_lds[];                    // [RL][CG * 4][2]
   const int C4 = C >> 2;
   const int CG = C4 < BN_T ? C4 : BN_T, RL = BN_T / CG;
@@ -138,7 +143,11 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_partial_kernel(const float *__res
       const float m[4] = {m4.x, m4.y, m4.z, m4.w}, is[4] = {i4.x, i4.y, i4.z, i4.w};
       for (int r = r_lo + rl; r < r_hi; r += RL) {
         const float4 v4 = *reinterpret_cast<const float4 *>(x + (int64_t)r * C + c4 * 4);
-        const float4 g4 = *reinterpret_cast<const float4 *>(dy + (int64_t)r * C + c4 * 4);
+        float4 g4 = *reinterpret_cast<const float4 *>(dy + (int64_t)r * C + c4 * 4);
+        if (y_or_null) {
+          const float4 y4 = *reinterpret_cast<const float4 *>(y_or_null + (int64_t)r * C + c4 * 4);
+          g4.x = y4.x > 0.f ? g4.x : 0.f; g4.y = y4.y > 0.f ? g4.y : 0.f; g4.z = y4.z > 0.f ? g4.z : 0.f; g4.w = y4.w > 0.f ? g4.w : 0.f;
+        }
         const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -192,10 +201,17 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_final_kernel(const float *__restr
 __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(const float4 *__restrict__ x, const float4 *__restrict__ dy, const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, const float *__restrict__ w,
                                                             const float *__restrict__ dw, const float *__restrict__ db, float4 *__restrict__ dx,
-                                                            int64_t total4, int C4, float inv_rows) {
+                                                            int64_t total4, int C4, float inv_rows, const float4 *__restrict__ y_or_null,
+                                                            float4 *__restrict__ dres_or_null) {
   for (int64_t i = (int64_t)blockIdx.x * BN_T + threadIdx.x; i < total4; i += (int64_t)gridDim.x * BN_T) {
     const int c = (int)(i % C4) * 4;
-    const float4 v4 = x[i], g4 = dy[i];
+    const float4 v4 = x[i];
+    float4 g4 = dy[i];
+    if (y_or_null) {
+      const float4 y4 = y_or_null[i];
+      g4.x = y4.x > 0.f ? g4.x : 0.f; g4.y = y4.y > 0.f ? g4.y : 0.f; g4.z = y4.z > 0.f ? g4.z : 0.f; g4.w = y4.w > 0.f ? g4.w : 0.f;
+    }
+    if (dres_or_null) dres_or_null[i] = g4;        // the gradient of the added identity: the masked incoming gradient
     const float v[4] = {v4.x, v4.y, v4.z, v4.w}, g[4] = {g4.x, g4.y, g4.z, g4.w};
     float o[4];
 #pragma unroll
@@ -225,12 +241,13 @@ extern "C" int64_t sgc_bn_rows_workspace_floats(int rows, int C) {
   return (int64_t)G * 2 * C;
 }
 
-extern "C" int sgc_bn_rows_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
-                                   float *running_var_or_null, float momentum, float eps, float *y, float *mean_out,
-                                   float *invstd_out, float *workspace, int64_t workspace_floats, int rows, int C,
-                                   sgc_stream_t stream) {
+static int bn_forward_impl(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                           float *running_var_or_null, float momentum, float eps, const float *residual_or_null, int relu, float *y,
+                           float *mean_out, float *invstd_out, float *workspace, int64_t workspace_floats, int rows, int C,
+                           sgc_stream_t stream) {
   if (!x || !weight || !bias || !y || !mean_out || !invstd_out || !workspace)
     return set_error(SGC_EINVAL, "sgc_bn_rows_forward: null pointer");
+  if ((uintptr_t)residual_or_null & 15) return set_error(SGC_EINVAL, "sgc_bn_rows_forward: pointers must be 16-byte aligned");
   if (rows <= 0 || C <= 0) return set_error(SGC_EINVAL, "sgc_bn_rows_forward: bad size");
   if (C % 4) return set_error(SGC_EUNSUP, "sgc_bn_rows_forward: needs C %% 4 == 0");
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)mean_out | (uintptr_t)invstd_out) & 15)
@@ -251,15 +268,32 @@ extern "C" int sgc_bn_rows_forward(const float *x, const float *weight, const fl
   const int64_t total4 = (int64_t)rows * C4;
   const int g = (int)((total4 + BN_T - 1) / BN_T < 4096 ? (total4 + BN_T - 1) / BN_T : 4096);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(g), dim3(BN_T), 0, st, reinterpret_cast<const float4 *>(x), (const float *)mean_out,
-                     (const float *)invstd_out, weight, bias, reinterpret_cast<float4 *>(y), total4, C4);
+                     (const float *)invstd_out, weight, bias, reinterpret_cast<float4 *>(y), total4, C4,
+                     reinterpret_cast<const float4 *>(residual_or_null), relu);
   return check_launch("bn_apply_kernel");
 }
 
-extern "C" int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, const float *invstd, const float *weight,
-                                    float *dx, float *dweight, float *dbias, float *workspace, int64_t workspace_floats, int rows,
-                                    int C, sgc_stream_t stream) {
+extern "C" int sgc_bn_rows_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                                   float *running_var_or_null, float momentum, float eps, float *y, float *mean_out,
+                                   float *invstd_out, float *workspace, int64_t workspace_floats, int rows, int C,
+                                   sgc_stream_t stream) {
+  return bn_forward_impl(x, weight, bias, running_mean_or_null, running_var_or_null, momentum, eps, nullptr, 0, y, mean_out, invstd_out,
+                         workspace, workspace_floats, rows, C, stream);
+}
+extern "C" int sgc_bn_rows_act_forward(const float *x, const float *weight, const float *bias, float *running_mean_or_null,
+                                       float *running_var_or_null, float momentum, float eps, const float *residual_or_null, int relu,
+                                       float *y, float *mean_out, float *invstd_out, float *workspace, int64_t workspace_floats,
+                                       int rows, int C, sgc_stream_t stream) {
+  return bn_forward_impl(x, weight, bias, running_mean_or_null, running_var_or_null, momentum, eps, residual_or_null, relu ? 1 : 0, y, mean_out,
+                         invstd_out, workspace, workspace_floats, rows, C, stream);
+}
+
+static int bn_backward_impl(const float *x, const float *dy, const float *y_or_null, const float *mean, const float *invstd, const float *weight,
+                            float *dx, float *dweight, float *dbias, float *dres_or_null, float *workspace, int64_t workspace_floats, int rows,
+                            int C, sgc_stream_t stream) {
   if (!x || !dy || !mean || !invstd || !weight || !dx || !dweight || !dbias || !workspace)
     return set_error(SGC_EINVAL, "sgc_bn_rows_backward: null pointer");
+  if (((uintptr_t)y_or_null | (uintptr_t)dres_or_null) & 15) return set_error(SGC_EINVAL, "sgc_bn_rows_backward: pointers must be 16-byte aligned");
   if (rows <= 0 || C <= 0) return set_error(SGC_EINVAL, "sgc_bn_rows_backward: bad size");
   if (C % 4) return set_error(SGC_EUNSUP, "sgc_bn_rows_backward: needs C %% 4 == 0");
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)mean | (uintptr_t)invstd) & 15)
@@ -270,7 +304,7 @@ extern "C" int sgc_bn_rows_backward(const float *x, const float *dy, const float
   hipStream_t st = (hipStream_t)stream;
   const int C4 = C / 4, CG = C4 < BN_T ? C4 : BN_T, RL = BN_T / CG;
   const size_t smem = (size_t)RL * CG * 4 * 2 * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(G), dim3(BN_T), smem, st, x, dy, mean, invstd, workspace, rows, C, rps);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(G), dim3(BN_T), smem, st, x, dy, mean, invstd, workspace, rows, C, rps, y_or_null);
   int rc = check_launch("bn_bwd_partial_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(ceil_div(C, BN_FC)), dim3(BN_T), 0, st, (const float *)workspace, G, C, dweight, dbias);
@@ -279,6 +313,21 @@ extern "C" int sgc_bn_rows_backward(const float *x, const float *dy, const float
   const int64_t total4 = (int64_t)rows * C4;
   const int g = (int)((total4 + BN_T - 1) / BN_T < 4096 ? (total4 + BN_T - 1) / BN_T : 4096);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g), dim3(BN_T), 0, st, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(dy), mean,
-                     invstd, weight, (const float *)dweight, (const float *)dbias, reinterpret_cast<float4 *>(dx), total4, C4, 1.0f / (float)rows);
+                     invstd, weight, (const float *)dweight, (const float *)dbias, reinterpret_cast<float4 *>(dx), total4, C4, 1.0f / (float)rows,
+                     reinterpret_cast<const float4 *>(y_or_null), reinterpret_cast<float4 *>(dres_or_null));
   return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int sgc_bn_rows_backward(const float *x, const float *dy, const float *mean, const float *invstd, const float *weight,
+                                    float *dx, float *dweight, float *dbias, float *workspace, int64_t workspace_floats, int rows,
+                                    int C, sgc_stream_t stream) {
+  return bn_backward_impl(x, dy, nullptr, mean, invstd, weight, dx, dweight, dbias, nullptr, workspace, workspace_floats, rows, C, stream);
+}
+// backward of sgc_bn_rows_act_forward: y_relu_or_null = its output when relu was set (the gradient passes where y > 0), dresidual_or_null
+// = where to put the gradient of the added identity (the masked incoming gradient; null when there was none or nobody needs it)
+extern "C" int sgc_bn_rows_act_backward(const float *x, const float *dy, const float *y_relu_or_null, const float *mean, const float *invstd,
+                                        const float *weight, float *dx, float *dweight, float *dbias, float *dresidual_or_null,
+                                        float *workspace, int64_t workspace_floats, int rows, int C, sgc_stream_t stream) {
+  return bn_backward_impl(x, dy, y_relu_or_null, mean, invstd, weight, dx, dweight, dbias, dresidual_or_null, workspace, workspace_floats, rows, C,
+                          stream);
 }

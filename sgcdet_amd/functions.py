@@ -344,22 +344,41 @@ class BatchNormRowsFunction(Function):
     """Training-mode ``nn.BatchNorm3d`` on channels-last rows [rows, C] (necks/imvoxelnet.py:36-64: every convolution of the neck
     is followed by one): statistics, normalisation and the backward reductions on ``sgc_bn_rows_forward / _backward`` (ordered
     reductions: the same bits every run) instead of torch's channels-last batch-norm kernels.  The running statistics are
-    updated in place by the forward kernel, as ``F.batch_norm(training=True)`` does."""
+    updated in place by the forward kernel, as ``F.batch_norm(training=True)`` does.
+
+    ``residual`` / ``relu`` (round 5): the elementwise tail of the neck's blocks inside the same passes -- ``relu(norm(conv))`` and the
+    ResBlock tail ``relu(norm2(conv2) + identity)`` -- i.e. ``y = relu(bn(rows) + residual)`` forward, and backward the incoming
+    gradient masked where ``y > 0`` (torch's ``threshold_backward``) before the BatchNorm backward; the identity's gradient is that
+    masked gradient (``sgc_bn_rows_act_forward / _backward``)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
         ops = ext.ops()
         x = rows.contiguous()
+        res = None if residual is None else residual.detach().contiguous()
         y, mean, invstd = ops.bn_rows_forward(x, weight.detach().contiguous(), bias.detach().contiguous(), running_mean, running_var,
-                                              momentum, eps)
-        ctx.save_for_backward(x, mean, invstd, weight.detach())
+                                              momentum, eps, residual=res, relu=relu)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        if relu:
+            ctx.save_for_backward(x, mean, invstd, weight.detach(), y)
+        else:
+            ctx.save_for_backward(x, mean, invstd, weight.detach())
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, mean, invstd, weight = ctx.saved_tensors
-        dx, dw, db = ext.ops().bn_rows_backward(x, grad_y.contiguous(), mean, invstd, weight.contiguous())
-        return dx, dw, db, None, None, None, None
+        saved = ctx.saved_tensors
+        x, mean, invstd, weight = saved[:4]
+        g = grad_y.contiguous()
+        if not ctx.relu and not ctx.has_res:
+            dx, dw, db = ext.ops().bn_rows_backward(x, g, mean, invstd, weight.contiguous())
+            return dx, dw, db, None, None, None, None, None, None
+        want_res = ctx.has_res and ctx.needs_input_grad[7]
+        if not ctx.relu:                               # no mask: the identity's gradient IS the incoming gradient
+            dx, dw, db = ext.ops().bn_rows_backward(x, g, mean, invstd, weight.contiguous())
+            return dx, dw, db, None, None, None, None, (g if want_res else None), None
+        dx, dw, db, dres = ext.ops().bn_rows_backward(x, g, mean, invstd, weight.contiguous(), y_relu=saved[4], want_dresidual=want_res)
+        return dx, dw, db, None, None, None, None, dres, None
 
 
 class LinearRowsFunction(Function):

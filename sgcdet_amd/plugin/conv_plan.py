@@ -128,6 +128,7 @@ class ConvSpec:
 # kernels (functions.ChannelsLastConv3dFunction), "library" = torch's convolutions (MIOpen) as in round 1
 TRAIN_CONV = os.environ.get("SGC_TRAIN_CONV", "hip")
 BN_ON_HIP = os.environ.get("SGC_BN_HIP", "1") != "0"      # training-mode BatchNorm of the neck on sgc_bn_rows_* (0: torch's kernels)
+BN_FUSE_TAIL = os.environ.get("SGC_BN_FUSE_TAIL", "1") != "0"   # `+ identity` / ReLU behind a BatchNorm inside its passes (0: torch ops, A/B)
 
 
 THROUGHPUT_GEOMETRY = False      # set_throughput_mode(True): scenes in flight, kernels sized for CU-time (read by ConvSpec._winograd_planes)
@@ -193,10 +194,15 @@ def conv_transpose_rows(conv, rows, grid):
     return ChannelsLastConvTranspose3dFunction.apply(rows, conv.weight, tuple(grid)), tuple(2 * d for d in grid)
 
 
-def bn_rows(bn, rows, grid):
-    """A BatchNorm3d-like module on channels-last rows [V, C].  ``nn.BatchNorm3d`` over [1, C, X, Y, Z] is the statistics of
-    the V rows per channel, i.e. ``F.batch_norm`` on the [V, C] matrix (same running-statistics update); any other module
-    (SyncBatchNorm3d, GroupNorm ...) gets the 5-D channels-last view."""
+def bn_rows(bn, rows, grid, residual=None, relu=False):
+    """A BatchNorm3d-like module on channels-last rows [V, C], optionally followed by ``+ residual`` and ``relu`` (the tails of the
+    neck's blocks; on the HIP path they run inside the normalisation passes).  ``nn.BatchNorm3d`` over [1, C, X, Y, Z] is the
+    statistics of the V rows per channel, i.e. ``F.batch_norm`` on the [V, C] matrix (same running-statistics update); any other
+    module (SyncBatchNorm3d, GroupNorm ...) gets the 5-D channels-last view."""
+    def tail(y):
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
     if type(bn) is torch.nn.BatchNorm3d:
         use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
         momentum = 0.0 if bn.momentum is None else bn.momentum
@@ -208,13 +214,16 @@ def bn_rows(bn, rows, grid):
                 and bn.weight is not None and bn.bias is not None and rows.shape[0] > 1):
             from ..functions import BatchNormRowsFunction
             track = bn.training and bn.track_running_stats
-            return BatchNormRowsFunction.apply(rows, bn.weight, bn.bias, bn.running_mean if track else None,
-                                               bn.running_var if track else None, float(momentum), float(bn.eps))
-        return torch.nn.functional.batch_norm(rows, bn.running_mean if not bn.training or bn.track_running_stats else None,
-                                              bn.running_var if not bn.training or bn.track_running_stats else None,
-                                              bn.weight, bn.bias, use_batch, momentum, bn.eps)
+            fuse = BN_FUSE_TAIL and (residual is None or (residual.dtype == torch.float32 and residual.shape == rows.shape))
+            y = BatchNormRowsFunction.apply(rows, bn.weight, bn.bias, bn.running_mean if track else None,
+                                            bn.running_var if track else None, float(momentum), float(bn.eps),
+                                            residual if fuse else None, bool(relu and fuse))
+            return y if fuse else tail(y)
+        return tail(torch.nn.functional.batch_norm(rows, bn.running_mean if not bn.training or bn.track_running_stats else None,
+                                                   bn.running_var if not bn.training or bn.track_running_stats else None,
+                                                   bn.weight, bn.bias, use_batch, momentum, bn.eps))
     y = bn(rows_to_ncdhw(rows, grid, rows.shape[1]))
-    return y[0].permute(1, 2, 3, 0).reshape(rows.shape[0], rows.shape[1])
+    return tail(y[0].permute(1, 2, 3, 0).reshape(rows.shape[0], rows.shape[1]))
 
 
 def module_fingerprint(module):

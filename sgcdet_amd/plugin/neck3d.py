@@ -118,36 +118,35 @@ class FastIndoorImVoxelNeck(nn.Module):
     def _forward_autograd_hip(self, x):
         """Training / autograd path on the HIP kernels: every convolution -- forward, input gradient,
         weight gradient -- through ``ChannelsLastConv3dFunction`` / ``ChannelsLastConvTranspose3dFunction`` on the
-        channels-last rows the voxel head hands over; BatchNorm (batch statistics), ReLU and the skip additions stay
-        torch ops on the same rows.  Same chain as imvoxelnet.py:22-34,146-173."""
-        relu = torch.relu
+        channels-last rows the voxel head hands over; BatchNorm with batch statistics on ``sgc_bn_rows_*``, the ReLU behind it and
+        the ResBlock's identity addition inside the same passes (``conv_plan.bn_rows(residual=, relu=)``).  Same chain as
+        imvoxelnet.py:22-34,146-173."""
         rows, grid = to_channels_last_rows(x)
         skips = []
         for i in range(self.n_scales):
             for blk in getattr(self, f"down_layer_{i}"):
                 h, g1 = conv_rows(blk.conv1, rows, grid)
-                h = relu(bn_rows(blk.norm1, h, g1))
+                h = bn_rows(blk.norm1, h, g1, relu=True)
                 o, _ = conv_rows(blk.conv2, h, g1)
-                o = bn_rows(blk.norm2, o, g1)
                 if blk.stride != 1:
                     skip, _ = conv_rows(blk.downsample[0], rows, grid)
                     skip = bn_rows(blk.downsample[1], skip, g1)
                 else:
                     skip = rows
-                rows, grid = relu(o + skip), g1
+                rows, grid = bn_rows(blk.norm2, o, g1, residual=skip, relu=True), g1      # relu(norm2(conv2) + identity)
             skips.append((rows, grid))
         outs = []
         for i in reversed(range(self.n_scales)):
             if i < self.n_scales - 1:
                 up = getattr(self, f"up_block_{i + 1}")
                 h, g = conv_transpose_rows(up[0], rows, grid)
-                h = relu(bn_rows(up[1], h, g))
+                h = bn_rows(up[1], h, g, relu=True)
                 h, _ = conv_rows(up[3], h, g)
-                h = relu(bn_rows(up[4], h, g))
+                h = bn_rows(up[4], h, g, relu=True)
                 rows, grid = skips[i][0] + h, g
             ob = getattr(self, f"out_block_{i}")
             o, _ = conv_rows(ob[0], rows, grid)
-            o = relu(bn_rows(ob[1], o, grid))
+            o = bn_rows(ob[1], o, grid, relu=True)
             outs.append(rows_to_ncdhw(o, grid, o.shape[1]))
         return outs[::-1]
 

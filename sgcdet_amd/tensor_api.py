@@ -826,37 +826,46 @@ class TensorOps:
         self._call("sgc_topk_select_ws", flat, n, int(k), idx, valid, mask, ws, wsb)
         return idx, valid, mask
 
-    def bn_rows_forward(self, x, weight, bias, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    def bn_rows_forward(self, x, weight, bias, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, residual=None, relu=False):
         """Training-mode BatchNorm over rows x [rows, C] -> (y, mean [C], invstd [C]); the running statistics are updated in
-        place as nn.BatchNorm does."""
-        self._check(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var)
-        self._f32(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var)
+        place as nn.BatchNorm does.  ``residual`` / ``relu``: y = relu(bn(x) + residual) in the same pass (``sgc_bn_rows_act_forward``)."""
+        self._check(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, residual=residual)
+        self._f32(x=x, weight=weight, bias=bias, running_mean=running_mean, running_var=running_var, residual=residual)
         rows, Cc = x.shape
-        if weight.numel() != Cc or bias.numel() != Cc:
+        if weight.numel() != Cc or bias.numel() != Cc or (residual is not None and residual.shape != x.shape):
             raise RuntimeError("bn_rows_forward: inconsistent shapes")
         y = torch.empty_like(x)
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
         n = int(self.lib._dll.sgc_bn_rows_workspace_floats(rows, Cc))
         ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
-        self._call("sgc_bn_rows_forward", x, weight, bias, running_mean, running_var, float(momentum), float(eps), y, mean, invstd, ws,
-                   ws.numel(), rows, Cc)
+        if residual is None and not relu:
+            self._call("sgc_bn_rows_forward", x, weight, bias, running_mean, running_var, float(momentum), float(eps), y, mean, invstd, ws,
+                       ws.numel(), rows, Cc)
+        else:
+            self._call("sgc_bn_rows_act_forward", x, weight, bias, running_mean, running_var, float(momentum), float(eps), residual, int(bool(relu)),
+                       y, mean, invstd, ws, ws.numel(), rows, Cc)
         return y, mean, invstd
 
-    def bn_rows_backward(self, x, dy, mean, invstd, weight):
-        """-> (dx [rows, C], dweight [C], dbias [C]) of ``bn_rows_forward``."""
-        self._check(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight)
-        self._f32(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight)
+    def bn_rows_backward(self, x, dy, mean, invstd, weight, y_relu=None, want_dresidual=False):
+        """-> (dx [rows, C], dweight [C], dbias [C]) of ``bn_rows_forward``; with ``y_relu`` (the forward's output when it ended in a
+        ReLU) and / or ``want_dresidual`` -> (dx, dweight, dbias, dresidual) through ``sgc_bn_rows_act_backward``."""
+        self._check(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight, y_relu=y_relu)
+        self._f32(x=x, dy=dy, mean=mean, invstd=invstd, weight=weight, y_relu=y_relu)
         rows, Cc = x.shape
-        if dy.shape != x.shape or mean.numel() != Cc or invstd.numel() != Cc or weight.numel() != Cc:
+        if dy.shape != x.shape or mean.numel() != Cc or invstd.numel() != Cc or weight.numel() != Cc or (y_relu is not None and y_relu.shape != x.shape):
             raise RuntimeError("bn_rows_backward: inconsistent shapes")
         dx = torch.empty_like(x)
         dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
         db = torch.empty_like(dw)
         n = int(self.lib._dll.sgc_bn_rows_workspace_floats(rows, Cc))
         ws = torch.empty(max(n, 4), dtype=torch.float32, device=x.device)
-        self._call("sgc_bn_rows_backward", x, dy, mean, invstd, weight, dx, dw, db, ws, ws.numel(), rows, Cc)
-        return dx, dw, db
+        if y_relu is None and not want_dresidual:
+            self._call("sgc_bn_rows_backward", x, dy, mean, invstd, weight, dx, dw, db, ws, ws.numel(), rows, Cc)
+            return dx, dw, db
+        dres = torch.empty_like(x) if want_dresidual else None
+        self._call("sgc_bn_rows_act_backward", x, dy, y_relu, mean, invstd, weight, dx, dw, db, dres, ws, ws.numel(), rows, Cc)
+        return dx, dw, db, dres
 
     def layer_norm_rows(self, x, gamma, beta, eps=1e-5, count=None, out=None):
         """nn.LayerNorm over the last dim of x [rows, C]; ``count``: int32 device tensor with the live row count."""

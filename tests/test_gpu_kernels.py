@@ -942,6 +942,49 @@ def test_batch_norm_rows_kernels_against_the_oracle_and_torch(rows, C, oracle_op
     assert float((bg.grad.cpu().double() - bd.grad).abs().max()) < 2e-4 * max(1.0, float(bd.grad.abs().max()))
 
 
+@pytest.mark.parametrize("rows,C,res,relu", [(25600, 256, True, True), (3200, 512, False, True), (1237, 128, True, False), (77, 1040, True, True)])
+def test_batch_norm_rows_with_the_block_tail_inside(rows, C, res, relu, oracle_ops, gpu_ops):
+    """sgc_bn_rows_act_forward / _backward: y = relu(bn(x) + residual) in the normalisation pass and its backward (gradient masked
+    where y > 0, identity gradient = the masked gradient) -- bit-identical to the plain kernels followed by torch's add / relu and
+    threshold_backward (the elementwise steps are the same float operations on the same values); the oracle twin; and
+    BatchNormRowsFunction(residual, relu) against F.batch_norm + add + relu autograd in float64."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + C + 1)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 3.0).cuda()
+    w, b = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    r = torch.randn(rows, C, generator=g).cuda() if res else None
+    dy = torch.randn(rows, C, generator=g).cuda()
+    y0, mean, invstd = gpu_ops.bn_rows_forward(x, w, b, None, None, momentum=0.1, eps=1e-5)
+    want = y0 + r if res else y0
+    want = torch.relu(want) if relu else want
+    y1, mean1, invstd1 = gpu_ops.bn_rows_forward(x, w, b, None, None, momentum=0.1, eps=1e-5, residual=r, relu=relu)
+    assert torch.equal(mean1, mean) and torch.equal(invstd1, invstd)
+    assert torch.equal(y1, want)                       # fmaf-free elementwise tail: the same bits as the separate kernels
+    gm = dy * (y1 > 0) if relu else dy
+    dx0, dw0, db0 = gpu_ops.bn_rows_backward(x, gm.contiguous(), mean, invstd, w)
+    out = gpu_ops.bn_rows_backward(x, dy, mean, invstd, w, y_relu=y1 if relu else None, want_dresidual=res)
+    assert torch.equal(out[0], dx0) and torch.equal(out[1], dw0) and torch.equal(out[2], db0)
+    if res:
+        assert torch.equal(out[3], gm)
+    tw = oracle_ops.bn_rows_forward(x.cpu(), w.cpu(), b.cpu(), None, None, momentum=0.1, eps=1e-5, residual=None if r is None else r.cpu(), relu=relu)
+    assert float((y1.cpu() - tw[0]).abs().max()) < 2e-4
+    # the autograd Function against torch in float64
+    from sgcdet_amd.functions import BatchNormRowsFunction
+    xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rg = r.clone().requires_grad_(True) if res else None
+    BatchNormRowsFunction.apply(xg, wg, bg, None, None, 0.1, 1e-5, rg, relu).backward(dy)
+    xd, wd, bd = x.cpu().double().requires_grad_(True), w.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    rd = r.cpu().double().requires_grad_(True) if res else None
+    t = F.batch_norm(xd, None, None, wd, bd, True, 0.1, 1e-5)
+    t = t + rd if res else t
+    # the float64 reference masks on ITS OWN sign; entries whose fp32 pre-activation is within rounding of zero may differ: use the fp32 mask
+    if relu:
+        t = t * (y1.cpu() > 0).double()
+    t.backward(dy.cpu().double())
+    for a, d in ((xg.grad, xd.grad), (wg.grad, wd.grad), (bg.grad, bd.grad)) + (((rg.grad, rd.grad),) if res else ()):
+        assert float((a.cpu().double() - d).abs().max()) < 2e-4 * max(1.0, float(d.abs().max()))
+
+
 @pytest.mark.parametrize("N,Nq,C", [(40, 700, 256), (100, 900, 128), (3, 100, 256), (128, 300, 128)])
 def test_projected_query_attention_against_oracle(N, Nq, C, oracle_ops, gpu_ops):
     """sgc_view_attend_pq vs its oracle twin (double accumulation) on random visible-pair lists: one and many cameras per voxel,

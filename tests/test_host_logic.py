@@ -205,6 +205,16 @@ def test_bn_rows_is_batchnorm3d_on_the_channels_last_rows():
     gn = torch.nn.GroupNorm(2, C)
     rows = torch.randn(60, C)
     assert torch.allclose(rows_to_ncdhw(bn_rows(gn, rows, grid), grid, C), gn(rows_to_ncdhw(rows, grid, C)), atol=1e-6)
+    # the block tail (`+ identity`, ReLU) through bn_rows: the torch composition on every path that does not fuse it
+    bn = torch.nn.BatchNorm3d(C).train()
+    ref = copy.deepcopy(bn)
+    rows, skip = torch.randn(60, C, requires_grad=True), torch.randn(60, C, requires_grad=True)
+    y = bn_rows(bn, rows, grid, residual=skip, relu=True)
+    vol, vskip = rows_to_ncdhw(rows.detach(), grid, C).contiguous().requires_grad_(True), rows_to_ncdhw(skip.detach(), grid, C).contiguous().requires_grad_(True)
+    y_ref = torch.relu(ref(vol) + vskip)
+    assert torch.allclose(rows_to_ncdhw(y, grid, C), y_ref, atol=1e-6)
+    y.square().sum().backward(); y_ref.square().sum().backward()
+    assert torch.allclose(rows_to_ncdhw(rows.grad, grid, C), vol.grad, atol=1e-5) and torch.allclose(rows_to_ncdhw(skip.grad, grid, C), vskip.grad, atol=1e-5)
 
 
 def test_fpn_restates_the_published_module():
