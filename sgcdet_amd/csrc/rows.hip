@@ -8,7 +8,7 @@
 //                     that order implementation-defined; voxels no camera sees carry bit-identical scores, so ties are
 //                     real) -- the same rule as the oracle, so both sides select the same voxels whenever their scores
 //                     agree bit for bit.  Replaces gatherTopK + 2 radix sorts + merges + scatter + 3 elementwise
-//                     kernels (~150 us per scene at config 2) by one launch; candidate sets of 16 384 scores or more go
+//                     kernels (~150 us per scene at config 2) by one launch; candidate sets of more than 32 768 scores go
 //                     through the many-workgroup form further down (same outputs).
 //   sgc_layer_norm_rows  nn.LayerNorm(C) over rows (the two norms of VoxFormerLayer, TU/encoder.py:311-338 via
 //                     build_norm_layer(dict(type='LN')), TU/custom_base_transformer_layer.py:153-156): one wave per
@@ -371,7 +371,10 @@ __global__ __launch_bounds__(256) void layer_norm_rows_generic_kernel(const floa
 
 using namespace sgc;
 
-namespace sgc { int g_tune_topk_multi_min = 16384; }   // candidate sets of at least this size use the many-workgroup form when a workspace is given
+// candidate sets of at least this size use the many-workgroup form (7 launches) when a workspace is given.  Round 5: 32 769 -- up to 32 768
+// candidates ONE workgroup with the keys in registers is as fast with one or four scenes in flight (573 / 566 / 579 against 574 / 567 / 564
+// scenes/s, 388 against 389 with one stream: profiles/r05_topk_ab.txt) and is one launch; it was 16 384 since round 3
+namespace sgc { int g_tune_topk_multi_min = 32769; }
 
 extern "C" int64_t sgc_topk_select_workspace_bytes(int n) {
   return n > 0 ? (int64_t)(4 * 256 + 2 * ceil_div(n, TK_CHUNK)) * (int64_t)sizeof(int) : 0;

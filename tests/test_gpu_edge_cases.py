@@ -150,7 +150,7 @@ def test_round2_entry_points_on_degenerate_shapes(oracle_ops, gpu_ops):
             b = oracle_ops.topk_select(s, k, want_valid=True, want_mask=True)
             assert all(torch.equal(u.cpu(), v) for u, v in zip(a, b)), (n, k)
     finally:
-        gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 16384)
+        gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 32769)
     N, Nq, C, heads = 1, 9, 32, 8                                     # one camera: softmax over one view, d_score = 0
     slot = torch.arange(Nq, dtype=torch.int32).view(1, Nq)
     vi = torch.arange(Nq, dtype=torch.int32)

@@ -710,7 +710,7 @@ def test_topk_many_workgroup_form_equals_the_one_workgroup_form(n, k, gpu_ops):
                 for a, b in zip(got, ref):
                     assert torch.equal(a, b)
         finally:
-            gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 16384)
+            gpu_ops.lib.call("sgc_set_tuning", b"topk_multi_min", 32769)
 
 
 def test_view_attend_backward_matches_oracle_and_multihead_attention(oracle_ops, gpu_ops):
