@@ -60,6 +60,7 @@ while left > 0:
 ms_step = round(sorted(blocks)[len(blocks) // 2], 2)
 ms_min = round(min(blocks), 2)
 l = float(l)
+n_grads = sum(int(p.grad is not None) for p in params)
 if args.profile:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -128,6 +129,6 @@ if args.glue:
     print(f"torch glue ops with device time: {tot / 1e3:.2f} ms per step", file=sys.stderr)
     for (name, site), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
         print(f"{t / 1e3:8.3f} ms  x{n:<4d} {name:28s} {site}", file=sys.stderr)
-print(json.dumps(dict(workload=args.workload, ms_per_step=ms_step, ms_per_step_best_block=ms_min, loss=l,
+print(json.dumps(dict(workload=args.workload, ms_per_step=ms_step, ms_per_step_best_block=ms_min, loss=l, params_with_grad=f"{n_grads}/{len(params)}",
                       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2**30, 2), no_neck=args.no_neck,
                       input_layout=args.input_layout)))
