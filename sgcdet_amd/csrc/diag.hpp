@@ -8,8 +8,9 @@
 //                     (sgc_diag_halo_stamp_buffer); no output value depends on them.
 //   SGC_HALO_SKIP     bit mask, lockstep form of the halo convolution (halo_stagger 0), TIMING ONLY (results are garbage): 1 no
 //                     barrier per tap, 2 no weight ds_write, 4 no weight global load, 8 weight fragments read from LDS once
-//                     instead of every tap, 16 halo fragments read once, 32 no MFMAs -- what each part of the tap loop costs (tools/halo_skip.py,
-//                     tools/kernel_power.py)
+//                     instead of every tap, 16 halo fragments read once, 32 no MFMAs, 64 (software-pipelined form) the halo image of the first channel slice is never
+//                     replaced: no loads / split / LDS stores per slice, 128 no epilogue -- what each part costs (tools/halo_skip.py,
+//                     tools/wz_skip.py, tools/kernel_power.py)
 //   SGC_RG_STAMPS     s_memtime stamps inside the staggered form of the persistent row GEMM (rows_depth 0; tools/rows_gemm_stamps.py):
 //                     buffer [workgroup < 8][wave parity 2][iteration < 32][8] x uint64 (sgc_diag_rows_stamp_buffer)
 #pragma once

@@ -44,6 +44,9 @@ def set_conv_mode(mode):
 WINOGRAD_Z = {"0": False, "1": True}.get(os.environ.get("SGC_WINOGRAD_Z", ""), "auto")
 WINOGRAD_Z_MIN_CH = int(os.environ.get("SGC_WINOGRAD_Z_MIN_CH", "256"))
 WINOGRAD_Z_RAGGED = os.environ.get("SGC_WINOGRAD_Z_RAGGED", "1") != "0"     # also slices the 8 x 8 pixel bricks do not tile exactly (20 x 20)
+# layers that keep the direct kernel although "auto" would give them the form: (Cin, Cout, gx, gy, gz) tuples, from per-layer A/B runs
+# with scenes in flight (profiles/r06_winograd_layers_ab.txt).  Env (A/B runs): SGC_WINOGRAD_Z_DENY="512:128:20:20:8,512:512:20:20:8"
+WINOGRAD_Z_DENY = {tuple(int(v) for v in item.split(":")) for item in os.environ.get("SGC_WINOGRAD_Z_DENY", "").split(",") if item}
 
 
 def set_winograd_z(mode, min_channels=None):
@@ -93,6 +96,8 @@ class ConvSpec:
         if (WINOGRAD_Z is False or self.ksize != 3 or self.stride != 1 or self.transposed or CONV_MODE != "bf16x3"
                 or (WINOGRAD_Z == "auto" and self.cin_p < WINOGRAD_Z_MIN_CH)
                 or (not WINOGRAD_Z_RAGGED and (grid[0] % 8 or grid[1] % 8))):
+            return None
+        if (self.cin_p, self.cout_p) + tuple(grid) in WINOGRAD_Z_DENY:
             return None
         ops = ext.ops()
         if not ops.conv3d_winograd_z_supported(grid, self.cin_p, self.cout_p):

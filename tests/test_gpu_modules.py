@@ -355,10 +355,13 @@ def _neck_head_oracle(det, w):
                         nms_pre=1000))
 
 
-@pytest.mark.parametrize("name,img_hw", [("cfg3_arkit", None), ("cfg4_scannet200_large", None), ("cfg5_arkit_large", None)])
+@pytest.mark.parametrize("name,img_hw", [("cfg3_arkit", None), ("cfg4_scannet200_large", None), ("cfg5_arkit_large", None),
+                                         ("cfg2_scannet_100v", None)])
 def test_full_view_count_scenes_against_the_oracle(name, img_hw):
     """BASELINE.json configs[2..4] at their FULL view counts (60 / 50 / 100 views; 48x48x16, 80x80x32 with 189
-    classes, 96x96x32) -- GPU vs the OpenMP build of the oracle: selected voxel sets identical up to near ties at the
+    classes, 96x96x32), and config 2 at the reference's own TEST-time view count (100 views, `n_images=100` of
+    configs/SGCDet_ScanNet.py:151-164: the shape its README numbers are produced on, and the only C = 256 shape that takes the
+    projected-query inter-view attention by default) -- GPU vs the OpenMP build of the oracle: selected voxel sets identical up to near ties at the
     cut, voxel features and occupancy within 1e-3, and neck + head (HIP) on the oracle's volume within 1e-3.
     These are the C = 128 (Cm = 16) shapes of the LDS-tiled gather at full pair counts (0.8 M / 2.4 M pairs)."""
     import sgcdet_amd.plugin  # noqa: F401
