@@ -50,9 +50,6 @@ int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until t
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_narrow = 1;       // halo kernel: 1 = 64-column tiles for layers with <= 64 output channels and 32-column tiles (8 x 1
                                   // waves) for <= 32; 64 = never below 64 columns (the round-2..4 form, A/B); 0 = always 128
-#if !defined(SGC_HALO_PROG)
-#define SGC_HALO_PROG 0           // 2-D form of the halo kernel: early halo loads + progressive split (see the kernel); bit-identical
-#endif
 int g_tune_halo_min_m = 2048;     // fewest output voxels for the halo kernel
 int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo kernel (128-column tiles) is used: the head's
                                  // 28-channel convolutions run 105 -> 67 us on it although 3/4 of the tile columns are padding
@@ -802,10 +799,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
   // last tap of a slice (the loads went out three taps earlier), so that between the slice's last barrier and the next
   // slice's first tap only the ds_writes remain -- the vector work of the split overlaps the other wave's MFMAs instead of
   // sitting between two barriers.
-  auto split_A = [&](int i0 = 0, int i1 = 1 << 20) {
+  auto split_A = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (i < i0 || i >= i1) continue;
       float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
       if constexpr (WZ) {                       // the input transform: one fp32 rounding per element (sign * b is exact)
         v[0] += wz_sign * rw[i].x; v[1] += wz_sign * rw[i].y; v[2] += wz_sign * rw[i].z; v[3] += wz_sign * rw[i].w;
@@ -918,10 +914,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
     __syncthreads();
     Frag P = {}, Q = {};
     constexpr int SKIP = SGC_HALO_SKIP;      // timing builds only (diag.hpp); 0 in the product
-    // 2-D form (9 taps per slice: a third of the 3-D form's tap loop for the same staging work): the next slice's halo loads go
-    // out at the slice's second tap and are split progressively, instead of loads at tap NTAP - 3 and one split under the last tap
-    constexpr bool PROG = TD && (SGC_HALO_PROG != 0);
-    constexpr int LOAD_TAP = PROG ? 1 : NTAP - 3;
     if (wave_live) { read_A(P, tap_off(0), 0); read_B(P, 0, 0); }
     int g = 0;
     for (int cc = c_lo; cc < c_hi; ++cc) {
@@ -938,16 +930,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
         }
         if (!(SKIP & 2) && more) store_B((g + 1) & 1);
         if (!(SKIP & 4) && g + 2 < steps_total) load_B(step_tap(g + 2), step_cc(g + 2));
-        if (!(SKIP & 64) && tap == LOAD_TAP && cc + 1 < c_hi) load_A(cc + 1);    // next slice's halo rides under the last taps
+        if (!(SKIP & 64) && tap == NTAP - 3 && cc + 1 < c_hi) load_A(cc + 1);    // next slice's halo rides under the last taps
         if (wave_live) mfma_half(P);
-        if constexpr (PROG) {
-          // two chunks per tap under the slice's last taps (the last chunk under the last tap): the split's vector work fits the
-          // issue slots beside a tap's MFMAs instead of standing between the last tap's two halves
-          const int sb = NA - 2 * (NTAP - 1 - tap), sa = sb - 2;           // chunks [sa, sb) at this tap; [NA - 2, NA) at the last one
-          if (!(SKIP & 64) && sb > 0 && cc + 1 < c_hi) split_A(sa < 0 ? 0 : sa, sb);
-        } else {
-          if (!(SKIP & 64) && last_tap && cc + 1 < c_hi) split_A();
-        }
+        if (!(SKIP & 64) && last_tap && cc + 1 < c_hi) split_A();
         if (!(SKIP & 1)) __syncthreads();
         // the fence keeps the refill of P behind the MFMAs that consumed it (hoisted above them it needs a second set of
         // registers) and behind the barrier that publishes the tile it reads
@@ -1089,7 +1074,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
 // history up to round 3): weights by LDS-DMA into a four-stage ring with swizzled unpadded rows (237 vs 230 us warm on the 90-GF
 // layer); weights straight from L2 into registers, no barrier per tap (236 vs 229-240, 2-7 % slower elsewhere); three weight
 // buffers staged two taps ahead (236 vs 232); v_mfma_f32_16x16x32_bf16 (234 vs 230); a one-wave-per-SIMD form with 512
-// registers (309 vs 251).
+// registers (309 vs 251).  Round 6, Winograd (2-D, 9 taps per slice) form: the next slice's halo loads issued at the slice's second tap
+// and split two chunks per tap under the last four taps instead of one split under the last tap -- 191.5 vs 191.2 us on the 90-GF layer,
+// 155.8 vs 151.8 on 512 -> 512 @ 20x20x8 (profiles/r06_wz_skip.txt: the 13 us the restaging costs are not vector-issue time).
 
 // Zero-fill of a split-K accumulation target as a KERNEL, not hipMemsetAsync: a memset captured into a large
 // hipGraph (the whole-scene graph) is not ordered with the kernel nodes around it on ROCm 7.2 -- from the second

@@ -3,7 +3,6 @@ stack of 4 Z/2 images + the output transform) spends its time -- the product lib
 9-tap loop removed (SGC_HALO_SKIP, csrc/diag.hpp; THEIR RESULTS ARE GARBAGE) and against other builds of the same kernel
 (tools/diag/libsgc_<name>.so that are not skip builds are checked bit for bit):
   for m in 1 2 6 24 32 64 128 192; do bash tools/diag_build.sh skip$m conv3d.hip -DSGC_HALO_SKIP=$m; done
-  bash tools/diag_build.sh prog conv3d.hip -DSGC_HALO_PROG=1
 Alternated rounds in one process; the first round is the cold one.  Usage: python tools/wz_skip.py [Cin Cout gx gy gz]"""
 import glob, os, re, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
