@@ -180,6 +180,23 @@ int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_
                              int B, int S, int M, int Cm, int D, int dist_heads,
                              int L, int n_items, int P, sgc_stream_t stream);
 
+/* The same backward for ONE level over a BINNED item list (round 6; training path): items = the visible (camera, voxel) pairs in
+ * the (camera, bin) order of sgc_bin_pairs, `bin_offset` [N * nbx * nby + 1] as sgc_bin_pairs writes it for bins of
+ * bin_w x bin_h feature pixels.  A workgroup owns (camera, bin): the window's slice of grad_value and of grad_dist is accumulated
+ * in LDS and flushed once (wms_deform_attn_cuda_kernel.cuh:82-159 and ms_depth_score_sample_cuda_kernel.cuh:150-241 add every corner
+ * with a global atomic; TU/multi_scale_3ddeformable_attn_function.py:303-351 merges the two stages as this entry point does).
+ * value [N,S,M,Cm], dist [N,S,D] (one depth map per camera: dist_heads == 1), loc3 [n_items, loc_heads, P, 3], attn
+ * [n_items, loc_heads, P] or NULL (= 1), grad_out [n_items, M*Cm]; loc_heads = M, or 1 = ONE sample set shared by the M channel
+ * groups (the geometry sample's single head over C = M * Cm channels); its gradients are then summed over the groups.
+ * grad_value / grad_dist must be zero-filled by the caller (they are accumulated into); grad_loc3 / grad_attn (either may be NULL)
+ * are written.  Cm in {16, 32}, P <= 4; the window (bin + halo) must fit LDS (sgc_dfa3d_backward_binned_lds_bytes <= 160 KiB).
+ * Same function of the inputs as sgc_dfa3d_backward_items; float atomics make the last bits order-dependent in both. */
+int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
+                              const int32_t *bin_offset, const float *grad_out, float *grad_value, float *grad_dist,
+                              float *grad_loc3_or_null, float *grad_attn_or_null, int N, int S, int H, int W, int M, int Cm,
+                              int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y, sgc_stream_t stream);
+int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y);
+
 /* ------------------------------------------------------------------------- *
  * 3. Voxel -> pixel projection and per-camera compaction
  *    (replaces VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223, and

@@ -466,6 +466,41 @@ int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_
   return SGC_OK;
 }
 
+/* Binned form of the item backward (product: csrc/dfa3d_bwd_tile.hip).  The bins only say which workgroup adds what: the
+ * function of the inputs is sgc_dfa3d_backward on every item with its camera's maps; a sample set shared by the M channel groups
+ * (loc_heads == 1 < M) is the one-head operator over C = M * Cm channels. */
+int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y) {
+  if (H <= 0 || W <= 0 || Cm <= 0 || D <= 0 || bin_w <= 0 || bin_h <= 0 || halo_x < 0 || halo_y < 0) return 0;
+  const int64_t tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W, th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
+  return tw * th * (Cm + 1 + D) * 4;
+}
+int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
+                              const int32_t *bin_offset, const float *grad_out, float *grad_value, float *grad_dist,
+                              float *grad_loc3_or_null, float *grad_attn_or_null, int N, int S, int H, int W, int M, int Cm,
+                              int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y, sgc_stream_t stream) {
+  (void)halo_x; (void)halo_y;
+  if (!value || !dist || !loc3 || !bin_offset || !grad_out || !grad_value || !grad_dist) return fail(SGC_EINVAL, "null pointer");
+  if (loc_heads != 1 && loc_heads != M) return fail(SGC_EINVAL, "loc_heads must be 1 or M");
+  const int nb = ((W + bin_w - 1) / bin_w) * ((H + bin_h - 1) / bin_h);
+  const int64_t MC = (int64_t)M * Cm;
+  const int Mo = loc_heads == 1 ? 1 : M, Cmo = loc_heads == 1 ? M * Cm : Cm;      /* the operator's own head split */
+  const int64_t SPI = (int64_t)Mo * P;
+  const int64_t shapes3[3] = {H, W, D}, lsi[1] = {0};
+  float *gl_tmp = (float *)malloc(sizeof(float) * (size_t)SPI * 3), *ga_tmp = (float *)malloc(sizeof(float) * (size_t)SPI);
+  int rc = SGC_OK;
+  for (int t = 0; t < N * nb && !rc; ++t) {
+    const int b = t / nb;
+    for (int i = bin_offset[t]; i < bin_offset[t + 1] && !rc; ++i) {
+      rc = sgc_dfa3d_backward(value + (int64_t)b * S * MC, dist + (int64_t)b * S * D, shapes3, lsi, loc3 + i * SPI * 3,
+                              attn_or_null ? attn_or_null + i * SPI : NULL, grad_out + i * MC, grad_value + (int64_t)b * S * MC,
+                              grad_dist + (int64_t)b * S * D, grad_loc3_or_null ? grad_loc3_or_null + i * SPI * 3 : gl_tmp,
+                              grad_attn_or_null ? grad_attn_or_null + i * SPI : ga_tmp, 1, S, Mo, Cmo, D, 1, 1, 1, P, stream);
+    }
+  }
+  free(gl_tmp); free(ga_tmp);
+  return rc;
+}
+
 /* ---- 3. projection + compaction ------------------------------------------ */
 /* VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223.  Fixed order:
  *   p = ref + origin;  cam_r = ((P_r0*x + P_r1*y) + P_r2*z) + P_r3  (no FMA);

@@ -21,6 +21,7 @@ SIGNATURES = {
     "sgc_dfa3d_backward": [_p] * 11 + [_i] * 9 + [_p],
     "sgc_dfa3d_forward_items": [_p] * 9 + [_i] * 9 + [_p],
     "sgc_dfa3d_backward_items": [_p] * 12 + [_i] * 9 + [_p],
+    "sgc_dfa3d_backward_binned": [_p] * 10 + [_i] * 13 + [_p],
     "sgc_project_points": [_p] * 6 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 9 + [_p],
@@ -86,6 +87,7 @@ INTROSPECTION = {
     "sgc_conv3d_winograd_z_workspace_floats": (C.c_int64, [_i] * 5),
     "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
+    "sgc_dfa3d_backward_binned_lds_bytes": (C.c_int64, [_i] * 8),
 }
 
 ABI_VERSION = 4      # == SGC_ABI_VERSION of include/sgcdet_amd.h (tests/test_abi_cpu.py compares the two)

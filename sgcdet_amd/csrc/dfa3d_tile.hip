@@ -238,8 +238,12 @@ template <> __device__ __forceinline__ float4 load_chunk<2>(const unsigned char 
                      __uint_as_float(u.y & 0xffff0000u));
 }
 
-template <int CM, int NW, bool DL, int NBUF, int VB>
+// DS (with DL, one head per workgroup): the staged depth window IS the head's value window (same origin, same extent), so a corner's
+// depth row is its value row and one window test serves both -- 14 vector instructions per step less in phase 1, which is what bounds
+// the kernel at Cm = 16 (round-6 counters: the vector ALU is busy 83 % of the kernel's time, profiles/r06_pmc_gather_cm16.json)
+template <int CM, int NW, bool DL, int NBUF, int VB, bool DS = false>
 __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParams p) {
+  static_assert(!DS || (DL && NBUF == 1), "DS: depth window in LDS, one head per workgroup");
   constexpr int P = 4;
   constexpr int NCH = CM / 16;          // 16-byte chunks of a row per lane in phase 2 (a unit's 4 lanes cover the row)
   constexpr int CV = CM / 4;            // 16-byte chunks per row
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       const bool in3 = in2 & (d_im > -1.f) & (d_im < fD);
       const float hf = floorf(h_im), wf = floorf(w_im), df = floorf(d_im);
       // (int) of a huge float is undefined: clamp the floats first (in2 / in3 already hold the decision)
-      const int h0 = (int)fminf(fmaxf(hf, -2.f), fH), w0 = (int)fminf(fmaxf(wf, -2.f), fW);
-      const int d0 = (int)fminf(fmaxf(df, -2.f), fD);
+      const int h0 = (int)__builtin_amdgcn_fmed3f(hf, -2.f, fH), w0 = (int)__builtin_amdgcn_fmed3f(wf, -2.f, fW);
+      const int d0 = (int)__builtin_amdgcn_fmed3f(df, -2.f, fD);
       const float lh = h_im - hf, lw = w_im - wf, ld = d_im - df;
       const float hh = 1.f - lh, hw = 1.f - lw, hd = 1.f - ld;
       const int dbase = min(max(d0, 0), Dm2);
@@ -399,10 +403,16 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
         const int trow_in = __mul24(ty, p.tw) + tx;
         trow[k] = inside[k] ? trow_in : npx;
         if (DL) {
-          const int dx = cw - xd0, dy = ch - yd0;
-          const bool din = ((unsigned)dx < (unsigned)p.dw) & ((unsigned)dy < (unsigned)p.dh);
-          const int drow = __mul24(dy, p.dw) + dx;
-          const unsigned char *dp = dep + (__mul24(din ? drow : 0, p.D) + dbase) * DB;
+          bool din;
+          int drow;
+          if constexpr (DS) {
+            din = inside[k]; drow = trow_in;
+          } else {
+            const int dx = cw - xd0, dy = ch - yd0;
+            din = ((unsigned)dx < (unsigned)p.dw) & ((unsigned)dy < (unsigned)p.dh);
+            drow = __mul24(dy, p.dw) + dx;
+          }
+          const unsigned char *dp = dep + (__umul24((unsigned)(din ? drow : 0), (unsigned)p.D) + (unsigned)dbase) * DB;
           if constexpr (DB == 4) { ta[k] = reinterpret_cast<const float *>(dp)[0]; tb[k] = reinterpret_cast<const float *>(dp)[1]; }
           else depth_pair(dp, ta[k], tb[k]);
           need_g |= in3 & ok[k] & !din;
@@ -428,11 +438,13 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       for (int k = 0; k < 4; ++k) {
         const float va = d0ok ? (dlo ? ta[k] : tb[k]) : 0.f;
         const float vb = d1ok ? (dlo ? tb[k] : ta[k]) : 0.f;
-        const float sc = (in3 & ok[k]) ? va * hd + vb * ld : 0.f;
+        const float sc = va * hd + vb * ld;
         const float bil = (k == 0 ? hh * hw : k == 1 ? hh * lw : k == 2 ? lh * hw : lh * lw);
-        wgt[k] = in2 ? bil * sc * aw : 0.f;
+        // ok[k] holds the 2-D gate and in3 implies it: ONE select instead of the score's and the weight's (a gated-off score is 0, and
+        // bil * 0 * aw is 0 for the finite operands the maps hold)
+        wgt[k] = (in3 & ok[k]) ? bil * sc * aw : 0.f;
         const bool fb = ok[k] & !inside[k];
-        rowb[k] = (unsigned)__mul24(ok[k] ? trow[k] : npx, CM * VB);       // outside the map / outside the window -> zero row
+        rowb[k] = (unsigned)(ok[k] ? trow[k] : npx) * (unsigned)(CM * VB); // outside the map / outside the window -> zero row (a shift)
         fbs[k] = fb ? (kFallbackBit | (unsigned)pix[k]) : 0u;
         any_fb |= fb;
       }
@@ -534,6 +546,7 @@ int g_tune_tile_xcd = -1;       // 1: camera n's workgroups on XCD n % 8 (head-m
                                 // camera's depth map was fetched through all eight L2s.  Config 4 (Cm = 16, depth window in LDS) was
                                 // 8 % slower with 1 (round 2: 385 vs 420 us) and keeps 0.
 int g_tune_tile_hg = 0;         // heads per workgroup.  auto: 1 (most workgroups: (camera, bin, head))
+int g_tune_tile_ds = 1;         // 1: one window test for value and depth where the two windows coincide (template flag DS); 0: A/B
 
 }  // namespace sgc
 
@@ -617,13 +630,21 @@ extern "C" int sgc_tile_window(int H, int W, int Cm, int D, int bin_w, int bin_h
   return SGC_OK;
 }
 
+template <int CM, int NW, bool DL, int NBUF, int VB, bool DS>
+static int launch_tile_ds(const TileParams &p, size_t smem, hipStream_t st) {
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void *)dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB, DS>, 160 * 1024, attr_done);
+  const int64_t grid = (int64_t)(p.xcd_map ? (p.N + 7) / 8 * 8 : p.N) * p.nbx * p.nby * (p.M / p.HG);
+  hipLaunchKernelGGL((dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB, DS>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
+  return check_launch("dfa3d_fwd_tile_kernel");
+}
+
 template <int CM, int NW, bool DL, int NBUF, int VB>
 static int launch_tile(const TileParams &p, size_t smem, hipStream_t st) {
-  static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>, 160 * 1024, attr_done);
-  const int64_t grid = (int64_t)(p.xcd_map ? (p.N + 7) / 8 * 8 : p.N) * p.nbx * p.nby * (p.M / p.HG);
-  hipLaunchKernelGGL((dfa3d_fwd_tile_kernel<CM, NW, DL, NBUF, VB>), dim3((unsigned)grid), dim3(NW * 64), smem, st, p);
-  return check_launch("dfa3d_fwd_tile_kernel");
+  if constexpr (DL && NBUF == 1) {
+    if (g_tune_tile_ds && p.HG == 1 && p.dw == p.tw && p.dh == p.th) return launch_tile_ds<CM, NW, DL, NBUF, VB, true>(p, smem, st);
+  }
+  return launch_tile_ds<CM, NW, DL, NBUF, VB, false>(p, smem, st);
 }
 
 extern "C" int sgc_pairs_deform_gather_tiled(const void *value_hm, int value_bf16, const void *dist, const float *pair_ref,

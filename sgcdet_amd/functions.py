@@ -114,7 +114,10 @@ class PairListDeformAttnFunction(Function):
 
     @staticmethod
     def forward(ctx, value, value_dpt_dist, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, item_batch):
+                attention_weights, item_batch, bins=None):
+        """``bins`` (one level only): (bin_offset, H, W, bin_w, bin_h, halo) when the items are in the (camera, bin) order of
+        ``sgc_bin_pairs`` -- the backward then takes the LDS-tiled kernel (``sgc_dfa3d_backward_binned``) instead of the item kernel's
+        global atomics.  The forward does not care about the order."""
         value = value.float().contiguous()
         value_dpt_dist = value_dpt_dist.float().contiguous()
         sampling_locations = sampling_locations.float().contiguous()
@@ -124,15 +127,30 @@ class PairListDeformAttnFunction(Function):
                                             sampling_locations, attention_weights, item_batch)
         ctx.save_for_backward(value, value_dpt_dist, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights, item_batch)
+        ctx.bins = bins
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         value, dist, shapes3, lsi, loc, attn, item_batch = ctx.saved_tensors
-        gv, gd, gl, ga = ext.ops().dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, item_batch,
-                                                        grad_output.float().contiguous())
-        return gv, gd, None, None, gl, ga, None
+        ops = ext.ops()
+        grad_output = grad_output.float().contiguous()
+        bins = ctx.bins
+        N, S, M, Cm = value.shape
+        n, LM, L, P = loc.shape[:4]
+        if bins is not None and L == 1 and dist.shape[2] == 1 and n > 0:
+            bin_offset, H, W, bw, bh, halo = bins
+            # the kernel's head split: channel groups of 32 (16) channels; one head over C channels (the geometry sample) runs as C / 32
+            # groups that share its sample set
+            cmb = Cm if Cm in (16, 32) else (32 if Cm % 32 == 0 else 16 if Cm % 16 == 0 else 0)
+            if cmb and (cmb == Cm or M == 1) and P <= 4 and ops.dfa3d_backward_binned_fits(H, W, cmb, dist.shape[-1], bw, bh, halo):
+                mb = M * Cm // cmb
+                gv, gd, gl, ga = ops.dfa3d_backward_binned(value.view(N, S, mb, cmb), dist, loc, attn, bin_offset, grad_output, H, W, bw, bh,
+                                                           halo, want_grad_loc=ctx.needs_input_grad[4], want_grad_attn=ctx.needs_input_grad[5])
+                return gv.view_as(value), gd, None, None, gl, ga, None, None
+        gv, gd, gl, ga = ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, item_batch, grad_output)
+        return gv, gd, None, None, gl, ga, None, None
 
 
 def _require_bf16_planes(who):

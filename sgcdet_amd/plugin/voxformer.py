@@ -66,6 +66,14 @@ TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
                                                                                   # workgroups per CU (27x30: 130 KB, one)
 
 
+# LDS-tiled backward of the two DFA3D calls of a TRAINING level (csrc/dfa3d_bwd_tile.hip, sgc_dfa3d_backward_binned): the training
+# forward bins its pairs like the inference path and the backward accumulates a (camera, bin) window of grad_value / grad_dist in
+# LDS.  ``bin`` / ``halo`` in feature pixels (the window = bin + 2 halo must fit 160 KiB at (Cm + 1 + D) * 4 bytes per pixel); corners
+# outside the window fall back to global atomics, so results never depend on these numbers beyond float-atomic order.
+# Env (A/B): SGC_TRAIN_BWD=0 (the item kernel, one global atomic per corner contribution) | "bin_w,bin_h,halo_x,halo_y".
+TRAIN_BWD_TILED = dict(enabled=True, bin=(16, 22), halo=(3, 3))
+
+
 def _tiled_env_overrides():
     """Sweeps without editing the file: SGC_TILED=0|1, SGC_TILED_CM32 / SGC_TILED_CM16 = "bin_w,bin_h,halo_x,halo_y,depth_in_lds"."""
     import os
@@ -73,6 +81,12 @@ def _tiled_env_overrides():
         TILED_GATHER["enabled"] = os.environ["SGC_TILED"] != "0"
     if os.environ.get("SGC_STORAGE") in ("f32", "bf16"):
         TILED_GATHER["storage"] = os.environ["SGC_STORAGE"]
+    spec = os.environ.get("SGC_TRAIN_BWD")
+    if spec == "0":
+        TRAIN_BWD_TILED["enabled"] = False
+    elif spec:
+        bw, bh, hx, hy = (int(v) for v in spec.split(","))
+        TRAIN_BWD_TILED.update(enabled=True, bin=(bw, bh), halo=(hx, hy))
     for key in ("cm32", "cm16"):
         spec = os.environ.get("SGC_TILED_" + key.upper())
         if spec:
@@ -465,7 +479,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
     # torch ops on [n_pairs, .] rows; the inter-view nn.MultiheadAttention keeps the reference's dense [N, L, C] slots.
     train_pair_list = True
 
-    def _forward_pairs_train(self, query, feat, dist, ref_cam, mask, spatial_shapes, level_start_index):
+    def _forward_pairs_train(self, query, feat, dist, ref_cam, mask, spatial_shapes, level_start_index, spatial_hw=None):
         from ..functions import PairListDeformAttnFunction
         C = self.embed_dims
         N, Nq = mask.shape
@@ -474,23 +488,36 @@ class DeformCrossAttention_DFA3D(BaseModule):
         S = feat.shape[1]
         value = None
         if self.deformable_attn:
-            # issued BEFORE the host syncs below: the value projection depends on the maps only, and its ~140 us of GPU work (config 2)
+            # issued BEFORE the host sync below: the value projection depends on the maps only, and its ~140 us of GPU work (config 2)
             # run while the host waits for the pair count and issues what follows
             from ..functions import linear_rows                    # the Linears' three passes on the MFMA kernels
             value = linear_rows(da.value_proj, feat).view(N, S, M, C // M)
-        # the two data-dependent sizes of the level, read back to back: the second `nonzero` used to sit behind the gathers and
-        # Linears below and drained the queue a second time (the GPU then idles until the host has issued the rest of the level)
-        cam, q = mask.nonzero(as_tuple=True)                         # camera-major, ascending query: the pair list
-        count = mask.sum(0)
-        valid_index = count.nonzero()[:, 0]
-        n_pairs = cam.shape[0]
+        # The pair list, the per-voxel camera counts, `slot` and the compact voxel rows come from the compaction kernels of the
+        # inference path (round 6; before: mask.nonzero / sum / index_put glue, two host syncs and ~10 torch launches per level).
+        # With one feature level the pairs are also BINNED by the pixel of their reference point (sgc_bin_pairs): everything below
+        # runs in that order (`slot` maps (camera, voxel) -> pair as before) and the backward of both DFA3D calls takes the
+        # LDS-tiled kernel (sgc_dfa3d_backward_binned) instead of one global atomic per corner contribution.
+        ops = _ops()
+        mask_u8 = mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+        pc = ops.compact_pairs(mask_u8.contiguous())
+        bins = None
+        if L == 1 and TRAIN_BWD_TILED["enabled"] and feat.is_cuda and C % 16 == 0:
+            H, W = spatial_hw if spatial_hw is not None else tuple(int(v) for v in spatial_shapes[0].tolist())
+            bw, bh = min(TRAIN_BWD_TILED["bin"][0], W), min(TRAIN_BWD_TILED["bin"][1], H)
+            if S >= H * W and ops.dfa3d_backward_binned_fits(H, W, 32 if C % 32 == 0 else 16, dist.shape[-1], bw, bh, TRAIN_BWD_TILED["halo"]):
+                pc = ops.bin_pairs(ref_cam.contiguous(), pc, H, W, bw, bh)
+                bins = (pc["bin_offset"], H, W, bw, bh, tuple(TRAIN_BWD_TILED["halo"]))
+        n_pairs, n_valid = pc["totals"][:2].tolist()                 # the level's one host sync
+        cam, q = pc["pair_cam"][:n_pairs].long(), pc["pair_q"][:n_pairs].long()     # camera-major; inside a camera by bin, or ascending q
+        valid_index = pc["valid_index"][:n_valid].long()
+        count = pc["vox_count"]
         shapes3 = da.get_spatial_shape_3D(spatial_shapes, dist.shape[-1])
         ref = ref_cam[cam, q]                                          # [n_pairs, 3]
-        item = cam.to(torch.int32)
+        item = pc["pair_cam"][:n_pairs]
         geo = PairListDeformAttnFunction.apply(feat.view(N, S, 1, C), dist.view(N, S, 1, -1), shapes3, level_start_index,
                                                ref.view(n_pairs, 1, 1, 1, 3).expand(n_pairs, 1, L, 1, 3).contiguous()
                                                if L > 1 else ref.view(n_pairs, 1, 1, 1, 3),
-                                               torch.ones((n_pairs, 1, L, 1), dtype=feat.dtype, device=feat.device), item)
+                                               torch.ones((n_pairs, 1, L, 1), dtype=feat.dtype, device=feat.device), item, bins)
         if self.deformable_attn:
             off_uv = linear_rows(da.sampling_offsets, geo).view(n_pairs, M, L, P, 2)
             off_d = (geo.new_zeros((n_pairs, M, L, P, 1)) if isinstance(da.sampling_offsets_depth, _ZeroLinear)
@@ -498,7 +525,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
             attn = linear_rows(da.attention_weights, geo).view(n_pairs, M, L * P).softmax(-1).view(n_pairs, M, L, P)
             normalizer = torch.stack([shapes3[..., 1], shapes3[..., 0], shapes3[..., 2]], -1).to(feat.dtype)   # (W, H, D) per level
             loc = ref.view(n_pairs, 1, 1, 1, 3) + torch.cat([off_uv, off_d], -1) / normalizer[None, None, :, None, :]
-            per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item)
+            per_pair = PairListDeformAttnFunction.apply(value, dist.view(N, S, 1, -1), shapes3, level_start_index, loc, attn, item, bins)
             if self.geo_residual:
                 per_pair = per_pair + geo
         else:
@@ -508,11 +535,8 @@ class DeformCrossAttention_DFA3D(BaseModule):
             # inter-view aggregation on the pair list as well: no dense [N, L, C] slots (262 MB at config 2), K/V in-projected
             # for visible pairs only, the softmax over views and its backward on sgc_view_attend(_backward)
             from ..functions import LinearRowsFunction, ViewAttendFunction, linear_rows
-            n_valid = valid_index.shape[0]
-            slot = torch.full((N, Nq), -1, dtype=torch.int32, device=feat.device)
-            slot[cam, q] = torch.arange(n_pairs, dtype=torch.int32, device=feat.device)
-            row_of = torch.full((Nq,), -1, dtype=torch.int64, device=feat.device)
-            row_of[valid_index] = torch.arange(n_valid, device=feat.device)
+            slot = pc["slot"]                        # (camera, voxel) -> pair row (in the binned order when binned), -1 = not visible
+            row_of = pc["row_of"].long()             # voxel -> compact row of `valid_index`, -1 = seen by no camera
             mean = torch.zeros((n_valid, C), dtype=per_pair.dtype, device=feat.device).index_add(0, row_of[q], per_pair)
             pooled = linear_rows(self.output_proj, mean / count[valid_index][:, None])
             if self.inter_view_aggregation == "attn":
@@ -520,12 +544,12 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 w, b = mha.in_proj_weight, mha.in_proj_bias
                 qv = LinearRowsFunction.apply(pooled, w[:C], b[:C])
                 kv = LinearRowsFunction.apply(per_pair, w[C:], b[C:])                  # [n_pairs, 2C] = k | v
-                ctx = ViewAttendFunction.apply(qv, kv, slot, valid_index.to(torch.int32), mha.num_heads)
+                ctx = ViewAttendFunction.apply(qv, kv, slot, pc["valid_index"][:n_valid], mha.num_heads)
                 pooled = LinearRowsFunction.apply(ctx, mha.out_proj.weight, mha.out_proj.bias)
         else:
             slots = torch.zeros((N, Nq, C), dtype=feat.dtype, device=feat.device).index_put((cam, q), per_pair)
             valid_slots = slots[:, valid_index]                                # [N,L,C]
-            valid_mask = mask[:, valid_index]                                  # [N,L]
+            valid_mask = mask.bool()[:, valid_index]                           # [N,L]
             pooled = (valid_slots * valid_mask[..., None]).sum(0) / count[valid_index][:, None]
             pooled = self.output_proj(pooled)
             if self.inter_view_aggregation == "attn":
@@ -597,8 +621,11 @@ class DeformCrossAttention_DFA3D(BaseModule):
         dist, ref_cam = self._depth_inputs(value_dpt_dist, reference_points_cam, N, S, Nq, feat)
         if torch.is_grad_enabled() and (query.requires_grad or feat.requires_grad or dist.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
-            fn = self._forward_pairs_train if self.train_pair_list else self._forward_reference_layout
-            return fn(query, feat, dist, ref_cam, bev_mask.reshape(N, Nq).bool(), spatial_shapes, level_start_index)
+            if self.train_pair_list:
+                return self._forward_pairs_train(query, feat, dist, ref_cam, bev_mask.reshape(N, Nq), spatial_shapes, level_start_index,
+                                                 spatial_hw=kwargs.get("spatial_hw"))
+            return self._forward_reference_layout(query, feat, dist, ref_cam, bev_mask.reshape(N, Nq).bool(), spatial_shapes,
+                                                  level_start_index)
         if spatial_shapes.shape[0] != 1:
             raise NotImplementedError("pair-list path supports one feature level per call (all SGCDet configs)")
         hw = kwargs.get("spatial_hw")

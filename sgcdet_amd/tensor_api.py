@@ -219,6 +219,41 @@ class TensorOps:
                        grad_dist, grad_loc3, grad_attn, B, S, M, Cm, D, dist_heads, L, n, P)
         return grad_value, grad_dist, grad_loc3, grad_attn
 
+    def dfa3d_backward_binned_fits(self, H, W, Cm, D, bin_w, bin_h, halo):
+        """Does the (bin + halo) window of the binned backward fit the LDS of a CU?"""
+        n = int(self.lib._dll.sgc_dfa3d_backward_binned_lds_bytes(int(H), int(W), int(Cm), int(D), int(bin_w), int(bin_h),
+                                                                   int(halo[0]), int(halo[1])))
+        return 0 < n <= 160 * 1024 and Cm in (16, 32)
+
+    def dfa3d_backward_binned(self, value, dist, loc3, attn, bin_offset, grad_out, H, W, bin_w, bin_h, halo=(2, 2),
+                              want_grad_loc=True, want_grad_attn=True):
+        """Backward of the one-level DFA3D operator over a BINNED item list (``sgc_dfa3d_backward_binned``): items in the
+        (camera, bin) order of ``bin_pairs``.  value [N,S,M,Cm]; dist [N,S,D] or [N,S,1,D]; loc3 [n,LM,(1,)P,3]; attn
+        [n,LM,(1,)P] or None (= 1); grad_out [n, M*Cm].  LM = M, or 1 = one sample set shared by the M channel groups."""
+        self._check(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn, bin_offset=bin_offset,
+                    grad_output=grad_out)
+        self._f32(value=value, value_dpt_dist=dist, sampling_locations=loc3, attention_weights=attn, grad_output=grad_out)
+        if bin_offset.dtype != torch.int32:
+            raise RuntimeError("bin_offset must be int32")
+        N, S, M, Cm = value.shape
+        D = dist.shape[-1]
+        if dist.numel() != N * S * D:
+            raise RuntimeError("dfa3d_backward_binned: one depth map per camera expected (dist_heads == 1)")
+        n, LM, P = loc3.shape[0], loc3.shape[1], loc3.shape[-2]
+        if loc3.numel() != n * LM * P * 3 or grad_out.shape != (n, M * Cm) or (attn is not None and attn.numel() != n * LM * P):
+            raise RuntimeError("dfa3d_backward_binned: inconsistent shapes")
+        nb = -(-W // bin_w) * -(-H // bin_h)
+        if bin_offset.numel() < N * nb + 1:
+            raise RuntimeError("dfa3d_backward_binned: bin_offset too short for these bins")
+        grad_value = torch.zeros_like(value)
+        grad_dist = torch.zeros_like(dist)
+        grad_loc3 = torch.empty_like(loc3) if want_grad_loc else None
+        grad_attn = torch.empty(loc3.shape[:-1], dtype=value.dtype, device=value.device) if want_grad_attn else None
+        if n:
+            self._call("sgc_dfa3d_backward_binned", value, dist, loc3, attn, bin_offset, grad_out, grad_value, grad_dist, grad_loc3,
+                       grad_attn, N, S, int(H), int(W), M, Cm, D, LM, P, int(bin_w), int(bin_h), int(halo[0]), int(halo[1]))
+        return grad_value, grad_dist, grad_loc3, grad_attn
+
     # ---- 3. projection + compaction ---------------------------------------
     def project_points(self, ref3d, origin, proj, img_w, img_h, d_near, d_far, sel=None):
         """``sel``: optional int64 [Nq] -- query q is voxel ``sel[q]`` of ``ref3d`` (the reference gathers

@@ -688,6 +688,116 @@ def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
         close(a, b, tol=2e-5)
 
 
+@pytest.mark.parametrize("Cm,HW,bins,halo,spread", [
+    (32, (29, 40), (16, 22), (3, 3), 0.08),     # the training default: bins of the forward, window 22 x 28
+    (32, (15, 20), (7, 5), (1, 1), 0.25),       # small windows, far offsets: many corners take the global fall-back
+    (16, (30, 40), (13, 10), (2, 2), 0.10),     # Cm = 16 (the C = 128 configs)
+    (16, (14, 20), (20, 14), (0, 0), 0.30),     # one bin per camera: the window is the whole map
+])
+def test_binned_backward_against_oracle(Cm, HW, bins, halo, spread, oracle_ops, gpu_ops):
+    """sgc_dfa3d_backward_binned (LDS-tiled backward of the training path, round 6) against the oracle's item backward on the same
+    items: grad_value, grad_dist, every grad_loc entry and grad_attn within 2e-5 of the scale (the bound of the item kernel's test);
+    the result must not depend on the bins, the halo or the workgroup size; the shared-sample form (one head over C channels run
+    as channel groups: the geometry sample) against the oracle's one-head operator; and the HIP item kernel as a second opinion."""
+    N, Nq, D, M, P = 5, 700, 12, 8, 4
+    H, W = HW
+    ref3d, origin, proj = _scene(N, Nq, 9)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = oracle_ops.compact_pairs(mk)
+    n = int(pc["totals"][0])
+    assert n > 300
+    g = torch.Generator().manual_seed(5 + Cm)
+    S = H * W
+    value = torch.randn(N, S, M, Cm, generator=g)
+    dist = torch.randn(N, S, 1, D, generator=g).mul(2).softmax(-1).contiguous()
+    shapes3 = torch.tensor([[H, W, D]], dtype=torch.int64)
+    lsi = torch.zeros(1, dtype=torch.int64)
+    cu = lambda t: t.cuda()
+    gpc = {k: cu(v) for k, v in pc.items()}
+    for bw, bh, hx, hy in [(bins[0], bins[1], halo[0], halo[1]), (max(1, bins[0] // 2), bins[1] + 3, 1, 2)]:
+        b = gpu_ops.bin_pairs(cu(rc), dict(gpc, slot=gpc["slot"].clone()), H, W, bw, bh)
+        cam, q = b["pair_cam"][:n].cpu().long(), b["pair_q"][:n].cpu().long()
+        ref = rc[cam, q]                                                       # the items' reference points, binned order
+        loc = (ref.view(n, 1, 1, 1, 3) + (torch.rand(n, M, 1, P, 3, generator=g) - 0.5) * spread).contiguous()
+        attn = torch.rand(n, M, 1, P, generator=g)
+        go = torch.randn(n, M * Cm, generator=g)
+        want = oracle_ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, cam.to(torch.int32), go)
+        try:
+            for nw in (8, 4, 16):
+                gpu_ops.lib.call("sgc_set_tuning", b"bwd_tile_nw", nw)
+                got = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc), cu(attn), b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy))
+                for a, w_ in zip(got, want):
+                    close(a, w_, tol=2e-5)
+        finally:
+            gpu_ops.lib.call("sgc_set_tuning", b"bwd_tile_nw", 8)
+        item_k = gpu_ops.dfa3d_backward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(cam.to(torch.int32)), cu(go))
+        for a, w_ in zip(got, item_k):
+            close(a, w_, tol=2e-5)
+        # the oracle's own binned twin walks the bins: same numbers as its item form
+        twin = oracle_ops.dfa3d_backward_binned(value, dist, loc, attn, b["bin_offset"].cpu(), go, H, W, bw, bh, (hx, hy))
+        for a, w_ in zip(twin, want):
+            close(a, w_, tol=1e-6)
+    # one sample set shared by the M channel groups, no attention weights, P = 1: the geometry sample's single head over C = M * Cm
+    loc1 = (ref.view(n, 1, 1, 1, 3) + (torch.rand(n, 1, 1, 1, 3, generator=g) - 0.5) * spread).contiguous()
+    go = torch.randn(n, M * Cm, generator=g)
+    want1 = oracle_ops.dfa3d_backward_items(value.view(N, S, 1, M * Cm), dist, shapes3, lsi, loc1, torch.ones(n, 1, 1, 1), cam.to(torch.int32), go)
+    got1 = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc1), None, b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy))
+    close(got1[0].view(N, S, 1, M * Cm), want1[0], tol=2e-5)
+    for a, w_ in zip(got1[1:], want1[1:]):
+        close(a, w_, tol=2e-5)
+    # gradients nobody asked for are not written
+    gv, gd, gl, ga = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc1), None, b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy),
+                                                   want_grad_loc=False, want_grad_attn=False)
+    assert gl is None and ga is None
+    close(gv.view(N, S, 1, M * Cm), want1[0], tol=2e-5)
+    close(gd, want1[1], tol=2e-5)
+
+
+def test_training_level_takes_the_binned_backward_and_keeps_its_gradients(gpu_ops):
+    """DeformCrossAttention_DFA3D in training mode: with the LDS-tiled backward (pairs binned, default) and with the item kernel
+    (SGC_TRAIN_BWD=0 / TRAIN_BWD_TILED disabled, pairs in ascending-voxel order) the loss and every parameter / input gradient agree to
+    float-atomic noise -- the pair ORDER and the backward kernel are scheduling choices, not part of the function."""
+    import sgcdet_amd.plugin  # noqa: F401
+    from sgcdet_amd.plugin import voxformer
+    from sgcdet_amd.mmcv_lite import build_attention
+    torch.manual_seed(3)
+    C, N, Nq, D = 256, 6, 500, 12
+    H, W = 29, 40
+    att = build_attention(dict(type="DeformCrossAttention_DFA3D", embed_dims=C, inter_view_aggregation="attn", dropout=0.0,
+                               deformable_attention=dict(type="MSDeformableAttention3D_DFA3D", embed_dims=C, num_heads=8, num_points=4,
+                                                         num_levels=1))).cuda().train()
+    with torch.no_grad():
+        for prm in att.parameters():
+            prm.add_(torch.randn_like(prm) * 0.02)
+    ref3d, origin, proj = _scene(N, Nq, 11)
+    rc, mk = gpu_ops.project_points(ref3d.cuda(), origin.cuda(), proj.cuda(), 320., 239., 0.2, 5.0)
+    g = torch.Generator().manual_seed(8)
+    feat0 = torch.randn(N, H * W, 1, C, generator=g).cuda()
+    dist0 = torch.randn(N, H * W, 1, D, generator=g).mul(2).softmax(-1).cuda()
+    query0 = torch.randn(1, Nq, C, generator=g).cuda()
+    shapes = torch.tensor([[H, W]], dtype=torch.int64).cuda()
+    lsi = torch.zeros(1, dtype=torch.int64).cuda()
+    results = []
+    for enabled in (True, False):
+        old = dict(voxformer.TRAIN_BWD_TILED)
+        voxformer.TRAIN_BWD_TILED["enabled"] = enabled
+        try:
+            feat, dist, query = feat0.clone().requires_grad_(), dist0.clone().requires_grad_(), query0.clone().requires_grad_()
+            att.zero_grad()
+            out = att(query, feat, feat, reference_points_cam=rc.view(N, 1, Nq, 1, 3), bev_mask=mk.view(N, 1, Nq, 1), spatial_shapes=shapes,
+                      level_start_index=lsi, value_dpt_dist=dist, spatial_hw=(H, W))
+            loss = (out * torch.linspace(-1, 1, C, device="cuda")).sum()
+            loss.backward()
+            results.append((loss.detach(), feat.grad, dist.grad, query.grad, {k: p.grad.clone() for k, p in att.named_parameters()}))
+        finally:
+            voxformer.TRAIN_BWD_TILED.update(old)
+    (l1, f1, d1, q1, p1), (l0, f0, d0, q0, p0) = results
+    close(l1, l0, tol=1e-5)
+    close(f1, f0, tol=5e-5); close(d1, d0, tol=5e-5); close(q1, q0, tol=5e-5)
+    for k in p0:
+        close(p1[k], p0[k], tol=1e-4)
+
+
 @pytest.mark.parametrize("n,k", [(204800, 51200), (294912, 73728), (25600, 6400), (16385, 1), (20000, 20000), (40961, 40960)])
 def test_topk_many_workgroup_form_equals_the_one_workgroup_form(n, k, gpu_ops):
     """sgc_topk_select_ws (histogram / count / compaction launches over 4096-candidate chunks) against the one-workgroup

@@ -107,7 +107,8 @@ res = []
 for cfg in configs:
     bw, bh, hx, hy, dl, nw, sh, nbuf, hg = cfg[:9]
     xcd = cfg[9] if len(cfg) > 9 else int(os.environ.get("SGC_TILE_XCD", "0"))        # optional 10th field: tile_xcd
-    for key, val in (("tile_nw", nw), ("tile_nbuf", nbuf), ("tile_hg", hg), ("tile_xcd", xcd)):
+    ds = cfg[10] if len(cfg) > 10 else 1                                               # optional 11th field: tile_ds (one window test for value and depth)
+    for key, val in (("tile_nw", nw), ("tile_nbuf", nbuf), ("tile_hg", hg), ("tile_xcd", xcd), ("tile_ds", ds)):
         ops.lib.call("sgc_set_tuning", key.encode(), val)
     hs = head_shift if sh else None
     ms = max_shift if sh else (0, 0)
@@ -131,7 +132,7 @@ for cfg in configs:
         print("failed", (bw, bh, hx, hy, dl, nw, sh, nbuf, hg), e)
         continue
     err = (o[:n_pairs] - ref[old]).abs().max().item()
-    line = (f"tile bin {bw:2d}x{bh:2d} halo {hx},{hy} dl {dl}->{geo['depth_in_lds']} nw {nw:2d} shift {sh} nbuf {nbuf}->{geo['nbuf']} hg {hg} xcd {xcd} "
+    line = (f"tile bin {bw:2d}x{bh:2d} halo {hx},{hy} dl {dl}->{geo['depth_in_lds']} nw {nw:2d} shift {sh} nbuf {nbuf}->{geo['nbuf']} hg {hg} xcd {xcd} ds {ds} "
             f"win {geo['tw']}x{geo['th']} ({geo['lds_bytes'] / 1024:5.1f} KB) {t:8.1f} us  {alg / t / 1e3 / 8000:.3f}  (bin {tb - 0:5.1f} us incl. slot clone)  "
             f"err {err:.1e}")
     if os.environ.get("SGC_TILE_DIAG"):
