@@ -9,20 +9,33 @@
 // rate) and 8 single-dword atomics per sample for grad_dist (64 lanes in 64 different rows: ~17x slower per byte,
 // MI355X_MICROARCH.md "Global float atomics") -- 2.45 ms of a 17.9-ms training step.  Here the forward's binning is
 // reused (sgc_bin_pairs: a camera's pairs grouped by the feature pixel their reference point projects to), so the
-// corners of a workgroup's pairs fall into one window of the map:
-//   * a workgroup owns (camera, bin) and walks the heads; per head the window's slice of grad_value ([th][tw][Cm] fp32)
-//     lives in LDS and takes the corner contributions as LDS atomics (ds_add_f32; rows pitched Cm + 1 floats so that the
-//     rows of different pixels start on different banks); the window is flushed ONCE per head with global float atomics
-//     (whole 64- / 128-byte head segments per pixel row: the full-rate shape) -- windows of neighbouring bins overlap by
-//     their halos, so the flush has to add, but it adds each touched element once per bin instead of once per sample;
-//   * grad_dist ([th][tw][D], shared by the heads: dist_heads == 1 on this path) is accumulated in LDS over ALL heads
-//     and flushed once per workgroup;
-//   * corners outside the window (large learned offsets) fall back to the global atomics of the item kernel, lane by lane;
-//   * lanes as in the tiled forward: phase 1 one lane per sample (unit = (pair, head): 4 lanes = its 4 points), phase 2 in
-//     the unit's quad -- lane c owns channels 4c .. 4c+3 (+16 for Cm = 32), sample descriptors by DPP quad broadcasts, the
-//     per-sample scalars (d/dx, d/dy, d/dattn, d/dscore[4]) reduced over the quad by two DPP steps.
-// Float atomics (LDS and global) make grad_value / grad_dist order-dependent in the last bits, like the item kernel and
-// like the reference's atomicAdd; grad_loc / grad_attn are written by their owning lane (deterministic).
+// corners of a workgroup's pairs fall into one window of the map, and a workgroup = (camera, bin, head) keeps that
+// head's window of grad_value ([th][tw][Cm] fp32) in LDS.
+//
+// LDS float atomics are NOT the way to fill it: measured (tools/bwd_tile_bench.py, round 6) a ds_add_f32 wave instruction
+// takes ~240 cycles -- the first form of this kernel, one ds_add per corner element, ran 2.96 ms against the item
+// kernel's 1.88 and 0.58 ms with the adds removed.  So nobody adds atomically; the window has OWNERS:
+//   phase A  (lanes as in the tiled forward: a unit = (pair, head) is a quad, lane = (unit, point) for the sample
+//            arithmetic, lane c = channels 4c .. 4c+3 (+16) for the row arithmetic)  every sample's descriptor -- LDS
+//            offsets of its two window rows and the four corner weights bil * score * attn -- goes to a queue in LDS,
+//            the unit's grad_out row beside it; the per-sample scalars (d/dx, d/dy, d/dattn, d/dscore[4]) are reduced
+//            over the quad by two DPP steps and finished by the sample's own lane (depth-score backward, grad_loc /
+//            grad_attn); corners that are in the map but outside the window take the item kernel's global atomic;
+//   phase B  window row y belongs to wave y % NW: phase A appends each sample's two row entries to the OWNER's queue (one sub-queue
+//            per (owner, producing wave), slots by ballot + popcount: no atomics), and every wave walks only its own entries
+//            (wave-uniform control flow): lane = (pixel of the row pair, channel), a plain ds_read / fma / ds_write of 2 x Cm
+//            consecutive floats -- no conflicts inside the instruction (two adjacent pixels), none between waves (disjoint
+//            rows); a wave's own accesses to one address stay in program order (two entries are in flight together only when
+//            their pixel pairs do not overlap).
+// The window is flushed ONCE with global float atomics (whole 64- / 128-byte head segments per pixel row: the full-rate
+// shape): windows of neighbouring bins overlap by their halos, so the flush has to add, but it adds each touched element
+// once per (bin, head) instead of once per sample.  grad_dist ([th][tw][D] per workgroup; dist_heads == 1) takes the few
+// depth atomics (8 per sample against 512 row elements) in LDS and is flushed the same way.
+// Float atomics make grad_value / grad_dist order-dependent in the last bits, like the item kernel and like the
+// reference's atomicAdd; grad_loc / grad_attn are written by their owning lane (deterministic) -- except for a sample set
+// shared by the channel groups (loc_heads == 1 < M), whose gradients are summed over the groups' workgroups atomically.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace sgc {
@@ -39,11 +52,14 @@ struct BwdTileParams {
   float *grad_attn;            // [items][LM][P] or null
   int N, S, H, W, D, M, LM, P;
   int bw, bh, nbx, nby, tw, th, hx, hy;
+  int diag;                    // TIMING ONLY (sgc_set_tuning "bwd_tile_diag", honoured with SGC_DIAG=1): 1 no phase B, 2 no flush,
+                               // 4 no value-row loads, 8 no depth atomics, 16 no row arithmetic in phase A
 };
 
-// LDS pointers carry their address space in the type: through the lambda below the compiler no longer proves that a plain float *
+// LDS pointers carry their address space in the type: through a lambda the compiler no longer proves that a plain float *
 // points into LDS and emits flat atomics (the slow path of both memories)
 typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) int lds_int;
 __device__ __forceinline__ void lds_add(lds_float *q, float v) { __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int S> __device__ __forceinline__ float qb(float v) { return dpp_move<S | (S << 2) | (S << 4) | (S << 6)>(v); }
@@ -51,15 +67,21 @@ template <int S> __device__ __forceinline__ int qbi(int v) {
   return __builtin_amdgcn_update_dpp(0, v, S | (S << 2) | (S << 4) | (S << 6), 0xf, 0xf, true);
 }
 
+constexpr int kBtQueue = 64;   // entries per (owner, producer) sub-queue: a lane's two rows have different owners, so a wave step adds <= 64
+struct __attribute__((aligned(16))) BtEntry { int off; float w0, w1; int unit; };     // window float index of (row, first pixel, channel 0);
+                                                                                      // weights of the two adjacent pixels; unit slot of the batch
+
+// (Measured and not kept, tools/bwd_tile_bench.py on the finest config-2 level: eight waves per workgroup -- 2.7 ms against 1.57 with
+//  four, in every form of phase B; producer and owner roles on different waves with double-buffered queues -- 2.7 ms: a bin holds
+//  ~70 pairs, i.e. one full batch and a remainder, so there is nothing to overlap.)
 template <int CM, int NW>
 __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTileParams p) {
   constexpr int NCH = CM / 16;           // 16-byte chunks of a head row per lane (a unit's 4 lanes cover the row)
-  constexpr int CMP = CM + 1;            // LDS row pitch in floats: odd, so the rows of different pixels start on different banks
-  constexpr int UPW = 16, NT = NW * 64;
+  constexpr int UPW = 16, NT = NW * 64, UB = NW * UPW;       // units per wave step / per batch of the workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char bt_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nb = p.nbx * p.nby;
-  const int t = blockIdx.x;                                         // (camera, bin)
+  const int m = blockIdx.x % p.M, t = blockIdx.x / p.M;             // (camera, bin), head innermost: a bin's heads run side by side
   const int i0 = p.bin_offset[t], i1 = p.bin_offset[t + 1];
   if (i0 >= i1) return;
   const int cnt = i1 - i0;
@@ -67,9 +89,13 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
   const int by = b / p.nbx, bx = b - by * p.nbx;
   const int npx = p.tw * p.th;
   const int x0 = max(0, min(bx * p.bw - p.hx, p.W - p.tw)), y0 = max(0, min(by * p.bh - p.hy, p.H - p.th));
-  lds_float *gval = (lds_float *)bt_smem;                           // [npx][CMP]
-  lds_float *gdist = gval + npx * CMP;                              // [npx][D]
-  for (int i = tid; i < npx * CMP + npx * p.D; i += NT) gval[i] = 0.f;
+  lds_float *win = (lds_float *)bt_smem;                            // [npx][CM]
+  lds_float *gdist = win + npx * CM;                                // [npx][D]
+  lds_float *tops = gdist + npx * p.D;                              // [UB][CM]: grad_out rows of the batch's units
+  typedef __attribute__((address_space(3))) BtEntry lds_entry;
+  lds_entry *queue = (lds_entry *)(win + ((npx * (CM + p.D) + UB * CM + 3) & ~3));     // [owner][producer][kBtQueue], 16-byte aligned
+  lds_int *qcount = (lds_int *)(queue + NW * NW * kBtQueue);        // [owner][producer]
+  for (int i = tid; i < npx * CM + npx * p.D; i += NT) win[i] = 0.f;
   const int MC = p.M * CM;
   const float *vcam = p.value + (int64_t)n * p.S * MC;
   float *gvcam = p.grad_value + (int64_t)n * p.S * MC;
@@ -77,34 +103,80 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
   float *gdcam = p.grad_dist + (int64_t)n * p.S * p.D;
   const int ul = lane >> 2, pt = lane & 3, c16 = lane & 3;
   const float fW = (float)p.W, fH = (float)p.H, fD = (float)p.D;
-  __syncthreads();
+  const int lm = p.LM == 1 ? 0 : m;
+  const bool shared_samples = p.LM == 1 && p.M > 1;                 // gradients of the sample set are summed over the groups' workgroups
 
-  for (int m = 0; m < p.M; ++m) {
-    const int lm = p.LM == 1 ? 0 : m;
-    for (int g0 = wid * UPW; g0 < cnt; g0 += NW * UPW) {
-      const bool unit_live = g0 + ul < cnt;
-      const int item = i0 + min(g0 + ul, cnt - 1);
-      // ---------------- phase 1: lane = (unit, point) ----------------
+  for (int base = 0; base < cnt; base += UB) {
+    __syncthreads();                                                // window zeroed / the previous batch's queues are consumed
+    // ======================= phase A =======================
+    {
+      const int us = wid * UPW + ul;                                // unit slot in the batch
+      const bool unit_live = base + us < cnt;
+      const int item = i0 + min(base + us, cnt - 1);
       const bool samp_live = unit_live && pt < p.P;
       const int64_t g = ((int64_t)item * p.LM + lm) * p.P + min(pt, p.P - 1);
       const float x = p.loc[g * 3], y = p.loc[g * 3 + 1], z = p.loc[g * 3 + 2];
       const float aw = p.attn ? p.attn[g] : 1.f;
       Sample sm;
       make_sample(sm, dcam, p.D, p.H, p.W, p.D, x, y, z, 1.f);
-      const int h0 = (int)fminf(fmaxf(floorf(sample_coord(y, fH)), -2.f), fH);
-      const int w0 = (int)fminf(fmaxf(floorf(sample_coord(x, fW)), -2.f), fW);
+      const int h0 = (int)__builtin_amdgcn_fmed3f(floorf(sample_coord(y, fH)), -2.f, fH);
+      const int w0 = (int)__builtin_amdgcn_fmed3f(floorf(sample_coord(x, fW)), -2.f, fW);
       // bit k: corner k (gather order (h0,w0) (h0,w1) (h1,w0) (h1,w1)) lies in the map and the sample passes the 2-D gate
       int okm = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) okm |= (samp_live && sm.off[k] >= 0) ? (1 << k) : 0;
       const float sgx = sm.s[0], sgy = sm.s[1], sgz = sm.s[3], sgw = sm.s[2];      // gather order
+      // ---- this lane's sample -> the queue.  Window rows ty0 = h0 - y0, ty0 + 1; pixels tx0 = w0 - x0, tx0 + 1.  A row pair is applied
+      //      as TWO ADJACENT window pixels starting at bx0 = clamp(tx0, 0, tw - 2): the weights move with the clamp, a corner whose
+      //      pixel is outside the window keeps weight 0 here (the row arithmetic below adds it with a global atomic) ----
+      {
+        const float hh = 1.f - sm.lh, hw = 1.f - sm.lw;
+        const float ak[4] = {hh * hw * sgx * aw, hh * sm.lw * sgy * aw, sm.lh * hw * sgz * aw, sm.lh * sm.lw * sgw * aw};
+        const int tx0 = w0 - x0, ty0 = h0 - y0;
+        const int bx0 = min(max(tx0, 0), p.tw - 2);
+        int offs[2], own[2];
+        float wq[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int ty = ty0 + r;
+          const bool row_in = (unsigned)ty < (unsigned)p.th;
+          float w_p0 = 0.f, w_p1 = 0.f;                              // weights of window pixels bx0, bx0 + 1 of this row
+          bool any = false;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int k = r * 2 + c, tx = tx0 + c;
+            const bool use = row_in && ((okm >> k) & 1) && (unsigned)tx < (unsigned)p.tw;
+            if (use && tx == bx0) w_p0 = ak[k];
+            if (use && tx == bx0 + 1) w_p1 = ak[k];
+            any |= use;
+          }
+          offs[r] = (any && samp_live) ? (ty * p.tw + bx0) * CM : -1;
+          own[r] = ty & (NW - 1);
+          wq[r * 2] = w_p0; wq[r * 2 + 1] = w_p1;
+        }
+        // append to the owners' queues: slot = rank among the wave's lanes that add to the same owner (row 0 entries first)
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int o = 0; o < NW; ++o) {
+          const bool a0 = offs[0] >= 0 && own[0] == o, a1 = offs[1] >= 0 && own[1] == o;
+          const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+          const int c0 = __popcll(m0);
+          lds_entry *q = queue + (o * NW + wid) * kBtQueue;
+          if (a0) { BtEntry e = {offs[0], wq[0], wq[1], us}; q[__popcll(m0 & lt)] = e; }
+          if (a1) { BtEntry e = {offs[1], wq[2], wq[3], us}; q[c0 + __popcll(m1 & lt)] = e; }
+          if (lane == 0) qcount[o * NW + wid] = c0 + __popcll(m1);
+        }
+      }
 
-      // ---------------- phase 2: the unit's quad; lane c owns channels 4c .. 4c+3 (+16 j) ----------------
+      // ---- row arithmetic in the unit's quad; lane c owns channels 4c .. 4c+3 (+16 j) ----
       float4 top[NCH];
 #pragma unroll
-      for (int j = 0; j < NCH; ++j)
+      for (int j = 0; j < NCH; ++j) {
         top[j] = unit_live ? *reinterpret_cast<const float4 *>(p.grad_out + (int64_t)item * MC + m * CM + (c16 + 4 * j) * 4)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        lds_float *tq = tops + us * CM + (c16 + 4 * j) * 4;
+        tq[0] = top[j].x; tq[1] = top[j].y; tq[2] = top[j].z; tq[3] = top[j].w;
+      }
       float res[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // of THIS lane's sample: gw, gh, ga, gs[4] (gather order)
       auto sample = [&](const int s, const float lh, const float lw, const float aws, const int sh0, const int sw0, const int som,
                         const float s0, const float s1, const float s2, const float s3) {
@@ -122,7 +194,8 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           pix[k] = hk * p.W + wk;
 #pragma unroll
           for (int j = 0; j < NCH; ++j)
-            vv[k][j] = *reinterpret_cast<const float4 *>(vcam + (int64_t)pix[k] * MC + m * CM + (c16 + 4 * j) * 4);
+            vv[k][j] = (p.diag & 4) ? make_float4(1.f, 2.f, 3.f, 4.f)
+                                    : *reinterpret_cast<const float4 *>(vcam + (int64_t)pix[k] * MC + m * CM + (c16 + 4 * j) * 4);
         }
         float val[NCH][4], ghw[NCH][4], gww[NCH][4], tgv[NCH][4];
 #pragma unroll
@@ -135,11 +208,9 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
         for (int k = 0; k < 4; ++k) {
           const bool okk = (som >> k) & 1;
           const float ak = bil[k] * sg[k];
-          const int hk = sh0 + (k >> 1), wk = sw0 + (k & 1);
-          const int tx = wk - x0, ty = hk - y0;
+          const int tx = sw0 + (k & 1) - x0, ty = sh0 + (k >> 1) - y0;
           const bool inside = ((unsigned)tx < (unsigned)p.tw) & ((unsigned)ty < (unsigned)p.th);
           float gsk = 0.f;
-          float add[NCH][4];
 #pragma unroll
           for (int j = 0; j < NCH; ++j) {
             const float v4[4] = {vv[k][j].x, vv[k][j].y, vv[k][j].z, vv[k][j].w};
@@ -150,24 +221,15 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
               gww[j][e] += sg[k] * dw_c[k] * v;
               gsk += v * bil[k] * tgv[j][e];
               val[j][e] += ak * v;
-              add[j][e] = ak * tgv[j][e];
             }
           }
-          // the corner's contribution to grad_value: the lanes of a quad share the corner, so the branches diverge between units only
-          if (okk) {
-            if (inside) {
-              lds_float *row = gval + (ty * p.tw + tx) * CMP + c16 * 4;
+          // rare: the corner is in the map but outside the staged window -> the item kernel's global atomic, lane by lane
+          if (okk && !inside) {
+            float *row = gvcam + (int64_t)pix[k] * MC + m * CM + c16 * 4;
 #pragma unroll
-              for (int j = 0; j < NCH; ++j)
+            for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lds_add(row + 16 * j + e, add[j][e]);
-            } else {
-              float *row = gvcam + (int64_t)pix[k] * MC + m * CM + c16 * 4;
-#pragma unroll
-              for (int j = 0; j < NCH; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(row + 16 * j + e, add[j][e]);
-            }
+              for (int e = 0; e < 4; ++e) atomicAdd(row + 16 * j + e, ak * tgv[j][e]);
           }
           part[3 + k] = gsk;
         }
@@ -189,14 +251,16 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           res[k] = pt == s ? r : res[k];
         }
       };
-      sample(0, qb<0>(sm.lh), qb<0>(sm.lw), qb<0>(aw), qbi<0>(h0), qbi<0>(w0), qbi<0>(okm), qb<0>(sgx), qb<0>(sgy), qb<0>(sgz), qb<0>(sgw));
-      if (p.P > 1) {
-        sample(1, qb<1>(sm.lh), qb<1>(sm.lw), qb<1>(aw), qbi<1>(h0), qbi<1>(w0), qbi<1>(okm), qb<1>(sgx), qb<1>(sgy), qb<1>(sgz), qb<1>(sgw));
-        if (p.P > 2) sample(2, qb<2>(sm.lh), qb<2>(sm.lw), qb<2>(aw), qbi<2>(h0), qbi<2>(w0), qbi<2>(okm), qb<2>(sgx), qb<2>(sgy), qb<2>(sgz), qb<2>(sgw));
-        if (p.P > 3) sample(3, qb<3>(sm.lh), qb<3>(sm.lw), qb<3>(aw), qbi<3>(h0), qbi<3>(w0), qbi<3>(okm), qb<3>(sgx), qb<3>(sgy), qb<3>(sgz), qb<3>(sgw));
+      if (!(p.diag & 16)) {
+        sample(0, qb<0>(sm.lh), qb<0>(sm.lw), qb<0>(aw), qbi<0>(h0), qbi<0>(w0), qbi<0>(okm), qb<0>(sgx), qb<0>(sgy), qb<0>(sgz), qb<0>(sgw));
+        if (p.P > 1) {
+          sample(1, qb<1>(sm.lh), qb<1>(sm.lw), qb<1>(aw), qbi<1>(h0), qbi<1>(w0), qbi<1>(okm), qb<1>(sgx), qb<1>(sgy), qb<1>(sgz), qb<1>(sgw));
+          if (p.P > 2) sample(2, qb<2>(sm.lh), qb<2>(sm.lw), qb<2>(aw), qbi<2>(h0), qbi<2>(w0), qbi<2>(okm), qb<2>(sgx), qb<2>(sgy), qb<2>(sgz), qb<2>(sgw));
+          if (p.P > 3) sample(3, qb<3>(sm.lh), qb<3>(sm.lw), qb<3>(aw), qbi<3>(h0), qbi<3>(w0), qbi<3>(okm), qb<3>(sgx), qb<3>(sgy), qb<3>(sgz), qb<3>(sgw));
+        }
       }
 
-      // ---------------- phase 3: lane = its own sample again: depth-score backward, grad_loc / grad_attn ----------------
+      // ---- lane = its own sample again: depth-score backward, grad_loc / grad_attn ----
       if (samp_live) {
         // scores' gradients back in the reference order (h0,w0) (h0,w1) (h1,w1) (h1,w0)
         const float gs_ref[4] = {res[3], res[4], res[6], res[5]};
@@ -214,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
               const bool inside = ((unsigned)tx < (unsigned)p.tw) & ((unsigned)ty < (unsigned)p.th);
               if (d0 >= 0) va = dcam[o + d0];
               if (d1 <= p.D - 1) vb = dcam[o + d1];
-              if (gs_ref[k] != 0.f) {
+              if (gs_ref[k] != 0.f && !(p.diag & 8)) {
                 if (inside) {                                  // explicit branches: one pointer that is LDS or global would make the atomics flat
                   lds_float *gd = gdist + (ty * p.tw + tx) * p.D;
                   if (d0 >= 0) lds_add(gd + d0, hd * gs_ref[k]);
@@ -229,66 +293,114 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
             gz += fD * (gs_ref[k] * (vb - va));
           }
         }
-        // a sample shared by the channel groups (LM == 1 < M: the geometry sample's one "head" over C channels run as M groups of
-        // CM): this lane owns the entry in every iteration of the head loop (same bin, same unit deal) and accumulates it
-        const bool first = p.LM != 1 || m == 0;
         if (p.grad_loc) {
           float *gl = p.grad_loc + g * 3;
-          gl[0] = first ? res[0] : gl[0] + res[0];
-          gl[1] = first ? res[1] : gl[1] + res[1];
-          gl[2] = first ? gz : gl[2] + gz;
+          if (shared_samples) { atomicAdd(gl, res[0]); atomicAdd(gl + 1, res[1]); atomicAdd(gl + 2, gz); }      // the caller zero-filled it
+          else { gl[0] = res[0]; gl[1] = res[1]; gl[2] = gz; }
         }
-        if (p.grad_attn) p.grad_attn[g] = first ? res[2] : p.grad_attn[g] + res[2];
+        if (p.grad_attn) {
+          if (shared_samples) atomicAdd(p.grad_attn + g, res[2]);
+          else p.grad_attn[g] = res[2];
+        }
       }
     }
     __syncthreads();
-    // ---- flush this head's window (and clear it for the next head): whole head segments of a pixel row per wave instruction ----
-    {
-      constexpr int RPP = NT / CM;                                // window rows per pass
-      const int ch = tid % CM;
-      int row = tid / CM;
-      int ty = row / p.tw, tx = row - ty * p.tw;
-      for (; row < npx; row += RPP) {
-        const float v = gval[row * CMP + ch];
-        if (v != 0.f) {
-          gval[row * CMP + ch] = 0.f;
-          atomicAdd(gvcam + ((int64_t)(y0 + ty) * p.W + x0 + tx) * MC + m * CM + ch, v);
+    // ======================= phase B: every wave applies the window rows it owns =======================
+    if (!(p.diag & 1)) {
+      const int ch = lane % CM;                                    // lane = (pixel of the adjacent pair, channel); CM = 16: lanes 32 .. 63 idle
+      const bool half = lane >= CM, lane_on = lane < 2 * CM;
+      // G entries in flight: their queue records, grad_out values and window values are read together (one LDS round trip each instead
+      // of one per entry); entries whose pixel pairs overlap must stay in program order, so a group with an overlap runs one by one
+      constexpr int G = 4;
+      for (int prod = 0; prod < NW; ++prod) {
+        const lds_entry *q = queue + (wid * NW + prod) * kBtQueue;
+        const int c = __builtin_amdgcn_readfirstlane(qcount[wid * NW + prod]);
+        for (int e = 0; e < c; e += G) {
+          BtEntry en[G];
+          int o[G];
+          float tv[G], wv[G];
+#pragma unroll
+          for (int i = 0; i < G; ++i) en[i] = q[e + i < c ? e + i : c - 1];
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            o[i] = __builtin_amdgcn_readfirstlane(en[i].off);
+            tv[i] = lane_on ? tops[en[i].unit * CM + ch] : 0.f;
+            wv[i] = half ? en[i].w1 : en[i].w0;
+          }
+          const int ng = min(G, c - e);
+          bool clash = false;
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = i + 1; j < G; ++j) clash |= j < ng && o[i] - o[j] < 2 * CM && o[j] - o[i] < 2 * CM;
+          if (lane_on) {
+            if (!clash) {
+              float v[G];
+#pragma unroll
+              for (int i = 0; i < G; ++i) v[i] = i < ng ? win[o[i] + lane] : 0.f;
+#pragma unroll
+              for (int i = 0; i < G; ++i)
+                if (i < ng) win[o[i] + lane] = v[i] + wv[i] * tv[i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < G; ++i)
+                if (i < ng) { lds_float *qq = win + o[i] + lane; *qq = *qq + wv[i] * tv[i]; }
+            }
+          }
         }
-        tx += RPP;
-        while (tx >= p.tw) { tx -= p.tw; ++ty; }
       }
     }
-    __syncthreads();
   }
-  // ---- flush the depth-gradient window ----
-  for (int i = tid; i < npx * p.D; i += NT) {
-    const float v = gdist[i];
-    if (v != 0.f) {
-      const int row = i / p.D, d = i - row * p.D;
-      const int ty = row / p.tw, tx = row - ty * p.tw;
-      atomicAdd(gdcam + ((int64_t)(y0 + ty) * p.W + x0 + tx) * p.D + d, v);
+  __syncthreads();
+  // ---- flush: whole head segments of a pixel row per wave instruction ----
+  if (!(p.diag & 2)) {
+    constexpr int RPP = NT / CM;                                // window rows per pass
+    const int ch = tid % CM;
+    int row = tid / CM;
+    int ty = row / p.tw, tx = row - ty * p.tw;
+    for (; row < npx; row += RPP) {
+      const float v = win[row * CM + ch];
+      if (v != 0.f) atomicAdd(gvcam + ((int64_t)(y0 + ty) * p.W + x0 + tx) * MC + m * CM + ch, v);
+      tx += RPP;
+      while (tx >= p.tw) { tx -= p.tw; ++ty; }
+    }
+    for (int i = tid; i < npx * p.D; i += NT) {
+      const float v = gdist[i];
+      if (v != 0.f) {
+        const int r = i / p.D, d = i - r * p.D;
+        const int yy = r / p.tw, xx = r - yy * p.tw;
+        atomicAdd(gdcam + ((int64_t)(y0 + yy) * p.W + x0 + xx) * p.D + d, v);
+      }
     }
   }
 }
 
-int g_tune_bwd_tile_nw = 8;     // waves per workgroup of the tiled backward (4 | 8 | 16)
+int g_tune_bwd_tile_diag = 0;   // timing experiments only (BwdTileParams.diag); inert unless SGC_DIAG=1 is in the environment
 
 }  // namespace sgc
 
 using namespace sgc;
 
-template <int CM, int NW>
+constexpr int kBtWaves = 4;     // waves per workgroup = window-row owners
+
+template <int CM>
 static int launch_bwd_tile(const BwdTileParams &p, size_t smem, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void *)dfa3d_bwd_tile_kernel<CM, NW>, 160 * 1024, attr_done);
-  hipLaunchKernelGGL((dfa3d_bwd_tile_kernel<CM, NW>), dim3((unsigned)(p.N * p.nbx * p.nby)), dim3(NW * 64), smem, st, p);
+  ensure_dynamic_lds((const void *)dfa3d_bwd_tile_kernel<CM, kBtWaves>, 160 * 1024, attr_done);
+  hipLaunchKernelGGL((dfa3d_bwd_tile_kernel<CM, kBtWaves>), dim3((unsigned)(p.N * p.nbx * p.nby * p.M)), dim3(kBtWaves * 64), smem, st, p);
   return check_launch("dfa3d_bwd_tile_kernel");
+}
+
+// window (grad_value slice of one head + grad_dist) + the batch's grad_out rows + its sample queues
+static int64_t bwd_tile_lds(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y) {
+  const int64_t tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W, th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
+  const int64_t nw = kBtWaves, ub = nw * 16;
+  return ((tw * th * (Cm + D) + ub * Cm + 3) & ~(int64_t)3) * 4 + nw * nw * kBtQueue * (int64_t)sizeof(BtEntry) + nw * nw * 4;
 }
 
 extern "C" int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y) {
   if (H <= 0 || W <= 0 || Cm <= 0 || D <= 0 || bin_w <= 0 || bin_h <= 0 || halo_x < 0 || halo_y < 0) return 0;
-  const int64_t tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W, th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
-  return tw * th * (Cm + 1 + D) * 4;
+  return bwd_tile_lds(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y);
 }
 
 extern "C" int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
@@ -303,7 +415,7 @@ extern "C" int sgc_dfa3d_backward_binned(const float *value, const float *dist, 
   if ((Cm != 16 && Cm != 32) || P < 1 || P > 4 || (loc_heads != 1 && loc_heads != M))
     return set_error(SGC_EUNSUP, "sgc_dfa3d_backward_binned: Cm in {16, 32}, 1 <= P <= 4, loc_heads in {1, M} (got Cm %d, P %d, loc_heads %d)", Cm, P, loc_heads);
   if (((uintptr_t)value | (uintptr_t)grad_out) & 15) return set_error(SGC_EINVAL, "sgc_dfa3d_backward_binned: value / grad_out must be 16-byte aligned");
-  const int64_t lds = sgc_dfa3d_backward_binned_lds_bytes(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y);
+  const int64_t lds = bwd_tile_lds(H, W, Cm, D, bin_w, bin_h, halo_x, halo_y);
   if (lds > 160 * 1024) return set_error(SGC_EUNSUP, "sgc_dfa3d_backward_binned: the window needs %lld bytes of LDS", (long long)lds);
   BwdTileParams p = {};
   p.value = value; p.dist = dist; p.loc = loc3; p.attn = attn_or_null; p.bin_offset = bin_offset; p.grad_out = grad_out;
@@ -311,12 +423,13 @@ extern "C" int sgc_dfa3d_backward_binned(const float *value, const float *dist, 
   p.N = N; p.S = S; p.H = H; p.W = W; p.D = D; p.M = M; p.LM = loc_heads; p.P = P;
   p.bw = bin_w; p.bh = bin_h; p.nbx = ceil_div(W, bin_w); p.nby = ceil_div(H, bin_h);
   p.hx = halo_x; p.hy = halo_y;
+  {
+    static const bool diag_ok = getenv("SGC_DIAG") && atoi(getenv("SGC_DIAG")) == 1;
+    p.diag = diag_ok ? g_tune_bwd_tile_diag : 0;
+  }
   p.tw = bin_w + 2 * halo_x < W ? bin_w + 2 * halo_x : W;
   p.th = bin_h + 2 * halo_y < H ? bin_h + 2 * halo_y : H;
+  if (p.tw < 2) return set_error(SGC_EUNSUP, "sgc_dfa3d_backward_binned: the window must be at least two pixels wide");
   hipStream_t st = (hipStream_t)stream;
-  const int nw = g_tune_bwd_tile_nw == 4 ? 4 : g_tune_bwd_tile_nw == 16 ? 16 : 8;
-#define SGC_BT_CASE(CMV, NWV) if (Cm == CMV && nw == NWV) return launch_bwd_tile<CMV, NWV>(p, (size_t)lds, st)
-  SGC_BT_CASE(32, 8); SGC_BT_CASE(16, 8); SGC_BT_CASE(32, 4); SGC_BT_CASE(16, 4); SGC_BT_CASE(32, 16); SGC_BT_CASE(16, 16);
-#undef SGC_BT_CASE
-  return set_error(SGC_EUNSUP, "sgc_dfa3d_backward_binned: no kernel for this shape");
+  return Cm == 32 ? launch_bwd_tile<32>(p, (size_t)lds, st) : launch_bwd_tile<16>(p, (size_t)lds, st);
 }

@@ -378,7 +378,7 @@ extern int g_tune_tile_diag;
 extern int g_tune_tile_nbuf;
 extern int g_tune_tile_hg;
 extern int g_tune_tile_ds;
-extern int g_tune_bwd_tile_nw;    // dfa3d_bwd_tile.hip
+extern int g_tune_bwd_tile_diag;    // dfa3d_bwd_tile.hip
 extern int g_tune_tile_xcd;
 extern int g_tune_conv_halo;    // conv3d.hip: halo-resident kernel for the 3x3x3 stride-1 layers   // 0: block-barrier kernel, 1: wave-private kernel (when the shape allows)
 
@@ -576,7 +576,7 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "tile_nbuf")) { g_tune_tile_nbuf = value; return SGC_OK; }
   if (!strcmp(key, "tile_hg")) { g_tune_tile_hg = value; return SGC_OK; }
   if (!strcmp(key, "tile_ds")) { g_tune_tile_ds = value; return SGC_OK; }
-  if (!strcmp(key, "bwd_tile_nw")) { g_tune_bwd_tile_nw = value; return SGC_OK; }
+  if (!strcmp(key, "bwd_tile_diag")) { g_tune_bwd_tile_diag = value; return SGC_OK; }
   if (!strcmp(key, "tile_xcd")) { g_tune_tile_xcd = value; return SGC_OK; }
   return set_error(SGC_EINVAL, "sgc_set_tuning: unknown key %s", key);
 }

@@ -106,6 +106,9 @@ class WeightedMultiScaleDeformableAttnFunction_fp32(Function):
         return grad_value, None, None, grad_loc, grad_attn, grad_score, None
 
 
+TRAIN_BWD_TILED_SHARED = os.environ.get("SGC_TRAIN_BWD_SHARED", "0") == "1"     # the one-head geometry sample on the tiled backward too (A/B)
+
+
 class PairListDeformAttnFunction(Function):
     """The fused DFA3D operator over an ITEM LIST: item i = (camera ``item_batch[i]``, its sampling locations / weights).
     Training-path counterpart of ``MultiScale3DDeformableAttnFunction_fp32`` without the reference's padded
@@ -144,6 +147,11 @@ class PairListDeformAttnFunction(Function):
             # the kernel's head split: channel groups of 32 (16) channels; one head over C channels (the geometry sample) runs as C / 32
             # groups that share its sample set
             cmb = Cm if Cm in (16, 32) else (32 if Cm % 32 == 0 else 16 if Cm % 16 == 0 else 0)
+            # measured (tools/bwd_tile_bench.py, profiles/r06_bwd_tile_bench_cfg2.txt): the deformable call (8 heads x 4 points) 1.25 ms
+            # tiled against 1.89 ms on the item kernel; the geometry sample (ONE sample per pair: 4 KB of atomics, not 16) 0.57 against
+            # 0.42 -- it keeps the item kernel unless TRAIN_BWD_TILED_SHARED says otherwise
+            if M == 1 and Cm != cmb and not TRAIN_BWD_TILED_SHARED:
+                cmb = 0
             if cmb and (cmb == Cm or M == 1) and P <= 4 and ops.dfa3d_backward_binned_fits(H, W, cmb, dist.shape[-1], bw, bh, halo):
                 mb = M * Cm // cmb
                 gv, gd, gl, ga = ops.dfa3d_backward_binned(value.view(N, S, mb, cmb), dist, loc, attn, bin_offset, grad_output, H, W, bw, bh,

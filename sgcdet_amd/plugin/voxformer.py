@@ -71,7 +71,7 @@ TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
 # LDS.  ``bin`` / ``halo`` in feature pixels (the window = bin + 2 halo must fit 160 KiB at (Cm + 1 + D) * 4 bytes per pixel); corners
 # outside the window fall back to global atomics, so results never depend on these numbers beyond float-atomic order.
 # Env (A/B): SGC_TRAIN_BWD=0 (the item kernel, one global atomic per corner contribution) | "bin_w,bin_h,halo_x,halo_y".
-TRAIN_BWD_TILED = dict(enabled=True, bin=(16, 22), halo=(3, 3))
+TRAIN_BWD_TILED = dict(enabled=True, bin=(8, 11), halo=(2, 2))       # 180-pixel windows: 56 KB of LDS, two workgroups per CU
 
 
 def _tiled_env_overrides():

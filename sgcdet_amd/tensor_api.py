@@ -247,8 +247,10 @@ class TensorOps:
             raise RuntimeError("dfa3d_backward_binned: bin_offset too short for these bins")
         grad_value = torch.zeros_like(value)
         grad_dist = torch.zeros_like(dist)
-        grad_loc3 = torch.empty_like(loc3) if want_grad_loc else None
-        grad_attn = torch.empty(loc3.shape[:-1], dtype=value.dtype, device=value.device) if want_grad_attn else None
+        # a sample set shared by the M channel groups: its gradients are summed over the groups' workgroups (atomics into zeros)
+        alloc = torch.zeros if (LM == 1 and M > 1) else torch.empty
+        grad_loc3 = alloc(loc3.shape, dtype=value.dtype, device=value.device) if want_grad_loc else None
+        grad_attn = alloc(loc3.shape[:-1], dtype=value.dtype, device=value.device) if want_grad_attn else None
         if n:
             self._call("sgc_dfa3d_backward_binned", value, dist, loc3, attn, bin_offset, grad_out, grad_value, grad_dist, grad_loc3,
                        grad_attn, N, S, int(H), int(W), M, Cm, D, LM, P, int(bin_w), int(bin_h), int(halo[0]), int(halo[1]))

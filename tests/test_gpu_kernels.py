@@ -697,7 +697,7 @@ def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
 def test_binned_backward_against_oracle(Cm, HW, bins, halo, spread, oracle_ops, gpu_ops):
     """sgc_dfa3d_backward_binned (LDS-tiled backward of the training path, round 6) against the oracle's item backward on the same
     items: grad_value, grad_dist, every grad_loc entry and grad_attn within 2e-5 of the scale (the bound of the item kernel's test);
-    the result must not depend on the bins, the halo or the workgroup size; the shared-sample form (one head over C channels run
+    the result must not depend on the bins or the halo; the shared-sample form (one head over C channels run
     as channel groups: the geometry sample) against the oracle's one-head operator; and the HIP item kernel as a second opinion."""
     N, Nq, D, M, P = 5, 700, 12, 8, 4
     H, W = HW
@@ -722,14 +722,9 @@ def test_binned_backward_against_oracle(Cm, HW, bins, halo, spread, oracle_ops, 
         attn = torch.rand(n, M, 1, P, generator=g)
         go = torch.randn(n, M * Cm, generator=g)
         want = oracle_ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, cam.to(torch.int32), go)
-        try:
-            for nw in (8, 4, 16):
-                gpu_ops.lib.call("sgc_set_tuning", b"bwd_tile_nw", nw)
-                got = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc), cu(attn), b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy))
-                for a, w_ in zip(got, want):
-                    close(a, w_, tol=2e-5)
-        finally:
-            gpu_ops.lib.call("sgc_set_tuning", b"bwd_tile_nw", 8)
+        got = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc), cu(attn), b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy))
+        for a, w_ in zip(got, want):
+            close(a, w_, tol=2e-5)
         item_k = gpu_ops.dfa3d_backward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(cam.to(torch.int32)), cu(go))
         for a, w_ in zip(got, item_k):
             close(a, w_, tol=2e-5)
