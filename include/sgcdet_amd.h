@@ -190,9 +190,10 @@ int sgc_dfa3d_backward_items(const float *value, const float *dist, const int64_
  * groups (the geometry sample's single head over C = M * Cm channels); its gradients are then summed over the groups.
  * grad_value / grad_dist must be zero-filled by the caller (they are accumulated into); grad_loc3 / grad_attn (either may be NULL)
  * are written.  Cm in {16, 32}, P <= 4; the window (bin + halo) must fit LDS (sgc_dfa3d_backward_binned_lds_bytes <= 160 KiB).
+ * head_shift_or_null [M][2] int32 (x, y) in pixels: head m's window is shifted by it (its mean sampling offset; speed only).
  * Same function of the inputs as sgc_dfa3d_backward_items; float atomics make the last bits order-dependent in both. */
 int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
-                              const int32_t *bin_offset, const float *grad_out, float *grad_value, float *grad_dist,
+                              const int32_t *bin_offset, const int32_t *head_shift_or_null, const float *grad_out, float *grad_value, float *grad_dist,
                               float *grad_loc3_or_null, float *grad_attn_or_null, int N, int S, int H, int W, int M, int Cm,
                               int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y, sgc_stream_t stream);
 int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y);

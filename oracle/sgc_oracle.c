@@ -475,10 +475,10 @@ int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin
   return tw * th * (Cm + 1 + D) * 4;
 }
 int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
-                              const int32_t *bin_offset, const float *grad_out, float *grad_value, float *grad_dist,
+                              const int32_t *bin_offset, const int32_t *head_shift_or_null, const float *grad_out, float *grad_value, float *grad_dist,
                               float *grad_loc3_or_null, float *grad_attn_or_null, int N, int S, int H, int W, int M, int Cm,
                               int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y, sgc_stream_t stream) {
-  (void)halo_x; (void)halo_y;
+  (void)halo_x; (void)halo_y; (void)head_shift_or_null;
   if (!value || !dist || !loc3 || !bin_offset || !grad_out || !grad_value || !grad_dist) return fail(SGC_EINVAL, "null pointer");
   if (loc_heads != 1 && loc_heads != M) return fail(SGC_EINVAL, "loc_heads must be 1 or M");
   const int nb = ((W + bin_w - 1) / bin_w) * ((H + bin_h - 1) / bin_h);

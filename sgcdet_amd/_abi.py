@@ -21,7 +21,7 @@ SIGNATURES = {
     "sgc_dfa3d_backward": [_p] * 11 + [_i] * 9 + [_p],
     "sgc_dfa3d_forward_items": [_p] * 9 + [_i] * 9 + [_p],
     "sgc_dfa3d_backward_items": [_p] * 12 + [_i] * 9 + [_p],
-    "sgc_dfa3d_backward_binned": [_p] * 10 + [_i] * 13 + [_p],
+    "sgc_dfa3d_backward_binned": [_p] * 11 + [_i] * 13 + [_p],
     "sgc_project_points": [_p] * 6 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 9 + [_p],

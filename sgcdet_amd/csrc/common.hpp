@@ -100,9 +100,11 @@ struct Sample {
   bool in2, in3;
 };
 
+// `taps` (optional, 8 floats): the two depth taps (d0, d0 + 1; 0 where gated off) of every corner in the GATHER order
+// (h0,w0) (h0,w1) (h1,w0) (h1,w1) -- what the depth-score backward needs again (dfa3d_bwd_tile.hip keeps them instead of re-loading)
 __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict__ dist_px0,
                                             int64_t pix_stride, int H, int W, int D,
-                                            float x, float y, float z, float aw) {
+                                            float x, float y, float z, float aw, float *taps = nullptr) {
   const float h_im = sample_coord(y, (float)H);
   const float w_im = sample_coord(x, (float)W);
   const float d_im = sample_coord(z, (float)D);
@@ -143,6 +145,9 @@ __device__ __forceinline__ void make_sample(Sample &sm, const float *__restrict_
         vb = d1 <= D - 1 ? p[d1] : 0.f;
       }
       v = va * hd + vb * sm.ld;
+      if (taps) { taps[2 * k] = va; taps[2 * k + 1] = vb; }
+    } else if (taps) {
+      taps[2 * k] = 0.f; taps[2 * k + 1] = 0.f;
     }
     sc[k] = v;
   }

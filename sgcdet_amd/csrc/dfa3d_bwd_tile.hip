@@ -46,6 +46,7 @@ struct BwdTileParams {
   const float *loc;            // [items][LM][P][3]
   const float *attn;           // [items][LM][P] or null (= 1)
   const int32_t *bin_offset;   // [N * nb + 1]
+  const int32_t *head_shift;   // [M][2] window shift per head in pixels (x, y), or null: the window follows the head's mean sampling offset
   const float *grad_out;       // [items][M * CM]
   float *grad_value, *grad_dist;
   float *grad_loc;             // [items][LM][P][3] or null
@@ -68,8 +69,8 @@ template <int S> __device__ __forceinline__ int qbi(int v) {
 }
 
 constexpr int kBtQueue = 64;   // entries per (owner, producer) sub-queue: a lane's two rows have different owners, so a wave step adds <= 64
-struct __attribute__((aligned(16))) BtEntry { int off; float w0, w1; int unit; };     // window float index of (row, first pixel, channel 0);
-                                                                                      // weights of the two adjacent pixels; unit slot of the batch
+typedef int BtEntry __attribute__((ext_vector_type(4)));     // x: window float index of (row, first pixel, channel 0); y, z: bits of the
+                                                             // weights of the two adjacent pixels; w: unit slot of the batch
 
 // (Measured and not kept, tools/bwd_tile_bench.py on the finest config-2 level: eight waves per workgroup -- 2.7 ms against 1.57 with
 //  four, in every form of phase B; producer and owner roles on different waves with double-buffered queues -- 2.7 ms: a bin holds
@@ -88,7 +89,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
   const int n = t / nb, b = t - n * nb;
   const int by = b / p.nbx, bx = b - by * p.nbx;
   const int npx = p.tw * p.th;
-  const int x0 = max(0, min(bx * p.bw - p.hx, p.W - p.tw)), y0 = max(0, min(by * p.bh - p.hy, p.H - p.th));
+  // the window of head m is shifted by that head's mean sampling offset (as in the tiled forward): the samples of a head sit around
+  // reference pixel + offset, and without the shift a third of the corners fell outside a 2-pixel halo (the global-atomic fall-back)
+  const int sx = p.head_shift ? p.head_shift[m * 2] : 0, sy = p.head_shift ? p.head_shift[m * 2 + 1] : 0;
+  const int x0 = max(0, min(bx * p.bw - p.hx + sx, p.W - p.tw)), y0 = max(0, min(by * p.bh - p.hy + sy, p.H - p.th));
   lds_float *win = (lds_float *)bt_smem;                            // [npx][CM]
   lds_float *gdist = win + npx * CM;                                // [npx][D]
   lds_float *tops = gdist + npx * p.D;                              // [UB][CM]: grad_out rows of the batch's units
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
       const float x = p.loc[g * 3], y = p.loc[g * 3 + 1], z = p.loc[g * 3 + 2];
       const float aw = p.attn ? p.attn[g] : 1.f;
       Sample sm;
-      make_sample(sm, dcam, p.D, p.H, p.W, p.D, x, y, z, 1.f);
+      float taps[8];                                                // the depth taps of the four corners: phase 3 needs them again
+      make_sample(sm, dcam, p.D, p.H, p.W, p.D, x, y, z, 1.f, taps);
       const int h0 = (int)__builtin_amdgcn_fmed3f(floorf(sample_coord(y, fH)), -2.f, fH);
       const int w0 = (int)__builtin_amdgcn_fmed3f(floorf(sample_coord(x, fW)), -2.f, fW);
       // bit k: corner k (gather order (h0,w0) (h0,w1) (h1,w0) (h1,w1)) lies in the map and the sample passes the 2-D gate
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
           const int c0 = __popcll(m0);
           lds_entry *q = queue + (o * NW + wid) * kBtQueue;
-          if (a0) { BtEntry e = {offs[0], wq[0], wq[1], us}; q[__popcll(m0 & lt)] = e; }
-          if (a1) { BtEntry e = {offs[1], wq[2], wq[3], us}; q[c0 + __popcll(m1 & lt)] = e; }
+          if (a0) { const BtEntry e = {offs[0], __float_as_int(wq[0]), __float_as_int(wq[1]), us}; q[__popcll(m0 & lt)] = e; }
+          if (a1) { const BtEntry e = {offs[1], __float_as_int(wq[2]), __float_as_int(wq[3]), us}; q[c0 + __popcll(m1 & lt)] = e; }
           if (lane == 0) qcount[o * NW + wid] = c0 + __popcll(m1);
         }
       }
@@ -178,6 +183,22 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
         tq[0] = top[j].x; tq[1] = top[j].y; tq[2] = top[j].z; tq[3] = top[j].w;
       }
       float res[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // of THIS lane's sample: gw, gh, ga, gs[4] (gather order)
+      // The corner rows of ALL the unit's samples are requested before the first one is used: a bin holds one or two batches, so a
+      // wave passes here once or twice per launch and every dependent round trip to L2 is exposed (measured: the phase took 0.8 ms of a
+      // 1.25-ms launch with one sample's rows in flight at a time).  4 samples x 4 corners x NCH 16-byte chunks = 128 registers at Cm = 32.
+      float4 vv[4][4][NCH];
+      int pixs[4][4];
+      auto request = [&](const int s, const int sh0, const int sw0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int hk = min(max(sh0 + (k >> 1), 0), p.H - 1), wk = min(max(sw0 + (k & 1), 0), p.W - 1);
+          pixs[s][k] = hk * p.W + wk;
+#pragma unroll
+          for (int j = 0; j < NCH; ++j)
+            vv[s][k][j] = (p.diag & 4) ? make_float4(1.f, 2.f, 3.f, 4.f)
+                                       : *reinterpret_cast<const float4 *>(vcam + (int64_t)pixs[s][k] * MC + m * CM + (c16 + 4 * j) * 4);
+        }
+      };
       auto sample = [&](const int s, const float lh, const float lw, const float aws, const int sh0, const int sw0, const int som,
                         const float s0, const float s1, const float s2, const float s3) {
         const float hh = 1.f - lh, hw = 1.f - lw;
@@ -186,17 +207,6 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
         const float dh_c[4] = {-hw, -lw, hw, lw};                   // d(bilinear weight)/dh, /dw: wms_deform_attn_cuda_kernel.cuh:116-150
         const float dw_c[4] = {-hh, hh, -lh, lh};
         float part[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float4 vv[4][NCH];
-        int pix[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int hk = min(max(sh0 + (k >> 1), 0), p.H - 1), wk = min(max(sw0 + (k & 1), 0), p.W - 1);
-          pix[k] = hk * p.W + wk;
-#pragma unroll
-          for (int j = 0; j < NCH; ++j)
-            vv[k][j] = (p.diag & 4) ? make_float4(1.f, 2.f, 3.f, 4.f)
-                                    : *reinterpret_cast<const float4 *>(vcam + (int64_t)pix[k] * MC + m * CM + (c16 + 4 * j) * 4);
-        }
         float val[NCH][4], ghw[NCH][4], gww[NCH][4], tgv[NCH][4];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           float gsk = 0.f;
 #pragma unroll
           for (int j = 0; j < NCH; ++j) {
-            const float v4[4] = {vv[k][j].x, vv[k][j].y, vv[k][j].z, vv[k][j].w};
+            const float v4[4] = {vv[s][k][j].x, vv[s][k][j].y, vv[s][k][j].z, vv[s][k][j].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float v = okk ? v4[e] : 0.f;
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           }
           // rare: the corner is in the map but outside the staged window -> the item kernel's global atomic, lane by lane
           if (okk && !inside) {
-            float *row = gvcam + (int64_t)pix[k] * MC + m * CM + c16 * 4;
+            float *row = gvcam + (int64_t)pixs[s][k] * MC + m * CM + c16 * 4;
 #pragma unroll
             for (int j = 0; j < NCH; ++j)
 #pragma unroll
@@ -252,6 +262,10 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
         }
       };
       if (!(p.diag & 16)) {
+        request(0, qbi<0>(h0), qbi<0>(w0));
+        if (p.P > 1) request(1, qbi<1>(h0), qbi<1>(w0));
+        if (p.P > 2) request(2, qbi<2>(h0), qbi<2>(w0));
+        if (p.P > 3) request(3, qbi<3>(h0), qbi<3>(w0));
         sample(0, qb<0>(sm.lh), qb<0>(sm.lw), qb<0>(aw), qbi<0>(h0), qbi<0>(w0), qbi<0>(okm), qb<0>(sgx), qb<0>(sgy), qb<0>(sgz), qb<0>(sgw));
         if (p.P > 1) {
           sample(1, qb<1>(sm.lh), qb<1>(sm.lw), qb<1>(aw), qbi<1>(h0), qbi<1>(w0), qbi<1>(okm), qb<1>(sgx), qb<1>(sgy), qb<1>(sgz), qb<1>(sgw));
@@ -262,35 +276,28 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
 
       // ---- lane = its own sample again: depth-score backward, grad_loc / grad_attn ----
       if (samp_live) {
-        // scores' gradients back in the reference order (h0,w0) (h0,w1) (h1,w1) (h1,w0)
-        const float gs_ref[4] = {res[3], res[4], res[6], res[5]};
         float gz = 0.f;
         if (sm.in3) {
           const int d0 = sm.d0, d1 = d0 + 1;
           const float ld = sm.ld, hd = 1.f - ld;
-          const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0 + 1, w0};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float va = 0.f, vb = 0.f;
-            if (hs[k] >= 0 && hs[k] <= p.H - 1 && ws[k] >= 0 && ws[k] <= p.W - 1) {
-              const int64_t o = ((int64_t)hs[k] * p.W + ws[k]) * p.D;
-              const int tx = ws[k] - x0, ty = hs[k] - y0;
+          for (int k = 0; k < 4; ++k) {                             // gather order: res[3 + k] is d/dscore of corner k, taps[2k], [2k+1] its depth taps
+            const int hk = h0 + (k >> 1), wk = w0 + (k & 1);
+            const float gs = res[3 + k];
+            if (hk >= 0 && hk <= p.H - 1 && wk >= 0 && wk <= p.W - 1 && gs != 0.f && !(p.diag & 8)) {
+              const int tx = wk - x0, ty = hk - y0;
               const bool inside = ((unsigned)tx < (unsigned)p.tw) & ((unsigned)ty < (unsigned)p.th);
-              if (d0 >= 0) va = dcam[o + d0];
-              if (d1 <= p.D - 1) vb = dcam[o + d1];
-              if (gs_ref[k] != 0.f && !(p.diag & 8)) {
-                if (inside) {                                  // explicit branches: one pointer that is LDS or global would make the atomics flat
-                  lds_float *gd = gdist + (ty * p.tw + tx) * p.D;
-                  if (d0 >= 0) lds_add(gd + d0, hd * gs_ref[k]);
-                  if (d1 <= p.D - 1) lds_add(gd + d1, ld * gs_ref[k]);
-                } else {
-                  float *gd = gdcam + o;
-                  if (d0 >= 0) atomicAdd(gd + d0, hd * gs_ref[k]);
-                  if (d1 <= p.D - 1) atomicAdd(gd + d1, ld * gs_ref[k]);
-                }
+              if (inside) {                                  // explicit branches: one pointer that is LDS or global would make the atomics flat
+                lds_float *gd = gdist + (ty * p.tw + tx) * p.D;
+                if (d0 >= 0) lds_add(gd + d0, hd * gs);
+                if (d1 <= p.D - 1) lds_add(gd + d1, ld * gs);
+              } else {
+                float *gd = gdcam + ((int64_t)hk * p.W + wk) * p.D;
+                if (d0 >= 0) atomicAdd(gd + d0, hd * gs);
+                if (d1 <= p.D - 1) atomicAdd(gd + d1, ld * gs);
               }
             }
-            gz += fD * (gs_ref[k] * (vb - va));
+            gz += fD * (gs * (taps[2 * k + 1] - taps[2 * k]));
           }
         }
         if (p.grad_loc) {
@@ -323,9 +330,9 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_bwd_tile_kernel(const BwdTilePa
           for (int i = 0; i < G; ++i) en[i] = q[e + i < c ? e + i : c - 1];
 #pragma unroll
           for (int i = 0; i < G; ++i) {
-            o[i] = __builtin_amdgcn_readfirstlane(en[i].off);
-            tv[i] = lane_on ? tops[en[i].unit * CM + ch] : 0.f;
-            wv[i] = half ? en[i].w1 : en[i].w0;
+            o[i] = __builtin_amdgcn_readfirstlane(en[i].x);
+            tv[i] = lane_on ? tops[en[i].w * CM + ch] : 0.f;
+            wv[i] = __int_as_float(half ? en[i].z : en[i].y);
           }
           const int ng = min(G, c - e);
           bool clash = false;
@@ -404,7 +411,7 @@ extern "C" int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int
 }
 
 extern "C" int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float *loc3, const float *attn_or_null,
-                                         const int32_t *bin_offset, const float *grad_out, float *grad_value, float *grad_dist,
+                                         const int32_t *bin_offset, const int32_t *head_shift_or_null, const float *grad_out, float *grad_value, float *grad_dist,
                                          float *grad_loc3_or_null, float *grad_attn_or_null, int N, int S, int H, int W, int M, int Cm,
                                          int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y,
                                          sgc_stream_t stream) {
@@ -419,6 +426,7 @@ extern "C" int sgc_dfa3d_backward_binned(const float *value, const float *dist, 
   if (lds > 160 * 1024) return set_error(SGC_EUNSUP, "sgc_dfa3d_backward_binned: the window needs %lld bytes of LDS", (long long)lds);
   BwdTileParams p = {};
   p.value = value; p.dist = dist; p.loc = loc3; p.attn = attn_or_null; p.bin_offset = bin_offset; p.grad_out = grad_out;
+  p.head_shift = head_shift_or_null;
   p.grad_value = grad_value; p.grad_dist = grad_dist; p.grad_loc = grad_loc3_or_null; p.grad_attn = grad_attn_or_null;
   p.N = N; p.S = S; p.H = H; p.W = W; p.D = D; p.M = M; p.LM = loc_heads; p.P = P;
   p.bw = bin_w; p.bh = bin_h; p.nbx = ceil_div(W, bin_w); p.nby = ceil_div(H, bin_h);

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
       const int dbase = min(max(d0, 0), Dm2);
       const bool dlo = d0 == dbase;               // false only at the two depth borders
       const bool d0ok = d0 >= 0, d1ok = d0 + 1 <= p.D - 1;
+      const unsigned char *depb = dep + dbase * DB;
       float ta[4], tb[4];
       bool ok[4], inside[4];
       int pix[4], trow[4];
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void dfa3d_fwd_tile_kernel(const TileParam
             din = ((unsigned)dx < (unsigned)p.dw) & ((unsigned)dy < (unsigned)p.dh);
             drow = __mul24(dy, p.dw) + dx;
           }
-          const unsigned char *dp = dep + (__umul24((unsigned)(din ? drow : 0), (unsigned)p.D) + (unsigned)dbase) * DB;
+          const unsigned char *dp = depb + __umul24((unsigned)(din ? drow : 0), (unsigned)(p.D * DB));
           if constexpr (DB == 4) { ta[k] = reinterpret_cast<const float *>(dp)[0]; tb[k] = reinterpret_cast<const float *>(dp)[1]; }
           else depth_pair(dp, ta[k], tb[k]);
           need_g |= in3 & ok[k] & !din;

@@ -143,7 +143,8 @@ class PairListDeformAttnFunction(Function):
         N, S, M, Cm = value.shape
         n, LM, L, P = loc.shape[:4]
         if bins is not None and L == 1 and dist.shape[2] == 1 and n > 0:
-            bin_offset, H, W, bw, bh, halo = bins
+            bin_offset, H, W, bw, bh, halo = bins[:6]
+            head_shift = bins[6] if len(bins) > 6 and M > 1 else None
             # the kernel's head split: channel groups of 32 (16) channels; one head over C channels (the geometry sample) runs as C / 32
             # groups that share its sample set
             cmb = Cm if Cm in (16, 32) else (32 if Cm % 32 == 0 else 16 if Cm % 16 == 0 else 0)
@@ -155,7 +156,8 @@ class PairListDeformAttnFunction(Function):
             if cmb and (cmb == Cm or M == 1) and P <= 4 and ops.dfa3d_backward_binned_fits(H, W, cmb, dist.shape[-1], bw, bh, halo):
                 mb = M * Cm // cmb
                 gv, gd, gl, ga = ops.dfa3d_backward_binned(value.view(N, S, mb, cmb), dist, loc, attn, bin_offset, grad_output, H, W, bw, bh,
-                                                           halo, want_grad_loc=ctx.needs_input_grad[4], want_grad_attn=ctx.needs_input_grad[5])
+                                                           halo, want_grad_loc=ctx.needs_input_grad[4], want_grad_attn=ctx.needs_input_grad[5],
+                                                           head_shift=head_shift)
                 return gv.view_as(value), gd, None, None, gl, ga, None, None
         gv, gd, gl, ga = ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc, attn, item_batch, grad_output)
         return gv, gd, None, None, gl, ga, None, None

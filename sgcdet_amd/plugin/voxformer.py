@@ -71,7 +71,7 @@ TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
 # LDS.  ``bin`` / ``halo`` in feature pixels (the window = bin + 2 halo must fit 160 KiB at (Cm + 1 + D) * 4 bytes per pixel); corners
 # outside the window fall back to global atomics, so results never depend on these numbers beyond float-atomic order.
 # Env (A/B): SGC_TRAIN_BWD=0 (the item kernel, one global atomic per corner contribution) | "bin_w,bin_h,halo_x,halo_y".
-TRAIN_BWD_TILED = dict(enabled=True, bin=(8, 11), halo=(2, 2))       # 180-pixel windows: 56 KB of LDS, two workgroups per CU
+TRAIN_BWD_TILED = dict(enabled=True, bin=(8, 22), halo=(2, 2))       # 12 x 26-pixel windows: 79 KB of LDS at Cm = 32, two workgroups per CU (sweep: profiles/r06_bwd_tile_bench_cfg2.txt)
 
 
 def _tiled_env_overrides():
@@ -506,7 +506,9 @@ class DeformCrossAttention_DFA3D(BaseModule):
             bw, bh = min(TRAIN_BWD_TILED["bin"][0], W), min(TRAIN_BWD_TILED["bin"][1], H)
             if S >= H * W and ops.dfa3d_backward_binned_fits(H, W, 32 if C % 32 == 0 else 16, dist.shape[-1], bw, bh, TRAIN_BWD_TILED["halo"]):
                 pc = ops.bin_pairs(ref_cam.contiguous(), pc, H, W, bw, bh)
-                bins = (pc["bin_offset"], H, W, bw, bh, tuple(TRAIN_BWD_TILED["halo"]))
+                # head m's window follows its mean sampling offset (the bias of sampling_offsets, as the tiled forward's head_shift)
+                shift = da.sampling_offsets.bias.detach().float().view(M, -1, 2).mean(1).round().clamp(-8, 8).to(torch.int32).contiguous()
+                bins = (pc["bin_offset"], H, W, bw, bh, tuple(TRAIN_BWD_TILED["halo"]), shift)
         n_pairs, n_valid = pc["totals"][:2].tolist()                 # the level's one host sync
         cam, q = pc["pair_cam"][:n_pairs].long(), pc["pair_q"][:n_pairs].long()     # camera-major; inside a camera by bin, or ascending q
         valid_index = pc["valid_index"][:n_valid].long()

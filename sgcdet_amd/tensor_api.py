@@ -226,7 +226,7 @@ class TensorOps:
         return 0 < n <= 160 * 1024 and Cm in (16, 32)
 
     def dfa3d_backward_binned(self, value, dist, loc3, attn, bin_offset, grad_out, H, W, bin_w, bin_h, halo=(2, 2),
-                              want_grad_loc=True, want_grad_attn=True):
+                              want_grad_loc=True, want_grad_attn=True, head_shift=None):
         """Backward of the one-level DFA3D operator over a BINNED item list (``sgc_dfa3d_backward_binned``): items in the
         (camera, bin) order of ``bin_pairs``.  value [N,S,M,Cm]; dist [N,S,D] or [N,S,1,D]; loc3 [n,LM,(1,)P,3]; attn
         [n,LM,(1,)P] or None (= 1); grad_out [n, M*Cm].  LM = M, or 1 = one sample set shared by the M channel groups."""
@@ -236,6 +236,10 @@ class TensorOps:
         if bin_offset.dtype != torch.int32:
             raise RuntimeError("bin_offset must be int32")
         N, S, M, Cm = value.shape
+        if head_shift is not None:
+            self._check(head_shift=head_shift)
+            if head_shift.dtype != torch.int32 or head_shift.numel() != 2 * M or not head_shift.is_contiguous():
+                raise RuntimeError("head_shift must be a contiguous int32 [M, 2]")
         D = dist.shape[-1]
         if dist.numel() != N * S * D:
             raise RuntimeError("dfa3d_backward_binned: one depth map per camera expected (dist_heads == 1)")
@@ -252,7 +256,7 @@ class TensorOps:
         grad_loc3 = alloc(loc3.shape, dtype=value.dtype, device=value.device) if want_grad_loc else None
         grad_attn = alloc(loc3.shape[:-1], dtype=value.dtype, device=value.device) if want_grad_attn else None
         if n:
-            self._call("sgc_dfa3d_backward_binned", value, dist, loc3, attn, bin_offset, grad_out, grad_value, grad_dist, grad_loc3,
+            self._call("sgc_dfa3d_backward_binned", value, dist, loc3, attn, bin_offset, head_shift, grad_out, grad_value, grad_dist, grad_loc3,
                        grad_attn, N, S, int(H), int(W), M, Cm, D, LM, P, int(bin_w), int(bin_h), int(halo[0]), int(halo[1]))
         return grad_value, grad_dist, grad_loc3, grad_attn
 

@@ -725,6 +725,12 @@ def test_binned_backward_against_oracle(Cm, HW, bins, halo, spread, oracle_ops, 
         got = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc), cu(attn), b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy))
         for a, w_ in zip(got, want):
             close(a, w_, tol=2e-5)
+        # a per-head window shift moves the windows, never the result
+        shift = torch.randint(-4, 5, (M, 2), generator=g, dtype=torch.int32)
+        got_s = gpu_ops.dfa3d_backward_binned(cu(value), cu(dist), cu(loc), cu(attn), b["bin_offset"], cu(go), H, W, bw, bh, (hx, hy),
+                                              head_shift=cu(shift))
+        for a, w_ in zip(got_s, want):
+            close(a, w_, tol=2e-5)
         item_k = gpu_ops.dfa3d_backward_items(cu(value), cu(dist), cu(shapes3), cu(lsi), cu(loc), cu(attn), cu(cam.to(torch.int32)), cu(go))
         for a, w_ in zip(got, item_k):
             close(a, w_, tol=2e-5)

@@ -39,6 +39,8 @@ ring = ring / ring.abs().max(-1, keepdim=True)[0]
 steps = torch.arange(1, P + 1, dtype=torch.float32)
 off = torch.cat([ring.view(M, 1, 2) * steps.view(1, P, 1), (((th.cos() + th.sin()) / 2).view(M, 1) * steps.view(1, P)).unsqueeze(-1)], -1).to(dev)
 norm = torch.tensor([W, H, D], dtype=torch.float32, device=dev)
+head_shift = torch.round(ring * steps.mean()).to(torch.int32).to(dev).contiguous()     # what the module derives from the offsets' bias
+use_shift = os.environ.get("SGC_BWD_SHIFT", "1") != "0" 
 print(f"{which} {H}x{W} C={C} pairs {n}")
 
 
@@ -78,7 +80,8 @@ for cfg in configs:
     pc = ops.bin_pairs(ref_cam, dict(pc0, slot=pc0["slot"].clone()), H, W, bw, bh)
     item_b, loc1_b, loc_b, attn_b, go_b = inputs(pc)
     t_i, _ = timed(lambda: ops.dfa3d_backward_items(value, dist, shapes3, lsi, loc_b, attn_b, item_b, go_b))
-    t1, o1 = timed(lambda: ops.dfa3d_backward_binned(value, dist, loc_b, attn_b, pc["bin_offset"], go_b, H, W, bw, bh, (hx, hy)))
+    t1, o1 = timed(lambda: ops.dfa3d_backward_binned(value, dist, loc_b, attn_b, pc["bin_offset"], go_b, H, W, bw, bh, (hx, hy),
+                                                     head_shift=head_shift if use_shift else None))
     t2, o2 = timed(lambda: ops.dfa3d_backward_binned(value, dist, loc1_b, None, pc["bin_offset"], go_b, H, W, bw, bh, (hx, hy),
                                                       want_grad_loc=False, want_grad_attn=False))
     cnt = (pc["bin_offset"][1:] - pc["bin_offset"][:-1]).float()
