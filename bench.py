@@ -404,7 +404,7 @@ def main():
     scene_graph_was, det.scene_graph = det.scene_graph, False
     tail_graph, det.use_graph = det.use_graph, False        # events cannot be recorded inside a capture / replay
     if args.eager_geometry == "latency":
-        set_throughput_mode(False)
+        set_throughput_mode(False, keep_winograd=True)   # the splits of the latency geometry, the SAME convolution forms as the timed graphs
     ops.event_log = []
     ops.event_names = None if args.breakdown else PATH_KERNELS
     calls0 = ops.n_calls
@@ -417,7 +417,7 @@ def main():
     lib_calls_per_scene = (ops.n_calls - calls0) / max(6, min(n_timed, 20))
     det.scene_graph, det.use_graph = scene_graph_was, tail_graph
     if args.eager_geometry == "latency":
-        set_throughput_mode(args.streams > 1)       # back to the geometry the graphs were captured with (the self check compares bits)
+        set_throughput_mode(args.streams > 1, keep_winograd=True)   # back to the geometry the graphs were captured with (the self check compares bits)
     roofline_pass = ("HIP events on the launch stream in an eager pass over the same scenes, one scene at a time, right "
                      "after the timed region (the timed region replays hipGraphs, which cannot carry events, with several "
                      "scenes in flight; inside it the kernel shares the chip with the other scenes and runs 0-3 % longer, see "
@@ -435,6 +435,21 @@ def main():
                 serial.append((r["volume"].clone(), r["occ"].clone(),
                                [t.clone() for t in r["centerness"] + r["bbox_pred"] + r["cls_score"]]))
         torch.cuda.synchronize()
+        # the same scenes with every convolution on the DIRECT kernel: what the Winograd-z layers cost in accuracy end to end (per layer
+        # <= 2e-5 of the tensor scale against the oracle's direct convolution, tested; here through neck + head on this run's scenes)
+        wino_diff = None
+        from sgcdet_amd.plugin import conv_plan as _cpw
+        if _cpw.WINOGRAD_Z is not False and args.conv_mode != "f32":
+            was = _cpw.WINOGRAD_Z
+            _cpw.set_winograd_z(False)
+            worst = torch.zeros((), device=device)
+            with torch.no_grad():
+                for (feats, dpt, metas), ref in zip(scenes, serial):
+                    r = det.forward_features(feats, metas, dpt)
+                    for a_, b_ in zip(r["centerness"] + r["bbox_pred"] + r["cls_score"], ref[2]):
+                        worst = torch.maximum(worst, (a_ - b_).abs().max() / b_.abs().max().clamp(min=1.0))
+            _cpw.set_winograd_z(was)
+            wino_diff = float(worst)
         det.use_graph, det.scene_graph = graph_was
         # every run is compared on its own stream, right behind the replay that produced it (no host sync, nothing
         # kept): per run one device-side flag and the largest deviations; SGC_SELF_CHECK_RUNS lengthens the check
@@ -461,7 +476,10 @@ def main():
         bad = torch.nonzero(flags).reshape(-1).tolist()
         self_check = dict(scene_runs=n_runs, mismatching=len(bad), max_abs_diff=float(devs[:, 0].max()),
                           head_max_rel_diff=float(devs[:, 1].max()),
-                          compared="volume, occupancy and all head tensors bit-exact (elementwise ==) vs serial eager launches")
+                          compared="volume, occupancy and all head tensors bit-exact (elementwise ==) vs serial eager launches",
+                          winograd_vs_direct_head_max_rel_diff=wino_diff,
+                          winograd_vs_direct_note=("largest |head tensor (as timed, Winograd-z layers) - head tensor (every layer on the direct kernel)| "
+                                                   "/ max(1, |direct|) over this run's scenes, serial eager launches" if wino_diff is not None else None))
         if os.environ.get("SGC_BENCH_DEBUG"):
             print("self-check mismatching runs:", bad, file=sys.stderr)
 
@@ -519,8 +537,8 @@ def main():
         mac_frac = m0.get("mac_frac", 1.0)                 # Winograd F(2,3) along z issues 18 of the 27 tap-GEMMs
         issued = top * mac_frac * nprod / t_c / 1e12
         roofline_mfma = dict(bound="mfma", achieved=round(issued, 1), peak=peak, unit="TFLOP/s", frac=round(issued / peak, 4),
-                             kernel=(("sgc_conv3d_winograd_z_bf16x3 = input transform + sgc::conv3d_halo_bf16x3_kernel (2-D form, 4 positions) + "
-                                      "output transform, all three launches inside the bracket" if mac_frac < 1.0 else
+                             kernel=(("sgc_conv3d_winograd_z_bf16x3 = sgc::conv3d_halo_bf16x3_kernel (2-D form on 4 transform-domain positions, the "
+                                      "input transform fused into its staging) + the output-transform launch, both launches inside the bracket" if mac_frac < 1.0 else
                                       "sgc::conv3d_halo_bf16x3_kernel") if bf else "sgc::conv3d_igemm_f32_kernel") +
                                     f" ({m0['Cin']}->{m0['Cout']} ch, 3x3x3, {m0['OV']} voxels)",
                              mac_frac_issued=round(mac_frac, 4),

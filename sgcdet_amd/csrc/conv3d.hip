@@ -58,6 +58,7 @@ int g_tune_halo_min_cout = 16;   // fewest output channels for which the halo ke
 
 // rows_gemm.hip: persistent weight-stationary form of the K <= 256 row GEMMs (every Linear of a level, the 1x1x1 layers)
 bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_t ldx);
+int device_cus();                // rows_gemm.hip: multiProcessorCount of the current device, cached
 int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,
                      const float *shift, const float *residual, void *y, const int32_t *m_dev, int M, int K, int N, int relu,
                      int hm_S, int hm_cm, int hm_bf16, hipStream_t st, float *zero_row = nullptr);
@@ -1140,7 +1141,7 @@ static int halo_splitk(int bricks, int nb, int nchunks) {
   // what counts is CU-time, which a split only raises.  Cost model: 13.6 us fixed + 24.2 us per slice
   // (profiles/r04_halo_fixed_cost.txt), + 20 us for the workspace round trip of a split.
   if (g_tune_halo_wave_fix && (g_tune_halo_split_target >= 192 || g_tune_halo_wave_fix == 2) && splitk == 1 && nchunks >= 2) {
-    const int cus = 256;
+    const int cus = device_cus();                 // queried (a partitioned device or another SKU has another count)
     const int64_t w1 = (int64_t)bricks * nb, w2 = 2 * w1;
     const double t1 = (double)((w1 + cus - 1) / cus) * (13.6 + 24.2 * nchunks);
     const double t2 = (double)((w2 + cus - 1) / cus) * (13.6 + 24.2 * ((nchunks + 1) / 2)) + 20.0;
@@ -2321,7 +2322,8 @@ extern "C" int64_t sgc_conv3d_winograd_z_workspace_floats(int ix, int iy, int iz
 }
 
 // 3x3x3 stride-1 convolution through the Winograd F(2,3) transform along z (see the kernels above): wg_hi / wg_lo are the bf16 hi / lo
-// planes of the TRANSFORMED weights [4][9][Cout][Cin] (position, (dx, dy) tap); workspace >= 2 V (Cin + Cout) floats.
+// planes of the TRANSFORMED weights [4][9][Cout][Cin] (position, (dx, dy) tap); workspace >= 2 V Cout floats (the four transform-domain
+// outputs; the input transform is fused into the halo staging, so no transformed copy of the input exists): two launches.
 extern "C" int sgc_conv3d_winograd_z_bf16x3(const float *x, const uint16_t *wg_hi, const uint16_t *wg_lo, const float *scale,
                                             const float *shift, const float *residual_or_null, float *y, int ix, int iy, int iz,
                                             int Cin, int Cout, int relu, float *workspace, int64_t workspace_floats,

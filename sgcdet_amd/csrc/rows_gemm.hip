@@ -399,7 +399,7 @@ bool rows_gemm_supported(int K, int N, int hm_cm, int hm_S, int64_t rows, int64_
   return true;
 }
 
-static int device_cus() {
+int device_cus() {      // also conv3d.hip (the wave-quantisation model of the halo kernel)
   static std::atomic<int> cached{0};
   int c = cached.load(std::memory_order_relaxed);
   if (c > 0) return c;

@@ -186,20 +186,43 @@ class TrainWeightPlanes:
     per-step views of a fused parameter (``in_proj_weight[:C]``) map to one entry; an entry no ``get`` has asked for during two
     steps is dropped (its parameter is gone or has moved).  ``SGC_TRAIN_PACK_BATCH=0`` restores the pack-per-use form."""
 
+    MAX_ENTRIES = 1024             # callers that never reach begin_step (stand-alone Functions, tests) cannot grow the table without bound
+
     def __init__(self):
         self.entries = {}          # (data_ptr, shape, transpose, flip, pad_rows, pad_cols) -> dict
+        self.ephemeral = {}        # data_ptr of a per-step temporary (mark_ephemeral) -> dict(ref=tensor, planes={form key: (hi, lo)})
         self.plans = None          # per device: (entries, launch plan)
         self.enabled = os.environ.get("SGC_TRAIN_PACK_BATCH", "1") != "0"
         self.launches = 0          # batched launches so far (tests)
         self.step = 0
 
+    def mark_ephemeral(self, weight):
+        """``weight`` is a temporary of this step (e.g. the head's ``torch.cat`` of three parameters): its planes are packed where they
+        are first used and shared by the step's later uses, but never REGISTERED -- a fresh temporary every step would add entries,
+        reset the batched plan (a host-side rebuild + a synchronous copy of the item list) and pin the dead storages for two steps."""
+        # the entry holds the tensor: its storage cannot be freed and re-used under the same address while the entry lives (entries go at
+        # begin_step, or oldest-first beyond eight for callers that never reach it)
+        if weight.data_ptr() not in self.ephemeral:
+            while len(self.ephemeral) >= 8:
+                del self.ephemeral[next(iter(self.ephemeral))]
+            self.ephemeral[weight.data_ptr()] = dict(ref=weight, planes={})
+
     def get(self, weight, transpose=False, flip=False, pad_rows=1, pad_cols=1):
         ops = ext.ops()
         if not self.enabled or not weight.is_cuda or weight.dtype != torch.float32 or not weight.is_contiguous():
             return ops.pack_conv_weight(weight.detach().float(), transpose=transpose, flip=flip, pad_rows=pad_rows, pad_cols=pad_cols)
+        eph = self.ephemeral.get(weight.data_ptr())
+        if eph is not None:
+            fk = (weight.shape, weight._version, transpose, flip, pad_rows, pad_cols)
+            if fk not in eph["planes"]:
+                eph["planes"][fk] = ops.pack_conv_weight(weight.detach(), transpose=transpose, flip=flip, pad_rows=pad_rows, pad_cols=pad_cols)
+            return eph["planes"][fk]
         key = (weight.data_ptr(), weight.shape, transpose, flip, pad_rows, pad_cols)
         e = self.entries.get(key)
         if e is None:
+            if len(self.entries) >= self.MAX_ENTRIES:          # least recently used half goes
+                for k in sorted(self.entries, key=lambda k: self.entries[k]["used"])[:self.MAX_ENTRIES // 2]:
+                    del self.entries[k]
             shape = ops.packed_shape(weight.shape, transpose, pad_rows, pad_cols)
             hi = torch.zeros(shape, dtype=torch.bfloat16, device=weight.device)
             lo = torch.zeros_like(hi)
@@ -229,6 +252,7 @@ class TrainWeightPlanes:
                 e["version"] = e["w"]._version
 
     def begin_step(self):
+        self.ephemeral = {}
         if not self.enabled or not self.entries:
             return
         self.step += 1
@@ -241,7 +265,7 @@ class TrainWeightPlanes:
             self.repack()
 
     def clear(self):
-        self.entries, self.plans = {}, None
+        self.entries, self.plans, self.ephemeral = {}, None, {}
 
 
 _TRAIN_PLANES = TrainWeightPlanes()

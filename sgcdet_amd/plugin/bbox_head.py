@@ -112,8 +112,9 @@ class ImVoxelHeadV2(nn.Module):
     def _forward_autograd_hip(self, feats):
         """Training / autograd path on the HIP kernels: the three 3x3x3 convolutions of a scale as ONE convolution with the
         concatenated weights (autograd splits the weight gradient back), imvoxel_head_v2.py:75-78,103-110."""
-        from ..functions import ChannelsLastConv3dFunction
+        from ..functions import ChannelsLastConv3dFunction, train_weight_planes
         w = torch.cat([self.centerness_conv.weight, self.reg_conv.weight, self.cls_conv.weight], 0)
+        train_weight_planes().mark_ephemeral(w)          # a fresh temporary every step: packed per use (once for the three scales), never registered
         n_reg = self.reg_conv.weight.shape[0]
         ctr, reg, cls = [], [], []
         for x, scale in zip(feats, self.scales):

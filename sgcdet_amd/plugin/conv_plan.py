@@ -105,7 +105,7 @@ class ConvSpec:
         # The transform-domain launch has Z/8 x ceil(X/8) x ceil(Y/8) bricks per position x 4 positions x ceil(Cout/128) column tiles
         # and no reduction split.  A layer ALONE needs enough of them to fill the chip (512 -> 128 @ 20x20x8: 36 workgroups, 154 us
         # against 55 us direct); with scenes in flight the other streams fill it and the saved multiply-adds count (+2 % at config 2).
-        if WINOGRAD_Z == "auto" and not THROUGHPUT_GEOMETRY:
+        if WINOGRAD_Z == "auto" and not WINOGRAD_IN_FLIGHT:
             wgs = (grid[2] // 8) * -(-grid[0] // 8) * -(-grid[1] // 8) * 4 * -(-self.cout_p // 128)
             if wgs < 192:
                 return None
@@ -136,10 +136,11 @@ BN_ON_HIP = os.environ.get("SGC_BN_HIP", "1") != "0"      # training-mode BatchN
 BN_FUSE_TAIL = os.environ.get("SGC_BN_FUSE_TAIL", "1") != "0"   # `+ identity` / ReLU behind a BatchNorm inside its passes (0: torch ops, A/B)
 
 
-THROUGHPUT_GEOMETRY = False      # set_throughput_mode(True): scenes in flight, kernels sized for CU-time (read by ConvSpec._winograd_planes)
+THROUGHPUT_GEOMETRY = False      # set_throughput_mode(True): scenes in flight, kernels sized for CU-time
+WINOGRAD_IN_FLIGHT = False       # the Winograd-z gate's view of it: follows set_throughput_mode unless that call says keep_winograd=True
 
 
-def set_throughput_mode(on):
+def set_throughput_mode(on, keep_winograd=False):
     """Launch geometry for several scenes in flight (one hipGraph per scene on its own stream, bench.py).  With four scenes
     overlapping the chip is CU-time bound -- the sum of workgroup residency of all kernels, not any kernel's latency, sets the
     throughput -- so kernels are sized for work per CU-second instead of for their own latency:
@@ -151,9 +152,13 @@ def set_throughput_mode(on):
         differ from the latency geometry by fp32 summation order (<= 1e-5 of the tensor scale, tested); each mode is
         deterministic and bit-identical between graph replays and eager launches.
     Together +3.5 % scenes/s (alternated runs).  Off = the latency-optimal geometry (one scene at a time, the default of the
-    library).  Call it before the first scene: captured graphs keep the geometry they were captured with."""
-    global THROUGHPUT_GEOMETRY
+    library).  Call it before the first scene: captured graphs keep the geometry they were captured with.
+    ``keep_winograd``: the reduction splits change, the choice of the Winograd-z form per layer does NOT (bench.py's
+    ``--eager-geometry latency`` pass must time the kernels the graphs replay, not another form of the small layers)."""
+    global THROUGHPUT_GEOMETRY, WINOGRAD_IN_FLIGHT
     THROUGHPUT_GEOMETRY = bool(on)
+    if not keep_winograd:
+        WINOGRAD_IN_FLIGHT = bool(on)
     from .. import ext
     lib = ext.ops().lib
     explicit = os.environ.get("SGC_TUNE", "")

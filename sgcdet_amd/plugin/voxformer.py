@@ -328,6 +328,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
     #   True / False force it on (where supported) / off.  Same function of the inputs either way (~1e-6: association of sums).
     projected_query = {"0": False, "1": True}.get(__import__("os").environ.get("SGC_PROJECTED_QUERY", ""), "auto")   # env: A/B runs
     projected_query_min_views = 48      # measured (profiles/r05_pq_ab.txt): 40 views -1 %, 50 views +1 %, 60 views +2.6 %, 100 views +9.8 %
+    # The form's two transients (projected queries and attention-weighted features) are [voxel capacity, heads * C] fp32 EACH: 0.6 GB per
+    # level and scene in flight at config 5's 73.7 k voxels.  Past this many bytes for the pair the level keeps the per-pair K | V GEMM
+    # (whose transient grows with the pairs instead).  A static rule on shapes: nothing is queried while a graph is being captured.
+    projected_query_max_bytes = 2 << 30
 
     def _projected_query_plan(self, mha, plan):
         """qp = scale * W_k,h^T q_h as ONE Linear on the pooled feature (composed with the q / output projections of `qo`), and
@@ -349,8 +353,10 @@ class DeformCrossAttention_DFA3D(BaseModule):
             wbd[h * hd:(h + 1) * hd, h * C:(h + 1) * C] = wv[h * hd:(h + 1) * hd]
         return dict(qp=LinearSpec(wqp.float(), bqp.float()), vbd=LinearSpec(wbd.float(), bv.float(), useful=1.0 / Hn))
 
-    def _use_projected_query(self, gemm, n_views):
+    def _use_projected_query(self, gemm, n_views, n_rows_cap=0):
         if gemm is None or gemm.get("qp") is None or self.projected_query is False:
+            return False
+        if 2 * n_rows_cap * self.attention_pooling.num_heads * self.embed_dims * 4 > self.projected_query_max_bytes:
             return False
         if not _ops().view_attend_pq_supported(n_views, self.embed_dims, self.attention_pooling.num_heads):
             return False
@@ -448,7 +454,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
         if self.inter_view_aggregation == "attn":
             mha = self.attention_pooling
             w, b = mha.in_proj_weight, mha.in_proj_bias
-            if use_mfma and self._use_projected_query(gemm, N):
+            if use_mfma and self._use_projected_query(gemm, N, n_valid):
                 # K and V off the pair list (sgc_view_attend_pq): one projected query per (voxel, head) against the raw pair
                 # features, V applied once per voxel to the attention-weighted feature
                 qp = gemm["qp"](mean, count=valid_cnt)                                   # [n_valid, heads * C]

@@ -534,6 +534,26 @@ def test_train_weight_planes_repack_once_per_step_and_never_serve_stale():
     assert len(tp.entries) == 1                        # everything not asked for during two steps is gone
     hi, lo = tp.get(ws[1], **forms[1])
     assert hi.shape[2] == 128 and not hi[:, :, 120:].any()        # the zero padding of the planes survives the batch
+    # a per-step temporary (the head's torch.cat of three parameters): marked ephemeral, it is packed where it is
+    # used, shared by the step's later uses and NEVER registered -- no new entry, no rebuilt plan, gone at the next begin_step
+    plans_before, n_before = tp.plans, len(tp.entries)
+    for step in range(3):
+        cat = torch.cat([ws[0].detach(), ws[0].detach() * 2.0], 0)
+        tp.mark_ephemeral(cat)
+        first = tp.get(cat, **forms[0])
+        assert same(first, fresh(cat, **forms[0]))
+        assert tp.get(cat.detach(), **forms[0])[0] is first[0]       # the alias a Function sees: the same planes, packed once
+        assert same(tp.get(cat, **forms[1]), fresh(cat, **forms[1]))
+        assert len(tp.entries) == n_before and tp.plans is plans_before
+        tp.begin_step()
+        assert not tp.ephemeral
+    # stand-alone callers never reach begin_step: the table is capped
+    tp2 = TrainWeightPlanes()
+    tp2.MAX_ENTRIES = 8
+    keep = [torch.randn(32, 32, device="cuda") for _ in range(20)]
+    for w in keep:
+        tp2.get(w)
+    assert len(tp2.entries) <= 8
 
 
 @pytest.mark.parametrize("cin,cout,grid,k,s,tr", [(64, 128, (8, 8, 8), 3, 2, False), (128, 256, (10, 10, 4), 3, 1, False),
