@@ -198,6 +198,19 @@ int sgc_dfa3d_backward_binned(const float *value, const float *dist, const float
                               int D, int loc_heads, int P, int bin_w, int bin_h, int halo_x, int halo_y, sgc_stream_t stream);
 int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin_w, int bin_h, int halo_x, int halo_y);
 
+/* Geometry-aware sample FUSED with the Linear that consumes it (round 6): y[p] = (sum_k w_k(p) feat[cam(p), corner_k(p), :]) @ W^T +
+ * shift -- `Grid_Sample_3D_Feature` (TU/deformable_cross_attention.py:67-116) followed by the fused offsets | logits projection of
+ * `MSDeformableAttention3D_DFA3D.forward` (:417-436), without the [pairs, C] tensor between them.  Arguments as
+ * sgc_pairs_geometry_sample + the bf16 hi / lo planes [Cout][C] of the weight; workspace >= sgc_pairs_geometry_linear_workspace_bytes(cap)
+ * (32 bytes per pair: the sample's corner weights and rows).  Bit-identical to sgc_pairs_geometry_sample + sgc_linear_rows_bf16x3.
+ * C == 128 and Cout == 128 (sgc_pairs_geometry_linear_supported). */
+int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *dist, const float *ref_cam, const int32_t *pair_cam,
+                                     const int32_t *pair_q, const int32_t *totals, const uint16_t *w_hi, const uint16_t *w_lo,
+                                     const float *shift_or_null, float *y, void *workspace, int N, int Nq, int H, int W, int C,
+                                     int D, int Cout, int cam_stride_or_0, int n_pairs_or_neg, int cap, sgc_stream_t stream);
+int sgc_pairs_geometry_linear_supported(int C, int Cout, int N, int S);
+int64_t sgc_pairs_geometry_linear_workspace_bytes(int cap);
+
 /* ------------------------------------------------------------------------- *
  * 3. Voxel -> pixel projection and per-camera compaction
  *    (replaces VoxFormerEncoder_DFA3D.point_sampling, TU/encoder.py:179-223, and

@@ -1316,6 +1316,26 @@ int sgc_linear_rows_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t 
   return sgc_conv3d_cl_bf16x3(x, w_hi, w_lo, NULL, shift, NULL, y, rows, 1, 1, Cin, Cout, 1, 1, 0, 0, NULL, 0, stream);
 }
 
+/* the geometry-aware sample followed by the Linear that consumes it (product: one fused pass, csrc/rows_gemm.hip GATHER form): here
+ * simply the two steps through a temporary */
+int sgc_pairs_geometry_linear_supported(int C, int Cout, int N, int S) { (void)N; (void)S; return C % 32 == 0 && Cout % 4 == 0; }
+int64_t sgc_pairs_geometry_linear_workspace_bytes(int cap) { return cap > 0 ? (int64_t)cap * 32 : 0; }
+int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *dist, const float *ref_cam, const int32_t *pair_cam,
+                                     const int32_t *pair_q, const int32_t *totals, const uint16_t *w_hi, const uint16_t *w_lo,
+                                     const float *shift_or_null, float *y, void *workspace, int N, int Nq, int H, int W, int C,
+                                     int D, int Cout, int cam_stride_or_0, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  (void)workspace;
+  if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  int np = n_pairs_or_neg >= 0 ? n_pairs_or_neg : (totals ? totals[0] : -1);
+  if (np < 0 || np > cap) return fail(SGC_EINVAL, "n_pairs out of range");
+  if (np == 0) return SGC_OK;
+  float *geo = (float *)malloc(sizeof(float) * (size_t)np * C);
+  int rc = sgc_pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, totals, geo, N, Nq, H, W, C, D, cam_stride_or_0, np, np, stream);
+  if (!rc) rc = sgc_linear_rows_bf16x3(geo, w_hi, w_lo, shift_or_null, y, NULL, np, C, Cout, stream);
+  free(geo);
+  return rc;
+}
+
 /* the same with one all-zero row behind the result (y holds rows_cap + 1 rows) */
 int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                 float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,

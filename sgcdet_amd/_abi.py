@@ -25,6 +25,7 @@ SIGNATURES = {
     "sgc_project_points": [_p] * 6 + [_i, _i, _f, _f, _f, _f, _p],
     "sgc_compact_pairs": [_p, _i, _i] + [_p] * 9 + [_p],
     "sgc_pairs_geometry_sample": [_p] * 7 + [_i] * 9 + [_p],
+    "sgc_pairs_geometry_linear_bf16x3": [_p] * 11 + [_i] * 10 + [_p],
     "sgc_pairs_deform_gather": [_p] * 9 + [_i] * 12 + [_p],
     "sgc_depth_pairs": [_p, _p] + [_i] * 5 + [_p],
     "sgc_bin_pairs": [_p] * 9 + [_i] * 7 + [_p],
@@ -88,6 +89,8 @@ INTROSPECTION = {
     "sgc_get_conv_products": (C.c_int, []),
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
     "sgc_dfa3d_backward_binned_lds_bytes": (C.c_int64, [_i] * 8),
+    "sgc_pairs_geometry_linear_supported": (C.c_int, [_i] * 4),
+    "sgc_pairs_geometry_linear_workspace_bytes": (C.c_int64, [_i]),
 }
 
 ABI_VERSION = 4      # == SGC_ABI_VERSION of include/sgcdet_amd.h (tests/test_abi_cpu.py compares the two)

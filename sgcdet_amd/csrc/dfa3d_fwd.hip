@@ -638,6 +638,71 @@ extern "C" int sgc_pairs_geometry_sample(const float *feat, const float *dist, c
   return launch_fwd<kPairsGeom>(p, n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Geometry-aware sample FUSED with the Linear that consumes it (round 6).  `Grid_Sample_3D_Feature` (TU/deformable_cross_attention.py:
+// 67-116) produces one C-channel row per visible pair, and the only reader of that row is the fused offsets / logits projection
+// (`sampling_offsets` | `sampling_offsets_depth` | `attention_weights`, :417-436): [pairs, C] written and read back -- 2.2 GB per scene
+// at BASELINE config 5.  Here a first launch leaves 32 bytes per pair (four corner weights = bilinear * depth score, four rows of the
+// feature map) and the row GEMM builds its A operand from them while it stages a tile (rows_gemm.hip, GATHER form): the sampled row
+// exists in registers only.  Same arithmetic as the two launches it replaces (the staged value is the fmas of the sample kernel, the
+// GEMM is the same kernel): bit-identical results.
+// ---------------------------------------------------------------------------------------------
+namespace sgc {
+bool rows_gemm_gather_supported(int K, int N, int64_t x_rows, int64_t rows);
+int rows_gemm_gather_launch(const float *x, int64_t x_rows, const float *gw, const int32_t *go, const uint16_t *w_hi, const uint16_t *w_lo,
+                            const float *shift, float *y, const int32_t *m_dev, int M, int K, int N, hipStream_t st);
+
+__global__ __launch_bounds__(256) void pairs_geometry_desc_kernel(const float *__restrict__ dist, const float *__restrict__ ref_cam,
+                                                                  const int32_t *__restrict__ pair_cam, const int32_t *__restrict__ pair_q,
+                                                                  const int32_t *__restrict__ totals, int n_items, int Nq, int S, int H, int W,
+                                                                  int D, float4 *__restrict__ gw, int4 *__restrict__ go) {
+  const int n = n_items >= 0 ? n_items : totals[0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int b = pair_cam[i], q = pair_q[i];
+    const float *rc = ref_cam + ((int64_t)b * Nq + q) * 3;
+    Sample sm;
+    make_sample(sm, dist + (int64_t)b * S * D, D, H, W, D, rc[0], rc[1], rc[2], 1.f);
+    gw[i] = make_float4(sm.w[0], sm.w[1], sm.w[2], sm.w[3]);       // 0 for a corner outside the map or gated off
+    const int row0 = b * S;
+    go[i] = make_int4(row0 + off_index(sm.off[0]), row0 + off_index(sm.off[1]), row0 + off_index(sm.off[2]), row0 + off_index(sm.off[3]));
+  }
+}
+}  // namespace sgc
+
+extern "C" int sgc_pairs_geometry_linear_supported(int C, int Cout, int N, int S) {
+  return rows_gemm_gather_supported(C, Cout, (int64_t)N * S, 1) ? 1 : 0;
+}
+extern "C" int64_t sgc_pairs_geometry_linear_workspace_bytes(int cap) { return cap > 0 ? (int64_t)cap * 32 : 0; }
+
+extern "C" int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *dist, const float *ref_cam, const int32_t *pair_cam,
+                                                const int32_t *pair_q, const int32_t *totals, const uint16_t *w_hi, const uint16_t *w_lo,
+                                                const float *shift_or_null, float *y, void *workspace, int N, int Nq, int H, int W, int C,
+                                                int D, int Cout, int cam_stride_or_0, int n_pairs_or_neg, int cap, sgc_stream_t stream) {
+  if (!feat || !dist || !ref_cam || !pair_cam || !pair_q || !w_hi || !w_lo || !y || !workspace)
+    return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: null pointer");
+  if (n_pairs_or_neg < 0 && !totals) return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: totals required");
+  if (n_pairs_or_neg > cap) return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: n_pairs > cap");
+  if (N <= 0 || Nq <= 0 || H <= 0 || W <= 0 || C <= 0 || D <= 0 || cap <= 0) return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: bad size");
+  if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: cam_stride < H*W");
+  const int S = cam_stride_or_0 > 0 ? cam_stride_or_0 : H * W;
+  if (!rows_gemm_gather_supported(C, Cout, (int64_t)N * S, cap))
+    return set_error(SGC_EUNSUP, "sgc_pairs_geometry_linear_bf16x3: needs C == 128, Cout == 128 and a map below 4 GiB (got C %d, Cout %d)", C, Cout);
+  if (((uintptr_t)feat | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)w_hi | (uintptr_t)w_lo) & 15)
+    return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  float4 *gw = reinterpret_cast<float4 *>(workspace);
+  int4 *go = reinterpret_cast<int4 *>(gw + cap);
+  const int items = n_pairs_or_neg >= 0 ? n_pairs_or_neg : cap;
+  if (items == 0) return SGC_OK;
+  const int grid = ceil_div(items, 256) < 4096 ? ceil_div(items, 256) : 4096;
+  hipLaunchKernelGGL(pairs_geometry_desc_kernel, dim3(grid), dim3(256), 0, st, dist, ref_cam, pair_cam, pair_q, totals, n_pairs_or_neg, Nq, S, H, W,
+                     D, gw, go);
+  int rc = check_launch("pairs_geometry_desc_kernel");
+  if (rc) return rc;
+  return rows_gemm_gather_launch(feat, (int64_t)N * S, reinterpret_cast<const float *>(gw), reinterpret_cast<const int32_t *>(go), w_hi, w_lo,
+                                 shift_or_null, y, n_pairs_or_neg >= 0 ? nullptr : totals, items, C, Cout, st);
+}
+
 extern "C" int sgc_pairs_deform_gather(const float *value, const float *dist, const float *dist_pairs_or_null,
                                        const float *ref_cam,
                                        const float *raw, const int32_t *pair_cam, const int32_t *pair_q,

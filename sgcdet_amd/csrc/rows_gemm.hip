@@ -65,6 +65,11 @@ struct RowsGemmParams {
   int64_t y_bytes;             // head-major output: bytes of the whole buffer (the range the stores are checked against)
   float *zero_row;             // optional: N floats the launch sets to zero (the all-zero row behind the value map the wave gather
                                // points out-of-image corners at, sgc_linear_rows_zrow_bf16x3) -- by workgroup 0, before its tiles
+  // GATHER form (sgc_pairs_geometry_linear_bf16x3): row r of the A operand is sum_k gw[r][k] * x[go[r][k]][:] -- the geometry-aware
+  // sample of a visible pair, built while the tile is staged instead of written to HBM by one kernel and read back by this one
+  const float *gw;             // [M][4] corner weights (bilinear * depth score)
+  const int32_t *go;           // [M][4] row of x of each corner (a valid row also where the weight is 0)
+  int64_t x_rows;              // rows of x (the whole feature map), GATHER only
 };
 
 constexpr int RG_ROWS = 32;
@@ -74,8 +79,9 @@ constexpr unsigned RG_OOB = 0xfffffff0u;    // a byte offset no buffer of < 4 Gi
 
 // EPI: 0 = y = acc * scale + shift (optional relu), row-major; 1 = head-major fp32 store (value_proj); 2 = row-major with
 // residual; 3 = head-major bf16 store (opt-in storage mode)
-template <int K, int NW, int DEPTH, int EPI, int NP = 3>   // NP: bf16 products per multiply-add (conv3d.hip: g_conv_products)
+template <int K, int NW, int DEPTH, int EPI, int NP = 3, bool GATHER = false>   // NP: bf16 products per multiply-add (conv3d.hip: g_conv_products)
 __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const RowsGemmParams p) {
+  static_assert(!GATHER || (DEPTH == 1 && EPI == 0), "the gather form runs the lockstep schedule with the plain epilogue");
   constexpr int NT = NW * 64;
   constexpr int KS = K / 16;                       // 16-deep k-steps
   constexpr int K4 = K / 4;                        // float4 chunks per row
@@ -103,7 +109,12 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
   // range check, so the tile loop has no branch (every wave issues the same memory instructions every iteration:
   // the compiler's counted vmcnt stays exact and the loads of the tiles ahead stay in flight across the waits).
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.x), 0, (p.diag & 2) ? 0 : (int)(unsigned)((int64_t)Mrows * p.ldx * 4), 0x00020000);
+      const_cast<float *>(p.x), 0, (p.diag & 2) ? 0 : (int)(unsigned)((int64_t)(GATHER ? p.x_rows : Mrows) * p.ldx * 4), 0x00020000);
+  // gather descriptors over the LIVE rows: past them both loads return zeros (weights 0, row 0: a valid row)
+  const __amdgpu_buffer_rsrc_t gwr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(GATHER ? p.gw : p.x), 0,
+                                                                        GATHER ? (int)(unsigned)((int64_t)Mrows * 16) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gor = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(GATHER ? p.go : (const int32_t *)p.x), 0,
+                                                                        GATHER ? (int)(unsigned)((int64_t)Mrows * 16) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
       p.y, 0, (p.diag & 1) ? 0 : (int)(unsigned)((EPI == 1 || EPI == 3) ? p.y_bytes : (int64_t)Mrows * p.N * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -133,9 +144,26 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
   const int late = STAG ? __builtin_amdgcn_readfirstlane(wid >> 2) : 0;      // 1: waves 4-7, half a period behind
   const int tl = STAG ? (tid & (NTL - 1)) : tid;
   const int ld_row = tl / K4 + late * RL, ld_c4 = tl % K4;
-  auto load_tile = [&](int t, float4 (&ra)[CH]) {
+  // A tile in flight: CH 16-byte chunks per thread -- or, GATHER, the four corner rows' chunks and their weights
+  constexpr int TV = GATHER ? 4 * CH + CH : CH;
+  auto load_tile = [&](int t, float4 (&ra)[TV]) {
     int ldx4 = (int)p.ldx * 4;
     asm volatile("" : "+s"(ldx4));
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const unsigned doff = t < ntiles ? (unsigned)(t * RG_ROWS + ld_row + i * (NTL / K4)) * 16u : RG_OOB;
+        const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(gor, doff, 0, 0);
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(gwr, doff, 0, 0);
+        ra[4 * CH + i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, o[k] * (unsigned)ldx4 + ld_c4 * 16, 0, 0);
+          ra[4 * i + k] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+      }
+      return;
+    }
     const unsigned base = t < ntiles ? (unsigned)(t * RG_ROWS + ld_row) * (unsigned)ldx4 + ld_c4 * 16 : RG_OOB;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -143,12 +171,25 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
       ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     }
   };
-  auto split_tile = [&](const float4 (&ra)[CH], int buf) {
+  auto split_tile = [&](const float4 (&ra)[TV], int buf) {
     __bf16 *a_hi = lds + buf * 2 * PLANE, *a_lo = a_hi + PLANE;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int row = ld_row + i * (NTL / K4), c4 = ld_c4;
-      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      float v[4];
+      if constexpr (GATHER) {
+        // the geometry sample's arithmetic (dfa3d_fwd_kernel<kPairsGeom>: acc += w[k] * v[k] over the corners in order, contracted
+        // to fmas): the staged row is the value sgc_pairs_geometry_sample would have written, bit for bit
+        const float wk[4] = {ra[4 * CH + i].x, ra[4 * CH + i].y, ra[4 * CH + i].z, ra[4 * CH + i].w};
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[0] = __builtin_fmaf(wk[k], ra[4 * i + k].x, v[0]); v[1] = __builtin_fmaf(wk[k], ra[4 * i + k].y, v[1]);
+          v[2] = __builtin_fmaf(wk[k], ra[4 * i + k].z, v[2]); v[3] = __builtin_fmaf(wk[k], ra[4 * i + k].w, v[3]);
+        }
+      } else {
+        v[0] = ra[i].x; v[1] = ra[i].y; v[2] = ra[i].z; v[3] = ra[i].w;
+      }
       bf16x4 h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -264,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
     // (measured on the 204,800-row Linear: staging 30 us + MFMA 33 us + memory, all additive).  Two LDS buffers are
     // enough: the half of tile i + 1 staged by waves 4-7 during the first half-period lands in the buffer of tile
     // i - 1, whose last reader (their own multiply) finished a barrier earlier.
-    float4 r0[CH];
+    float4 r0[TV];
     RG_STAMP_PTR(p, wid, late);
     load_tile(t, r0);
     split_tile(r0, 0);
@@ -303,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
     }
     if (late) store_tile(t - nstripes, acc);
   } else if constexpr (DEPTH == 2) {
-    float4 r0[CH], r1[CH];                 // tile j of this workgroup lives in set j & 1 until it is split
+    float4 r0[TV], r1[TV];                 // tile j of this workgroup lives in set j & 1 until it is split
     load_tile(t, r0);
     load_tile(t + nstripes, r1);
     split_tile(r0, 0);
@@ -339,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
     }
     if (n & 1) even();
   } else {
-    float4 r0[CH];
+    float4 r0[TV];
     int buf = 0;
     load_tile(t, r0);
     split_tile(r0, 0);
@@ -410,6 +451,48 @@ int device_cus() {      // also conv3d.hip (the wave-quantisation model of the h
     c = prop.multiProcessorCount;
   cached.store(c, std::memory_order_relaxed);
   return c;
+}
+
+// Gather form (see RowsGemmParams): K == 128, N == 128 columns (four waves), the lockstep schedule.  (K = 256: the tile in flight is
+// 8 chunks x 4 corner rows = 128 registers beside the 128 of the resident weights -- 388 bytes of scratch per lane; not instantiated.)
+bool rows_gemm_gather_supported(int K, int N, int64_t x_rows, int64_t rows) {
+  return rows_gemm_supported(K, N, 0, 0, rows, K) && K == 128 && N == 128 && x_rows > 0 && (x_rows + 1) * K * 4 < (int64_t)RG_OOB;
+}
+
+template <int K>
+static int launch_rows_gemm_gather(const RowsGemmParams &p, int grid, hipStream_t st) {
+  constexpr int smem = 2 * 2 * RG_ROWS * (K + 8) * (int)sizeof(uint16_t);
+  static std::atomic<uint64_t> attr_done{0};
+  if (g_conv_products == 1) {
+    ensure_dynamic_lds((const void *)rows_gemm_bf16x3_kernel<K, 4, 1, 0, 1, true>, smem, attr_done);
+    hipLaunchKernelGGL((rows_gemm_bf16x3_kernel<K, 4, 1, 0, 1, true>), dim3(grid), dim3(256), smem, st, p);
+  } else if (g_conv_products == 2) {
+    static std::atomic<uint64_t> attr2{0};
+    ensure_dynamic_lds((const void *)rows_gemm_bf16x3_kernel<K, 4, 1, 0, 2, true>, smem, attr2);
+    hipLaunchKernelGGL((rows_gemm_bf16x3_kernel<K, 4, 1, 0, 2, true>), dim3(grid), dim3(256), smem, st, p);
+  } else {
+    static std::atomic<uint64_t> attr3{0};
+    ensure_dynamic_lds((const void *)rows_gemm_bf16x3_kernel<K, 4, 1, 0, 3, true>, smem, attr3);
+    hipLaunchKernelGGL((rows_gemm_bf16x3_kernel<K, 4, 1, 0, 3, true>), dim3(grid), dim3(256), smem, st, p);
+  }
+  return check_launch("rows_gemm_bf16x3_kernel (gather)");
+}
+
+int rows_gemm_gather_launch(const float *x, int64_t x_rows, const float *gw, const int32_t *go, const uint16_t *w_hi, const uint16_t *w_lo,
+                            const float *shift, float *y, const int32_t *m_dev, int M, int K, int N, hipStream_t st) {
+  RowsGemmParams p = {};
+  p.x = x; p.ldx = K; p.x_rows = x_rows; p.gw = gw; p.go = go;
+  p.w_hi = reinterpret_cast<const __bf16 *>(w_hi); p.w_lo = reinterpret_cast<const __bf16 *>(w_lo);
+  p.shift = shift; p.y = y; p.m_dev = m_dev; p.M = M; p.N = N;
+  p.y_bytes = (int64_t)M * N * 4;
+  p.ncg = N / 128;
+  const int cap_tiles = ceil_div(M, RG_ROWS);
+  int stripes = device_cus() * 2 / p.ncg;                       // two 4-wave workgroups per CU
+  if (g_tune_rows_cu_pct > 0 && g_tune_rows_cu_pct < 100) stripes = stripes * g_tune_rows_cu_pct / 100;
+  if (stripes > cap_tiles) stripes = cap_tiles;
+  stripes = (stripes + 7) / 8 * 8;
+  const int grid = stripes * p.ncg;
+  return launch_rows_gemm_gather<128>(p, grid, st);
 }
 
 int rows_gemm_launch(const float *x, int64_t ldx, const uint16_t *w_hi, const uint16_t *w_lo, const float *scale,

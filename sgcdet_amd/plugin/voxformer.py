@@ -71,6 +71,9 @@ TILED_GATHER = dict(enabled=True, min_pixels=2048, storage="f32",
 # LDS.  ``bin`` / ``halo`` in feature pixels (the window = bin + 2 halo must fit 160 KiB at (Cm + 1 + D) * 4 bytes per pixel); corners
 # outside the window fall back to global atomics, so results never depend on these numbers beyond float-atomic order.
 # Env (A/B): SGC_TRAIN_BWD=0 (the item kernel, one global atomic per corner contribution) | "bin_w,bin_h,halo_x,halo_y".
+# sample + offsets | logits projection in one pass where supported (sgc_pairs_geometry_linear_bf16x3); SGC_GEO_LINEAR=0: the two launches (A/B)
+GEO_LINEAR_FUSED = __import__("os").environ.get("SGC_GEO_LINEAR", "1") != "0"
+
 TRAIN_BWD_TILED = dict(enabled=True, bin=(8, 22), halo=(2, 2))       # 12 x 26-pixel windows: 79 KB of LDS at Cm = 32, two workgroups per CU (sweep: profiles/r06_bwd_tile_bench_cfg2.txt)
 
 
@@ -408,7 +411,19 @@ class DeformCrossAttention_DFA3D(BaseModule):
             # that order (slot is rewritten, so the inter-view stages do not notice)
             pc = ops.bin_pairs(ref_cam, pc, H, W, bw, bh)
             pair_q = pc["pair_q"]
-        geo = ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=totals)
+        # The sampled row of a pair has ONE reader, the fused offsets | logits projection: where the entry point takes the shape
+        # (C = 128: BASELINE configs 4 / 5) sample and projection are one pass and the [pairs, C] tensor never exists
+        # (sgc_pairs_geometry_linear_bf16x3; bit-identical to the two launches)
+        fuse_geo = (GEO_LINEAR_FUSED and self.deformable_attn and not self.geo_residual and use_mfma and CONV_MODE == "bf16x3"
+                    and da.num_levels == 1 and ops.pairs_geometry_linear_supported(C, da.num_heads * da.num_points * 4, N, S))
+        geo = None if fuse_geo else ops.pairs_geometry_sample(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=totals)
+
+        def raw_projection(spec):
+            if fuse_geo:
+                return ops.pairs_geometry_linear(feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, spec.w_hi, spec.w_lo, spec.shift,
+                                                 totals=totals)
+            return spec(geo, count=pairs_cnt)
+
         if self.deformable_attn:
             if da.num_levels != 1:
                 raise NotImplementedError("pair-list path supports num_levels == 1 (all SGCDet configs)")
@@ -421,7 +436,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
                     # the head-major layout the tiled gather stages its windows from (the copy costs ~70 us at the finest
                     # config-2 level, the tiled gather saves ~180 against the wave kernel)
                     value = gemm["value"](feat.view(N * S, C)).view(N, S, da.num_heads, Cm).permute(0, 2, 1, 3).contiguous()
-                raw = gemm["raw_hm"](geo, count=pairs_cnt)
+                raw = raw_projection(gemm["raw_hm"])
                 if not self.geo_residual:
                     del geo
                 # the storage mode covers both maps: bf16 depth distributions beside the bf16 value map (one cast per level)
@@ -435,7 +450,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
             else:
                 zero_row = use_mfma and CONV_MODE == "bf16x3"
                 value = gemm["value"](feat.view(N * S, C), extra_zero_row=zero_row) if use_mfma else da.value_proj(feat)
-                raw = gemm["raw"](geo, count=pairs_cnt) if use_mfma else da.raw_projection(geo)
+                raw = raw_projection(gemm["raw"]) if use_mfma else da.raw_projection(geo)
                 if not self.geo_residual:
                     del geo                               # capacity-sized in static mode: let the allocator reuse it
                 per_pair = ops.pairs_deform_gather(value.view(N, S, da.num_heads, C // da.num_heads), dist,

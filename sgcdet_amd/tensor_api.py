@@ -299,6 +299,35 @@ class TensorOps:
         out["row_of"] = ws[:Nq]            # inverse of valid_index (-1: seen by no camera), left in the workspace
         return out
 
+    def pairs_geometry_linear_supported(self, C, Cout, N, S):
+        return bool(self.lib._dll.sgc_pairs_geometry_linear_supported(int(C), int(Cout), int(N), int(S)))
+
+    def pairs_geometry_linear(self, feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, w_hi, w_lo, shift=None, totals=None):
+        """The geometry-aware sample of every visible pair FUSED with the Linear that consumes it
+        (``sgc_pairs_geometry_linear_bf16x3``): y [cap, Cout] = sample(feat, dist, ref)[cap, C] @ W^T + shift without the sampled rows
+        in memory.  Arguments as ``pairs_geometry_sample`` (``n_pairs`` < 0: the count is ``totals[0]`` on the device) + the bf16
+        hi / lo planes [1, Cout, C] of the weight.  Bit-identical to ``pairs_geometry_sample`` + ``linear_rows_bf16x3``."""
+        self._check(feat=feat, dist=dist, ref_cam=ref_cam, pair_cam=pair_cam, pair_q=pair_q, totals=totals, w_hi=w_hi, w_lo=w_lo, shift=shift)
+        self._f32(feat=feat, dist=dist, ref_cam=ref_cam, shift=shift)
+        self._i32(pair_cam=pair_cam, pair_q=pair_q, totals=totals)
+        N, S, C = feat.shape
+        D = dist.shape[-1]
+        Nq = ref_cam.shape[1]
+        cap = pair_q.numel()
+        Cout = w_hi.shape[-2]
+        if w_hi.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape or w_hi.shape[-1] != C or w_hi.numel() != Cout * C:
+            raise RuntimeError("pairs_geometry_linear: w_hi / w_lo must be bfloat16 [1, Cout, C]")
+        if S < H * W or dist.numel() != N * S * D:
+            raise RuntimeError("pairs_geometry_linear: inconsistent map shapes")
+        y = torch.empty((cap, Cout), dtype=torch.float32, device=feat.device)
+        if cap == 0 or n_pairs == 0:
+            return y
+        ws = torch.empty(max(int(self.lib._dll.sgc_pairs_geometry_linear_workspace_bytes(cap)), 16), dtype=torch.uint8, device=feat.device)
+        self._call("sgc_pairs_geometry_linear_bf16x3", feat, dist, ref_cam, pair_cam, pair_q, totals, w_hi, w_lo, shift, y, ws, N, ref_cam.shape[1],
+                   int(H), int(W), C, D, Cout, S if S != H * W else 0, int(n_pairs), cap,
+                   _meta=dict(V=cap if n_pairs < 0 else int(n_pairs), Cin=C, Cout=Cout, taps=1, OV=cap if n_pairs < 0 else int(n_pairs)))
+        return y if n_pairs < 0 else y[:int(n_pairs)]
+
     # ---- 4. pair-list gathers ------------------------------------------------
     def pairs_geometry_sample(self, feat, dist, ref_cam, pair_cam, pair_q, n_pairs, H, W, totals=None):
         self._check(feat=feat, dist=dist, ref_cam=ref_cam, pair_cam=pair_cam, pair_q=pair_q, totals=totals)

@@ -665,6 +665,39 @@ def test_bf16_storage_mode_of_the_tiled_gather(C, HW, bins, oracle_ops, gpu_ops)
     assert torch.equal(y16, y32.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("HW,stride_extra", [((29, 40), 0), ((15, 20), 0), ((14, 20), 20)])
+def test_geometry_sample_fused_with_its_linear(HW, stride_extra, oracle_ops, gpu_ops):
+    """sgc_pairs_geometry_linear_bf16x3 (round 6): the geometry-aware sample of every visible pair built while the row GEMM stages
+    its tile == sgc_pairs_geometry_sample + sgc_linear_rows_bf16x3, BIT FOR BIT (same fmas, same GEMM kernel), host-counted and
+    device-counted, with the cropped-row camera stride; and within the bf16x3 bound of the oracle's two steps."""
+    N, Nq, C, D, Cout = 5, 800, 128, 12, 128
+    H, W = HW
+    S = H * W + stride_extra
+    ref3d, origin, proj = _scene(N, Nq, 13)
+    rc, mk = oracle_ops.project_points(ref3d, origin, proj, 320., 239., 0.2, 5.0)
+    pc = oracle_ops.compact_pairs(mk)
+    n = int(pc["totals"][0])
+    g = torch.Generator().manual_seed(31)
+    feat = torch.randn(N, S, C, generator=g)
+    dist = torch.randn(N, S, D, generator=g).mul(2).softmax(-1).contiguous()
+    w = torch.randn(1, Cout, C, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    hi, lo = gpu_ops.split_bf16(w)
+    cu = lambda t: t.cuda()
+    gpc = {k: cu(v) for k, v in pc.items()}
+    assert gpu_ops.pairs_geometry_linear_supported(C, Cout, N, S)
+    geo = gpu_ops.pairs_geometry_sample(cu(feat), cu(dist), cu(rc), gpc["pair_cam"], gpc["pair_q"], n, H, W)
+    two = gpu_ops.linear_rows_bf16x3(geo, cu(hi), cu(lo), cu(b))
+    one = gpu_ops.pairs_geometry_linear(cu(feat), cu(dist), cu(rc), gpc["pair_cam"], gpc["pair_q"], n, H, W, cu(hi), cu(lo), cu(b))
+    assert one.shape == two.shape and torch.equal(one, two)
+    dev = gpu_ops.pairs_geometry_linear(cu(feat), cu(dist), cu(rc), gpc["pair_cam"], gpc["pair_q"], -1, H, W, cu(hi), cu(lo), cu(b),
+                                        totals=gpc["totals"])
+    assert torch.equal(dev[:n], two)
+    want = oracle_ops.pairs_geometry_linear(feat, dist, rc, pc["pair_cam"], pc["pair_q"], n, H, W, hi, lo, b)
+    close(one, want, tol=1e-4)
+    assert not gpu_ops.pairs_geometry_linear_supported(256, Cout, N, S)        # C = 256: the tile in flight would spill (rows_gemm.hip)
+
+
 def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
     """sgc_dfa3d_forward_items / sgc_dfa3d_backward_items (training path on pair lists) vs the oracle."""
     B, S_hw, M, Cm, D, L, P, n = 4, (9, 11), 8, 8, 6, 1, 4, 333
