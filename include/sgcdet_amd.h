@@ -203,7 +203,7 @@ int64_t sgc_dfa3d_backward_binned_lds_bytes(int H, int W, int Cm, int D, int bin
  * `MSDeformableAttention3D_DFA3D.forward` (:417-436), without the [pairs, C] tensor between them.  Arguments as
  * sgc_pairs_geometry_sample + the bf16 hi / lo planes [Cout][C] of the weight; workspace >= sgc_pairs_geometry_linear_workspace_bytes(cap)
  * (32 bytes per pair: the sample's corner weights and rows).  Bit-identical to sgc_pairs_geometry_sample + sgc_linear_rows_bf16x3.
- * C == 128 and Cout == 128 (sgc_pairs_geometry_linear_supported). */
+ * C in {128, 256} and Cout == 128 (sgc_pairs_geometry_linear_supported). */
 int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *dist, const float *ref_cam, const int32_t *pair_cam,
                                      const int32_t *pair_q, const int32_t *totals, const uint16_t *w_hi, const uint16_t *w_lo,
                                      const float *shift_or_null, float *y, void *workspace, int N, int Nq, int H, int W, int C,

@@ -686,7 +686,7 @@ extern "C" int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *
   if (cam_stride_or_0 > 0 && cam_stride_or_0 < H * W) return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: cam_stride < H*W");
   const int S = cam_stride_or_0 > 0 ? cam_stride_or_0 : H * W;
   if (!rows_gemm_gather_supported(C, Cout, (int64_t)N * S, cap))
-    return set_error(SGC_EUNSUP, "sgc_pairs_geometry_linear_bf16x3: needs C == 128, Cout == 128 and a map below 4 GiB (got C %d, Cout %d)", C, Cout);
+    return set_error(SGC_EUNSUP, "sgc_pairs_geometry_linear_bf16x3: needs C in {128, 256}, Cout == 128 and a map below 4 GiB (got C %d, Cout %d)", C, Cout);
   if (((uintptr_t)feat | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)w_hi | (uintptr_t)w_lo) & 15)
     return set_error(SGC_EINVAL, "sgc_pairs_geometry_linear_bf16x3: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;

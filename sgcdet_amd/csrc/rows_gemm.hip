@@ -404,6 +404,147 @@ __global__ __launch_bounds__(NW * 64, 2) void rows_gemm_bf16x3_kernel(const Rows
 
 extern int g_conv_products;      // conv3d.hip
 
+// ---------------------------------------------------------------------------------------------
+// Gather form at K = 256 (round 6): PRODUCER and CONSUMER waves.  In the kernel above a wave stages its share of the next tile AND
+// multiplies the current one: at K = 256 with the gather that is the resident weights of its 32 columns (128 registers) plus a tile in
+// flight of 8 chunks x 4 corner rows (128 registers + weights of the corners) -- 388 bytes of scratch per lane.  Here the two jobs
+// sit on different waves of an 8-wave workgroup, so neither register set meets the other:
+//   waves 0-3 (consumers)  hold the weights of 32 columns each (N = 128) and multiply tile i from LDS buffer i & 1, then store it;
+//   waves 4-7 (producers)  request the corner rows of tile i + 2, build tile i + 1's rows (the sample's fmas), split them to bf16 hi | lo
+//                          and write LDS buffer (i + 1) & 1;
+// ONE barrier per tile: behind barrier i buffer i & 1 holds tile i and every consumer is done with buffer (i + 1) & 1 (tile i - 1).
+// Same A values (the fmas of the geometry sample), same k order and product order as the plain kernel: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int K, int NP>
+__global__ __launch_bounds__(512) void rows_gemm_gather_pc_kernel(const RowsGemmParams p) {
+  constexpr int KS = K / 16, K4 = K / 4, PITCH = K + 8, PLANE = RG_ROWS * PITCH;
+  constexpr int NTP = 256;                          // producer threads
+  constexpr int CH = RG_ROWS * K4 / NTP;            // chunks per producer thread and tile (8 at K = 256)
+  static_assert(RG_ROWS * K4 % NTP == 0 && NTP % K4 == 0, "tile must deal evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rg_smem[];
+  __bf16 *lds = reinterpret_cast<__bf16 *>(rg_smem);   // [2 buffers][hi | lo][32][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int Mrows = p.m_dev ? min(p.M, *p.m_dev) : p.M;
+  const int ntiles = (Mrows + RG_ROWS - 1) / RG_ROWS;
+  const int stripe = blockIdx.x, nstripes = gridDim.x;           // N == 128: one column group
+  if (stripe >= ntiles) return;
+  const int n = (ntiles - stripe + nstripes - 1) / nstripes;    // tiles of this workgroup, >= 1
+  const bool consumer = wid < 4;
+  if (consumer) {
+    const int col = wid * 32 + fr;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(unsigned)((int64_t)Mrows * p.N * 4), 0x00020000);
+    bf16x8 bh[KS], bl[KS];
+    {
+      const __bf16 *wh = p.w_hi + (int64_t)col * K + fh * 8, *wl = p.w_lo + (int64_t)col * K + fh * 8;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        bh[kk] = *reinterpret_cast<const bf16x8 *>(wh + kk * 16);
+        if constexpr (NP == 3) bl[kk] = *reinterpret_cast<const bf16x8 *>(wl + kk * 16);
+      }
+    }
+    const float sc = p.scale ? p.scale[col] : 1.f, sh = p.shift ? p.shift[col] : 0.f;
+    constexpr int PD = 3;
+    int t = stripe;
+    for (int i = 0; i < n; ++i, t += nstripes) {
+      __syncthreads();                                           // tile i is in buffer i & 1
+      const __bf16 *a_hi = lds + (i & 1) * 2 * PLANE + fr * PITCH + fh * 8, *a_lo = a_hi + PLANE;
+      f32x16 acc;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+      bf16x8 ah[PD + 1], al[PD + 1];
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) {
+        ah[kk] = *reinterpret_cast<const bf16x8 *>(a_hi + kk * 16);
+        if constexpr (NP == 3) al[kk] = *reinterpret_cast<const bf16x8 *>(a_lo + kk * 16);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        if (kk + PD < KS) {
+          ah[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_hi + (kk + PD) * 16);
+          if constexpr (NP == 3) al[(kk + PD) % (PD + 1)] = *reinterpret_cast<const bf16x8 *>(a_lo + (kk + PD) * 16);
+        }
+        if constexpr (NP == 3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk % (PD + 1)], bh[kk], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk % (PD + 1)], bl[kk], acc, 0, 0, 0);
+        }
+        acc = mma_hh<NP>(ah[kk % (PD + 1)], bh[kk], acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      int n4 = p.N * 4;
+      asm volatile("" : "+s"(n4));
+      const unsigned base = (unsigned)(t * RG_ROWS + 4 * fh) * (unsigned)n4 + col * 4;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float v = acc[k] * sc;                              // two roundings, as the plain kernel's epilogue
+        asm volatile("" : "+v"(v));
+        v += sh;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, base + ((k & 3) + 8 * (k >> 2)) * n4, 0, 0);
+      }
+    }
+    __syncthreads();                                             // the producers' last barrier
+    return;
+  }
+  // ---------------- producers ----------------
+  const int pt = tid - 256;
+  const int ld_row = pt / K4, ld_c4 = pt % K4;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)(unsigned)(p.x_rows * p.ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t gwr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gw), 0, (int)(unsigned)((int64_t)Mrows * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t gor = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.go), 0, (int)(unsigned)((int64_t)Mrows * 16), 0x00020000);
+  float4 rv[4 * CH], rw[CH];
+  auto request = [&](int t) {
+    int ldx4 = (int)p.ldx * 4;
+    asm volatile("" : "+s"(ldx4));
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const unsigned doff = t < ntiles ? (unsigned)(t * RG_ROWS + ld_row + i * (NTP / K4)) * 16u : RG_OOB;
+      const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(gor, doff, 0, 0);
+      const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(gwr, doff, 0, 0);
+      rw[i] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, o[k] * (unsigned)ldx4 + ld_c4 * 16, 0, 0);
+        rv[4 * i + k] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      }
+    }
+  };
+  auto build = [&](int buf) {
+    __bf16 *a_hi = lds + buf * 2 * PLANE, *a_lo = a_hi + PLANE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int row = ld_row + i * (NTP / K4);
+      const float wk[4] = {rw[i].x, rw[i].y, rw[i].z, rw[i].w};
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[0] = __builtin_fmaf(wk[k], rv[4 * i + k].x, v[0]); v[1] = __builtin_fmaf(wk[k], rv[4 * i + k].y, v[1]);
+        v[2] = __builtin_fmaf(wk[k], rv[4 * i + k].z, v[2]); v[3] = __builtin_fmaf(wk[k], rv[4 * i + k].w, v[3]);
+      }
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hb = op_hi<NP>(v[e]);
+        h[e] = hb;
+        l[e] = op_lo<NP>(v[e], hb);
+      }
+      *reinterpret_cast<bf16x4 *>(a_hi + row * PITCH + ld_c4 * 4) = h;
+      if constexpr (NP == 3) *reinterpret_cast<bf16x4 *>(a_lo + row * PITCH + ld_c4 * 4) = l;
+    }
+  };
+  int t = stripe;
+  request(t);
+  build(0);
+  request(t + nstripes);
+  for (int i = 0; i < n; ++i) {
+    __syncthreads();                                             // tile i published; buffer (i + 1) & 1 is free
+    if (i + 1 < n) {
+      build((i + 1) & 1);
+      request(t + (i + 2) * nstripes);
+    }
+  }
+  __syncthreads();
+}
+
 template <int K, int NW, int DEPTH, int EPI, int NP>
 static int launch_rows_gemm_np(const RowsGemmParams &p, int grid, hipStream_t st) {
   constexpr int smem = 2 * 2 * RG_ROWS * (K + 8) * (int)sizeof(uint16_t);
@@ -453,10 +594,18 @@ int device_cus() {      // also conv3d.hip (the wave-quantisation model of the h
   return c;
 }
 
-// Gather form (see RowsGemmParams): K == 128, N == 128 columns (four waves), the lockstep schedule.  (K = 256: the tile in flight is
-// 8 chunks x 4 corner rows = 128 registers beside the 128 of the resident weights -- 388 bytes of scratch per lane; not instantiated.)
+// Gather form (see RowsGemmParams): N == 128 columns; K == 128 on the kernel above (four waves, the lockstep schedule), K == 256 on
+// the producer / consumer kernel (rows_gemm_gather_pc_kernel).
 bool rows_gemm_gather_supported(int K, int N, int64_t x_rows, int64_t rows) {
-  return rows_gemm_supported(K, N, 0, 0, rows, K) && K == 128 && N == 128 && x_rows > 0 && (x_rows + 1) * K * 4 < (int64_t)RG_OOB;
+  return rows_gemm_supported(K, N, 0, 0, rows, K) && N == 128 && x_rows > 0 && (x_rows + 1) * K * 4 < (int64_t)RG_OOB;
+}
+
+template <int NP>
+static void launch_gather_pc(const RowsGemmParams &p, int grid, hipStream_t st) {
+  constexpr int smem = 2 * 2 * RG_ROWS * (256 + 8) * (int)sizeof(uint16_t);
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void *)rows_gemm_gather_pc_kernel<256, NP>, smem, attr_done);
+  hipLaunchKernelGGL((rows_gemm_gather_pc_kernel<256, NP>), dim3(grid), dim3(512), smem, st, p);
 }
 
 template <int K>
@@ -492,6 +641,15 @@ int rows_gemm_gather_launch(const float *x, int64_t x_rows, const float *gw, con
   if (stripes > cap_tiles) stripes = cap_tiles;
   stripes = (stripes + 7) / 8 * 8;
   const int grid = stripes * p.ncg;
+  if (K == 256) {
+    int s8 = device_cus();                                      // one 8-wave workgroup per CU
+    if (g_tune_rows_cu_pct > 0 && g_tune_rows_cu_pct < 100) s8 = s8 * g_tune_rows_cu_pct / 100;
+    if (s8 > cap_tiles) s8 = cap_tiles;
+    if (g_conv_products == 1) launch_gather_pc<1>(p, s8, st);
+    else if (g_conv_products == 2) launch_gather_pc<2>(p, s8, st);
+    else launch_gather_pc<3>(p, s8, st);
+    return check_launch("rows_gemm_gather_pc_kernel");
+  }
   return launch_rows_gemm_gather<128>(p, grid, st);
 }
 

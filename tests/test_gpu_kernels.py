@@ -665,12 +665,14 @@ def test_bf16_storage_mode_of_the_tiled_gather(C, HW, bins, oracle_ops, gpu_ops)
     assert torch.equal(y16, y32.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("C", [128, 256])
 @pytest.mark.parametrize("HW,stride_extra", [((29, 40), 0), ((15, 20), 0), ((14, 20), 20)])
-def test_geometry_sample_fused_with_its_linear(HW, stride_extra, oracle_ops, gpu_ops):
+def test_geometry_sample_fused_with_its_linear(HW, stride_extra, C, oracle_ops, gpu_ops):
     """sgc_pairs_geometry_linear_bf16x3 (round 6): the geometry-aware sample of every visible pair built while the row GEMM stages
     its tile == sgc_pairs_geometry_sample + sgc_linear_rows_bf16x3, BIT FOR BIT (same fmas, same GEMM kernel), host-counted and
-    device-counted, with the cropped-row camera stride; and within the bf16x3 bound of the oracle's two steps."""
-    N, Nq, C, D, Cout = 5, 800, 128, 12, 128
+    device-counted, with the cropped-row camera stride; and within the bf16x3 bound of the oracle's two steps.  C = 128: the gather
+    form of the persistent row GEMM; C = 256: its producer / consumer form (rows_gemm_gather_pc_kernel)."""
+    N, Nq, D, Cout = 5, 800, 12, 128
     H, W = HW
     S = H * W + stride_extra
     ref3d, origin, proj = _scene(N, Nq, 13)
@@ -695,7 +697,7 @@ def test_geometry_sample_fused_with_its_linear(HW, stride_extra, oracle_ops, gpu
     assert torch.equal(dev[:n], two)
     want = oracle_ops.pairs_geometry_linear(feat, dist, rc, pc["pair_cam"], pc["pair_q"], n, H, W, hi, lo, b)
     close(one, want, tol=1e-4)
-    assert not gpu_ops.pairs_geometry_linear_supported(256, Cout, N, S)        # C = 256: the tile in flight would spill (rows_gemm.hip)
+    assert not gpu_ops.pairs_geometry_linear_supported(C, 256, N, S)        # only the 128-column projection (M * P * 4)
 
 
 def test_item_list_operator_and_backward_against_oracle(oracle_ops, gpu_ops):
