@@ -42,7 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-MFMA_SUSTAINED_TFLOPS = 1847.0   # dense bf16 MFMA rate the chip holds at its power limit on random operands (profiles/r04_mfma_power.txt)
+MFMA_SUSTAINED_TFLOPS = 1882.0   # dense bf16 MFMA rate the chip holds at its power limit on random operands (profiles/r06_mfma_power.txt:
+                                 # 1882 TFLOP/s at 1.87 GHz / 1.34 kW on the round-6 tree's box; round 4 read 1847 at 1.89 GHz / 1.31 kW)
 
 
 def parse():
@@ -129,7 +130,7 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 # (MFMA roofline); together they are the work the whole-path floor of `path_roofline` is made of
 PATH_KERNELS = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_pairs_geometry_sample", "sgc_conv3d_cl_bf16x3",
                 "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_bf16x3_act", "sgc_conv3d_winograd_z_bf16x3", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3",
-                "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3"}
+                "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3", "sgc_pairs_geometry_linear_bf16x3"}
 
 
 def usable_cores():
@@ -575,13 +576,15 @@ def main():
                         - (4 - m.get("depth_bytes", 4)) * m["N"] * m["H"] * m["W"] * m["D"]
                 elif name == "sgc_pairs_geometry_sample":     # raw map + depth map + (u, v, z) per pair + output (B_gs)
                     gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * (12 + m["C"] * 4)
+                elif name == "sgc_pairs_geometry_linear_bf16x3":   # the sample fused with its Linear: B_gs WITHOUT the sampled rows, which
+                    gbytes += m["N"] * m["H"] * m["W"] * (m["C"] + m["D"]) * 4 + m["n_pairs"] * 12      # no longer exist (the floor shrinks)
         gbytes /= n_e
         bf = args.conv_mode != "f32"
         issued = gemm_issued * (3 if args.conv_mode == "bf16x3" else 1)
         floor_ms = (issued / ((2500.0 if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         # the same floor with the matrix pipe priced at what it SUSTAINS under the package power limit on non-zero data
-        # (1847 TFLOP/s at 1.89 GHz / 1.31 kW, tools/probe/mfma_power.hip, profiles/r04_mfma_power.txt; the 2.5 PFLOP/s of
-        # the guide is reached with all-zero operands only: 2461 TFLOP/s at 2.39 GHz / 0.85 kW) -- reported beside `frac`
+        # (1882 TFLOP/s at 1.87 GHz / 1.34 kW, tools/probe/mfma_power.hip, profiles/r06_mfma_power.txt; the 2.5 PFLOP/s of
+        # the guide is reached with all-zero operands only: 2477 TFLOP/s at 2.39 GHz / 0.86 kW) -- reported beside `frac`
         floor_pl_ms = (issued / ((MFMA_SUSTAINED_TFLOPS if bf else 157.0) * 1e12) + gbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
         path_roofline = dict(gather_mb_algorithmic=round(gbytes / 1e6, 1), gemm_gflop_algorithmic=round(gemm / 1e9, 1),
                              gemm_gflop_issued=round(issued / 1e9, 1), floor_ms_per_scene=round(floor_ms, 3),

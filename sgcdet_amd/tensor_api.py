@@ -325,7 +325,8 @@ class TensorOps:
         ws = torch.empty(max(int(self.lib._dll.sgc_pairs_geometry_linear_workspace_bytes(cap)), 16), dtype=torch.uint8, device=feat.device)
         self._call("sgc_pairs_geometry_linear_bf16x3", feat, dist, ref_cam, pair_cam, pair_q, totals, w_hi, w_lo, shift, y, ws, N, ref_cam.shape[1],
                    int(H), int(W), C, D, Cout, S if S != H * W else 0, int(n_pairs), cap,
-                   _meta=dict(V=cap if n_pairs < 0 else int(n_pairs), Cin=C, Cout=Cout, taps=1, OV=cap if n_pairs < 0 else int(n_pairs)))
+                   _meta=dict(V=cap if n_pairs < 0 else int(n_pairs), Cin=C, Cout=Cout, taps=1, OV=cap if n_pairs < 0 else int(n_pairs),
+                              N=N, H=int(H), W=int(W), C=C, D=D, n_pairs=cap if n_pairs < 0 else int(n_pairs)))
         return y if n_pairs < 0 else y[:int(n_pairs)]
 
     # ---- 4. pair-list gathers ------------------------------------------------

@@ -269,7 +269,8 @@ def test_committed_bench_lines_follow_from_their_own_fields():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     from roofline_check import check_line
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(root, "profiles", "r05_bench_*.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(root, "profiles", "r05_bench_*.json"))
+                   + glob.glob(os.path.join(root, "profiles", "r06_bench_*.json")))
     assert len(files) >= 8
     for f in files:
         line = open(f).readline()

@@ -1,7 +1,7 @@
 """Every bench line committed under profiles/ must follow from its own fields: roofline.frac = achieved / peak with
 achieved = algorithmic bytes / average launch time (HBM-bound kernel) or issued FLOPs / average launch time (MFMA kernel),
 path_roofline.frac = floor / measured time per scene, value = scenes / second of the timed region.
-Usage: python tools/roofline_check.py [files...]   (default: profiles/r04_bench_*.json and r05_bench_*.json); exits non-zero on a mismatch.
+Usage: python tools/roofline_check.py [files...]   (default: profiles/r04_bench_*.json, r05_bench_*.json and r06_bench_*.json); exits non-zero on a mismatch.
 tests/test_host_logic.py runs it over the committed files."""
 import glob, json, os, sys
 
@@ -39,7 +39,7 @@ def check_line(d, name="line"):
 
 
 if __name__ == "__main__":
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*.json")))
     bad = []
     for f in files:
         line = open(f).readline()
