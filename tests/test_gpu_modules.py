@@ -501,7 +501,24 @@ def test_full_size_config2_scene_against_the_oracle():
     assert res["tie_flips"] <= 8, res
     assert int(r["valid"].sum()) == 6400
     # neck + head at full size (490 + 5 GFLOP): HIP convolutions on the oracle's volume vs torch-CPU conv3d
-    _check_neck_head_on(det, vol_c, _neck_head_oracle(det, w))
+    rp2 = _neck_head_oracle(det, w)
+    _check_neck_head_on(det, vol_c, rp2)
+    # ... and in the configuration bench.py TIMES (round-5 review, parity item 3: the oracle comparison of the as-benched combination
+    # ran at 6 views only): the throughput launch geometry, where every 3x3x3 layer with >= 256 channels takes the Winograd-z form
+    # (also the 20 x 20 x 8 layers the latency geometry leaves on the direct kernel) and the few-voxel layers use the coarser splits
+    from sgcdet_amd.plugin import conv_plan
+    from sgcdet_amd import ext
+    ops = ext.ops()
+    try:
+        conv_plan.set_throughput_mode(True)
+        log = []
+        orig = ops.conv3d_winograd_z
+        ops.conv3d_winograd_z = lambda *a, **k: (log.append(a[3]), orig(*a, **k))[1]
+        _check_neck_head_on(det, vol_c, rp2)
+        assert (20, 20, 8) in log and (40, 40, 16) in log and len(log) == 7, log       # seven layers of config 2 on the form
+    finally:
+        ops.conv3d_winograd_z = orig
+        conv_plan.set_throughput_mode(False)
 
 
 def test_training_path_gradients_match_oracle_backward():
