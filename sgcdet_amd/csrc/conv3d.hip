@@ -46,6 +46,7 @@ int g_tune_halo_brick = 0;        // 0: brick shape by grid (below), 1: prefer 4
                                   // results): 8x8x4 is 1.5 - 2.5 % faster than 4x4x16 (236 vs 241 us, 129.5 vs 133, 534 vs 546;
                                   // 600 halo rows instead of 648) -> it is the choice wherever it tiles the grid exactly
 int g_tune_wgrad_waves = 8;       // weight-gradient kernel: 4 or 8 waves per 128 x 128 tile
+int g_tune_split_free = 1, g_tune_split_min_steps = 8, g_tune_split_max = 32;   // tile kernel, round 6: see pick_split_steps
 int g_tune_split_target = 512;    // implicit GEMM: tap groups are split until the launch has this many workgroups (interleaved A/B,
                                   // tools/split_ab.py: 128 / 256 are 20-30 % slower on the stride-2 and 400-voxel layers, 1024+ no better)
 int g_tune_halo_narrow = 1;       // halo kernel: 1 = 64-column tiles for layers with <= 64 output channels and 32-column tiles (8 x 1
@@ -78,6 +79,7 @@ struct ConvParams {
   int relu;
   int taps;               // ksize^3
   int splitk;             // number of tap groups (divides taps); >1 -> atomic accumulate, no epilogue
+  int steps_per;          // bf16x3 tile kernel, splitk > 1: K steps (32 channels of one tap) per split; the last split may hold fewer
   int M;                  // gx*gy*gz
   float *ws;              // optional split-K workspace [splitk][OV][Cout]: every split stores its partial tile there and
   int64_t ws_stride;      // the epilogue kernel sums them in split order (deterministic); null: float atomics into y
@@ -305,10 +307,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   int zid = bz;
   int parity = 0;
   if (p.transposed) { parity = zid % 8; zid /= 8; }
-  const int taps_per = p.taps / p.splitk;
-  const int tap_lo = zid * taps_per;
+  // Split z of a split launch owns the K steps [zid * steps_per, ...) of the (tap, channel chunk) sequence: a split boundary may fall
+  // inside a tap, so any number of splits balances a launch (round 6; groups of whole taps only allowed 3 / 9 / 27)
   const int ksteps_c = p.Cin / BK;
-  const int nsteps = taps_per * ksteps_c;
+  const int total_steps = (p.transposed ? 1 : p.taps) * ksteps_c;
+  const int step_lo = p.splitk > 1 ? zid * p.steps_per : 0;
+  const int nsteps = p.splitk > 1 ? min(p.steps_per, total_steps - step_lo) : total_steps;
+  if (nsteps <= 0) return;                              // (the host never launches an empty split)
 
   // Staging rows are dealt so that the lanes one LDS write pass covers (32 lanes x 8 B for A, 16 lanes x 16 B for B)
   // sit in rows {r, r+4, r+8, r+12}: with the 20-dword row pitch those start 16 banks apart and tile all 64 banks;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   //  split-K layers.  Two resident workgroups at 88 VGPRs hide more latency than the deeper prefetch.)
   float4 ra[ACH];
   uint4 rbh[BCH], rbl[BCH];
-  int ld_tap = p.transposed ? parity : tap_lo, ld_kc = 0;        // (tap, channel chunk) of the NEXT load_step
+  int ld_tap = p.transposed ? parity : step_lo / ksteps_c;       // (tap, channel chunk) of the NEXT load_step
+  int ld_kc = p.transposed ? step_lo : step_lo % ksteps_c;
   set_tap(ld_tap);
   auto load_step = [&]() {
     const int soff_a = __builtin_amdgcn_readfirstlane(ld_kc * (BK * 4));
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     if (++ld_kc == ksteps_c) {                          // next tap: uniform branch, once per Cin / 32 steps
       ld_kc = 0;
       ++ld_tap;
-      if (!p.transposed && ld_tap < tap_lo + taps_per) set_tap(ld_tap);
+      if (!p.transposed && ld_tap < p.taps) set_tap(ld_tap);
     }
   };
   auto store_step = [&](int buf) {
@@ -1331,6 +1337,29 @@ static int pick_splitk(const ConvParams &p, int mb, int nb, int target_blocks) {
   return splitk;
 }
 
+// bf16x3 tile kernel (round 6): splits of whole K STEPS.  Groups of whole taps (above) only allow 3 / 9 / 27 splits and overshoot the
+// target (100 tiles -> 300 or 900 workgroups on 256 CUs: some CUs carry twice the work of others); steps let a launch land on
+// floor(target / tiles) splits of equal length.  split_free = 0 restores the tap groups (A/B), split_min_steps bounds how short a
+// split may get (its prologue + the partial tile it stores are fixed costs), split_max the partial tiles the epilogue kernel re-reads.
+static int pick_split_steps(const ConvParams &p, int mb, int nb, int target_blocks, int *steps_per) {
+  const int total = (p.transposed ? 1 : p.taps) * (p.Cin / BK);
+  *steps_per = total;
+  if (p.two_d) return 1;                       // the 2-D entry point carries no workspace
+  if (!g_tune_split_free) {
+    const int k = pick_splitk(p, mb, nb, target_blocks);
+    *steps_per = total / k;
+    return k;
+  }
+  const int64_t tiles = (int64_t)mb * nb * (p.transposed ? 8 : 1);
+  int64_t want = target_blocks / (tiles > 0 ? tiles : 1);
+  if (want > total / g_tune_split_min_steps) want = total / g_tune_split_min_steps;
+  if (want > g_tune_split_max) want = g_tune_split_max;
+  if (want <= 1) return 1;
+  const int per = (total + (int)want - 1) / (int)want;
+  *steps_per = per;
+  return (total + per - 1) / per;
+}
+
 static int conv_finish(const ConvParams &p, int64_t OV, hipStream_t st) {
   if (p.splitk <= 1) return SGC_OK;
   if (p.Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
@@ -1475,7 +1504,7 @@ static int conv3d_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w
   const bool narrow = Cout <= 64;
   const int bn = narrow ? 64 : 128;
   const int mb = ceil_div(p.M, BM), nb = ceil_div(Cout, bn);
-  p.splitk = pick_splitk(p, mb, nb, g_tune_split_target);
+  p.splitk = pick_split_steps(p, mb, nb, g_tune_split_target, &p.steps_per);
   if (p.splitk > 1) {
     if (Cout % 4) return set_error(SGC_EUNSUP, "conv3d: split-K path needs Cout %% 4 == 0");
     if (p.ws && p.ws_floats >= (int64_t)p.splitk * OV * Cout) {
@@ -2424,7 +2453,8 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     // form splits further, so that neither ever falls back to float atomics for want of workspace
     ConvParams p = {};
     p.taps = 27; p.Cin = Cin; p.M = (int)M; p.gx = gx; p.gy = gy; p.gz = gz;
-    const int tile_split = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, Cout <= 64 ? 64 : 128), g_tune_split_target);
+    int per;
+    const int tile_split = pick_split_steps(p, ceil_div((int)M, BM), ceil_div(Cout, Cout <= 64 ? 64 : 128), g_tune_split_target, &per);
     if (tile_split > splitk) splitk = tile_split;
   } else {
     ConvParams p = {};
@@ -2432,7 +2462,9 @@ extern "C" int64_t sgc_conv3d_workspace_floats(int ix, int iy, int iz, int Cin, 
     p.Cin = Cin; p.M = (int)M; p.gx = gx; p.gy = gy; p.gz = gz;
     p.taps = transposed ? 8 : ksize * ksize * ksize;
     const int bn = bf16x3 ? (Cout <= 64 ? 64 : 128) : (Cout <= 32 ? 32 : 128);
-    splitk = pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target);
+    int per;
+    splitk = bf16x3 ? pick_split_steps(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target, &per)
+                    : pick_splitk(p, ceil_div((int)M, BM), ceil_div(Cout, bn), g_tune_split_target);
   }
   return splitk > 1 ? (int64_t)splitk * OV * Cout : 0;
 }

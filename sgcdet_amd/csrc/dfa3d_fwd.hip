@@ -368,7 +368,7 @@ extern int g_tune_pq_depth;         // view_pool.hip
 extern int g_tune_halo_wave_fix;     // conv3d.hip
 extern int g_tune_compact2;          // project.hip: two-launch segment form of sgc_compact_pairs
 extern int g_tune_halo_narrow;
-extern int g_tune_split_target;
+extern int g_tune_split_target, g_tune_split_free, g_tune_split_min_steps, g_tune_split_max;
 extern int g_tune_wgrad_waves;
 extern int g_tune_rows_gemm, g_tune_rows_depth, g_tune_rows_diag, g_tune_igemm_xcd, g_tune_halo_2d, g_tune_rows_cu_pct, g_tune_halo_split_target;
 extern int g_tune_topk_multi_min;
@@ -561,6 +561,9 @@ extern "C" int sgc_set_tuning(const char *key, int value) {
   if (!strcmp(key, "halo_wave_fix")) { g_tune_halo_wave_fix = value; return SGC_OK; }
   if (!strcmp(key, "halo_narrow")) { g_tune_halo_narrow = value; return SGC_OK; }
   if (!strcmp(key, "split_target")) { g_tune_split_target = value; return SGC_OK; }
+  if (!strcmp(key, "split_free")) { g_tune_split_free = value; return SGC_OK; }
+  if (!strcmp(key, "split_min_steps")) { g_tune_split_min_steps = value > 0 ? value : 1; return SGC_OK; }
+  if (!strcmp(key, "split_max")) { g_tune_split_max = value > 0 ? value : 1; return SGC_OK; }
   if (!strcmp(key, "wgrad_waves")) { g_tune_wgrad_waves = value; return SGC_OK; }
   if (!strcmp(key, "rows_gemm")) { g_tune_rows_gemm = value; return SGC_OK; }
   if (!strcmp(key, "igemm_xcd")) { g_tune_igemm_xcd = value; return SGC_OK; }

@@ -582,6 +582,46 @@ def test_tile_kernel_options_are_bit_identical(cin, cout, grid, k, s, tr, oracle
         assert torch.equal(y_v, y_d), (key, val)
 
 
+@pytest.mark.parametrize("cin,cout,grid,k,s,tr,min_steps,res,relu", [
+    (160, 128, (8, 6, 4), 3, 2, False, 8, True, 1),      # 135 K steps in 15 splits of 9: boundaries INSIDE taps (5 chunks per tap)
+    (256, 96, (5, 4, 3), 2, 2, True, 2, False, 1),       # transposed: the 8 channel chunks of a parity in 4 splits
+    (96, 128, (6, 6, 4), 1, 2, False, 1, False, 0),      # 1x1x1 stride 2: one split per channel chunk
+    (64, 200, (7, 5, 3), 3, 1, False, 4, True, 2),       # ragged rows / columns, 54 steps in 11 splits of 5 (the last one holds 4)
+])
+def test_tile_kernel_splits_of_whole_steps_against_the_oracle(cin, cout, grid, k, s, tr, min_steps, res, relu, oracle_ops, gpu_ops):
+    """Round 6: the tile kernel splits a reduction at any K step (32 channels of one tap), not only between groups of taps
+    (`pick_split_steps`, csrc/conv3d.hip).  A split that starts and ends inside a tap must decode its (tap, chunk) start, walk
+    into the next tap and stop short of the last one's end: against the oracle within the bf16x3 bound, bitwise reproducible,
+    and within summation order of the tap-group splits it replaces."""
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    V = grid[0] * grid[1] * grid[2]
+    taps = 8 if tr else k ** 3
+    x = torch.randn(V, cin, generator=g)
+    w = torch.randn(taps, cout, cin, generator=g) * (1.0 / (cin * (1 if tr else taps)) ** 0.5)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    y0, og = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, k, s, tr, sc, sh, None, 0)
+    r = torch.randn(y0.shape, generator=g) if res else None
+    y_o, _ = oracle_ops.conv3d_cl_bf16x3(x, hi, lo, grid, k, s, tr, sc, sh, r, relu)
+    args = (x.cuda(), hi.cuda(), lo.cuda(), grid, k, s, tr, sc.cuda(), sh.cuda(), r.cuda() if res else None, relu)
+    try:
+        gpu_ops.lib.call("sgc_set_tuning", b"split_min_steps", min_steps)
+        n_ws = int(gpu_ops.lib._dll.sgc_conv3d_workspace_floats(*grid, cin, cout, k, s, 1 if tr else 0, 1))
+        assert n_ws >= 3 * y_o.numel()                       # the layer IS split, at least three ways
+        y_a, og_g = gpu_ops.conv3d_cl_bf16x3(*args)
+        y_b, _ = gpu_ops.conv3d_cl_bf16x3(*args)
+        gpu_ops.lib.call("sgc_set_tuning", b"split_free", 0)
+        y_t, _ = gpu_ops.conv3d_cl_bf16x3(*args)
+    finally:
+        gpu_ops.lib.call("sgc_set_tuning", b"split_free", 1)
+        gpu_ops.lib.call("sgc_set_tuning", b"split_min_steps", 8)
+    assert tuple(og_g) == tuple(og)
+    scale = max(1.0, float(y_o.abs().max()))
+    assert float((y_a.cpu() - y_o).abs().max()) <= 1e-4 * scale
+    assert torch.equal(y_a, y_b)
+    assert float((y_a - y_t).abs().max()) <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("grid,cin,cout", [((40, 40, 16), 128, 28), ((20, 20, 8), 128, 28), ((10, 10, 4), 128, 28), ((12, 12, 4), 64, 200),
                                            ((24, 24, 8), 128, 24)])
 def test_conv_with_the_head_activation_in_its_epilogue(grid, cin, cout, oracle_ops, gpu_ops):

@@ -73,6 +73,9 @@ if args.profile:
     rows = sorted(allrows, key=lambda e: -e.device_time_total)[:25]
     for e in rows:
         print(f"{e.device_time_total / 2e3:9.3f} ms/step  x{e.count // 2:<5d} {e.key[:110]}", file=sys.stderr)
+    print("by launch count (the step is launch-bound on the host):", file=sys.stderr)
+    for e in sorted(allrows, key=lambda e: -e.count)[:25]:
+        print(f"    x{e.count // 2:<5d} {e.device_time_total / 2e3:9.3f} ms/step  {e.key[:110]}", file=sys.stderr)
 if args.cprofile:
     import cProfile, pstats, io
     pr = cProfile.Profile()
