@@ -370,6 +370,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
   //  split-K layers.  Two resident workgroups at 88 VGPRs hide more latency than the deeper prefetch.)
   float4 ra[ACH];
   uint4 rbh[BCH], rbl[BCH];
+  if constexpr ((SGC_TILE_SKIP & 6) != 0) {               // timing builds: the registers the skipped loads would have filled
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) ra[i] = make_float4(1.f + tid, 2.f, 3.f, 4.f);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) { rbh[i] = make_uint4(tid, 1, 2, 3); rbl[i] = make_uint4(3, 2, 1, tid); }
+  }
   int ld_tap = p.transposed ? parity : step_lo / ksteps_c;       // (tap, channel chunk) of the NEXT load_step
   int ld_kc = p.transposed ? step_lo : step_lo % ksteps_c;
   set_tap(ld_tap);
@@ -378,11 +384,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     const int soff_b = __builtin_amdgcn_readfirstlane((ld_tap * p.Cout * p.Cin + ld_kc * BK) * 2);
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
+      if constexpr ((SGC_TILE_SKIP & 2) != 0) break;      // timing builds (diag.hpp): no input loads
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff[i], soff_a, 0);
       ra[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
+      if constexpr ((SGC_TILE_SKIP & 4) != 0) break;      // timing builds: no weight loads
       const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(whr, boff[i], soff_b, 0);
       rbh[i] = make_uint4(h[0], h[1], h[2], h[3]);
       if constexpr (NP == 3) {
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
     }
   };
   auto store_step = [&](int buf) {
+    if constexpr ((SGC_TILE_SKIP & 8) != 0) { if (p.relu != 77) return; }    // timing builds: no split, no LDS stores
     __bf16 *a_hi = base + buf * BUF, *a_lo = a_hi + A_PLANE, *b_hi = a_lo + A_PLANE, *b_lo = b_hi + B_PLANE;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
@@ -444,6 +453,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      if constexpr ((SGC_TILE_SKIP & 16) != 0) {           // timing builds: no fragment reads
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ah[i] = (bf16x8)(__bf16)(float)(lane + kk); al[i] = (bf16x8)(__bf16)(float)(lane + 2 * kk); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bh[j] = (bf16x8)(__bf16)(float)(wid + kk); bl[j] = (bf16x8)(__bf16)(float)(wid + 3 * kk); }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + i * 32 * LDKH + kk * 16);
@@ -453,6 +468,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const bf16x8 *>(b_hi + j * 32 * LDKH + kk * 16);
         if constexpr (NP == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + j * 32 * LDKH + kk * 16);
+      }
+      }
+      if constexpr ((SGC_TILE_SKIP & 1) != 0) {            // timing builds: everything but the MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -466,8 +489,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3d_igemm_bf16x3_kernel(const
         }
     }
     if (s + 1 < nsteps) store_step(buf ^ 1);
-    __syncthreads();
+    if constexpr ((SGC_TILE_SKIP & 32) == 0) __syncthreads();     // timing builds: no barrier per step
   }
+  if constexpr ((SGC_TILE_SKIP & 64) != 0) { if (p.relu != 77) return; }      // timing builds: no epilogue
 
   // Epilogue through LDS: in the MFMA layout a lane owns ONE column and 16 rows of a tile, i.e. 4-byte stores, 32 per
   // lane -- store-issue bound (PMC on the K = 256 Linears: waves parked 54 % of their cycles, matrix pipe busy 20 %).

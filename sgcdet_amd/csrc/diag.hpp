@@ -21,6 +21,9 @@
 #if !defined(SGC_HALO_SKIP)
 #define SGC_HALO_SKIP 0
 #endif
+#if !defined(SGC_TILE_SKIP)
+#define SGC_TILE_SKIP 0    // timing builds of the tile implicit GEMM (conv3d_igemm_bf16x3_kernel): 1 no MFMAs, 2 no input loads, 4 no weight
+#endif                     // loads, 8 no split + LDS stores, 16 no fragment reads, 32 no barrier per step, 64 no epilogue (tools/tile_skip.py)
 
 #if defined(SGC_HALO_STAMPS)
 namespace sgc { inline unsigned long long *g_halo_stamp_buf = nullptr; }
