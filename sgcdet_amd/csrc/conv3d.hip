@@ -1369,6 +1369,8 @@ static int pick_split_steps(const ConvParams &p, int mb, int nb, int target_bloc
   const int total = (p.transposed ? 1 : p.taps) * (p.Cin / BK);
   *steps_per = total;
   if (p.two_d) return 1;                       // the 2-D entry point carries no workspace
+  if (!p.transposed && p.taps == 1) return 1;  // 1x1x1 layers are plain GEMMs: one K order everywhere (sgc_level_tail and the row GEMM are
+                                               // tested bit for bit against this kernel); splitting them bought 1 us of 18 alone
   if (!g_tune_split_free) {
     const int k = pick_splitk(p, mb, nb, target_blocks);
     *steps_per = total / k;

@@ -585,7 +585,7 @@ def test_tile_kernel_options_are_bit_identical(cin, cout, grid, k, s, tr, oracle
 @pytest.mark.parametrize("cin,cout,grid,k,s,tr,min_steps,res,relu", [
     (160, 128, (8, 6, 4), 3, 2, False, 8, True, 1),      # 135 K steps in 15 splits of 9: boundaries INSIDE taps (5 chunks per tap)
     (256, 96, (5, 4, 3), 2, 2, True, 2, False, 1),       # transposed: the 8 channel chunks of a parity in 4 splits
-    (96, 128, (6, 6, 4), 1, 2, False, 1, False, 0),      # 1x1x1 stride 2: one split per channel chunk
+    (96, 128, (6, 6, 4), 3, 2, False, 1, False, 0),      # one split per K step (81 steps, capped at 32 splits of 3)
     (64, 200, (7, 5, 3), 3, 1, False, 4, True, 2),       # ragged rows / columns, 54 steps in 11 splits of 5 (the last one holds 4)
 ])
 def test_tile_kernel_splits_of_whole_steps_against_the_oracle(cin, cout, grid, k, s, tr, min_steps, res, relu, oracle_ops, gpu_ops):
