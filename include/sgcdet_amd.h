@@ -57,9 +57,11 @@ typedef void *sgc_stream_t; /* hipStream_t */
 
 int sgc_abi_version(void);
 /* Development knobs (A/B of kernel variants and launch geometries in one process; keys in csrc/dfa3d_fwd.hip).  Results do not
- * depend on them, with one stated exception: "split_target" / "halo_split_target" choose over how many workgroups a layer with
- * few voxels splits its reduction -- a different split adds the same partial sums in another order (fp32 rounding, <= 1e-5 of
- * the tensor scale; deterministic for a given value).                                                                      */
+ * depend on them, with one stated exception: "split_target" / "halo_split_target" (and, round 6, "split_free" / "split_min_steps" /
+ * "split_max": the tile kernel splits at any K step, see pick_split_steps in csrc/conv3d.hip) choose over how many workgroups a
+ * layer with few voxels splits its reduction -- a different split adds the same partial sums in another order (fp32 rounding,
+ * <= 1e-5 of the tensor scale; deterministic for a given value).  sgc_conv3d_workspace_floats follows the current values:
+ * query it under the setting the call will run with.                                                                       */
 int sgc_set_tuning(const char *key, int value);
 /* Arithmetic mode of every bf16 MFMA kernel of the library (sgc_conv3d_cl_bf16x3 and its 2-D / masked forms,
  * sgc_linear_rows_*_bf16x3, sgc_level_tail):
