@@ -17,6 +17,7 @@ ap.add_argument("--input-layout", default="nchw", choices=["nchw", "nhwc"],
                 help="memory layout of the feature / depth maps handed to the path (nhwc = what plugin/fpn.py produces)")
 ap.add_argument("--wgrad-layers", action="store_true", help="list every weight-gradient call of one step: shapes, kernel form, time")
 ap.add_argument("--cprofile", action="store_true", help="host side: the 45 python functions with the most own time over 5 steps (the step is launch-bound)")
+ap.add_argument("--sites", action="store_true", help="torch ops of one step by the line of this package that issues them (a TorchDispatchMode: forward and backward)")
 ap.add_argument("--glue", action="store_true", help="attribute the torch glue ops (copy / add / fill / sum / mul ...) to source lines of this package")
 args = ap.parse_args()
 w = workload(args.workload)
@@ -76,6 +77,29 @@ if args.profile:
     print("by launch count (the step is launch-bound on the host):", file=sys.stderr)
     for e in sorted(allrows, key=lambda e: -e.count)[:25]:
         print(f"    x{e.count // 2:<5d} {e.device_time_total / 2e3:9.3f} ms/step  {e.key[:110]}", file=sys.stderr)
+if args.sites:
+    import collections, traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = collections.Counter()
+
+    class Sites(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, a=(), kw=None):
+            out = func(*a, **(kw or {}))
+            name = func.__name__ if hasattr(func, "__name__") else str(func)
+            if any(k in name for k in ("fill", "zero", "copy", "add", "cat", "sum", "mul", "div", "index", "clone", "contiguous", "to_copy")):
+                fr = [f for f in traceback.extract_stack() if f.filename.startswith(root) and "/tools/" not in f.filename]
+                where = f"{os.path.relpath(fr[-1].filename, root)}:{fr[-1].lineno}" if fr else "(no frame of this package)"
+                shape = tuple(out.shape) if isinstance(out, torch.Tensor) else ()
+                seen[(name, where, shape)] += 1
+            return out
+
+    with Sites():
+        step()
+    torch.cuda.synchronize()
+    print("torch ops of one step by issuing line (count, op, line, result shape):", file=sys.stderr)
+    for (name, where, shape), n in sorted(seen.items(), key=lambda kv: (-kv[1], kv[0][1])):
+        print(f"  x{n:<4d} {name:28s} {where:46s} {shape}", file=sys.stderr)
 if args.cprofile:
     import cProfile, pstats, io
     pr = cProfile.Profile()
