@@ -130,7 +130,8 @@ def algorithmic_bytes(n_views, hw, C, D, M, P, pairs, s=4):
 # (MFMA roofline); together they are the work the whole-path floor of `path_roofline` is made of
 PATH_KERNELS = {"sgc_pairs_deform_gather", "sgc_pairs_deform_gather_tiled", "sgc_pairs_geometry_sample", "sgc_conv3d_cl_bf16x3",
                 "sgc_conv3d_cl_bf16x3_masked", "sgc_conv3d_cl_bf16x3_act", "sgc_conv3d_winograd_z_bf16x3", "sgc_conv3d_cl_f32", "sgc_linear_rows_bf16x3",
-                "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3", "sgc_pairs_geometry_linear_bf16x3"}
+                "sgc_linear_rows_zrow_bf16x3", "sgc_linear_rows_headmajor_bf16x3", "sgc_pairs_geometry_linear_bf16x3",
+                "sgc_linear_rows_blockdiag_bf16x3"}
 
 
 def usable_cores():

@@ -572,6 +572,18 @@ int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint
 int sgc_linear_rows_headmajor_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                      void *y, int y_bf16, int N, int S, int Cin, int M, int Cm, sgc_stream_t stream);
 
+/* Block-diagonal Linear over a row list (round 6): y[r][g * Nh + j] = sum_k x[r][g * K + k] * w[g][j][k] + shift[g * Nh + j]
+ * -- the per-voxel V projection of the projected-query attention (head g multiplies the attention-weighted raw feature
+ * sgc_view_attend_pq leaves for it with its own rows of nn.MultiheadAttention.in_proj_weight,
+ * TU/deformable_cross_attention.py:826-833) without the 7/8 zero blocks of the dense [G K -> G Nh] form.
+ *   x [rows_cap][G K] fp32, w_hi / w_lo [G][Nh][K] bf16 split, y [rows_cap][G Nh]; rows as in sgc_linear_rows_bf16x3.
+ *   Same products and K order as sgc_linear_rows_bf16x3 on the dense block-diagonal matrix: BIT-IDENTICAL results.
+ *   Supported: G == 8, K in {128, 256}, Nh == K / 8 (sgc_linear_rows_blockdiag_supported); SGC_EUNSUP otherwise. */
+int sgc_linear_rows_blockdiag_supported(int G, int K, int Nh);
+int sgc_linear_rows_blockdiag_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift_or_null,
+                                     float *y, const int32_t *rows_dev_or_null, int rows_cap, int G, int K, int Nh,
+                                     sgc_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * 7b. Row-wise glue of the coarse-to-fine head (no library kernels inside the scene graphs)
  * ------------------------------------------------------------------------- */

@@ -1336,6 +1336,29 @@ int sgc_pairs_geometry_linear_bf16x3(const float *feat, const float *dist, const
   return rc;
 }
 
+/* block-diagonal Linear: group g's K inputs -> its Nh outputs (product: csrc/rows_blockdiag.hip; reference: the V rows of
+ * nn.MultiheadAttention.in_proj_weight applied per head, TU/deformable_cross_attention.py:826-833).  Here: one sgc_linear_rows_bf16x3
+ * per group on a copy of its K columns. */
+int sgc_linear_rows_blockdiag_supported(int G, int K, int Nh) { return G > 0 && K % 32 == 0 && Nh % 4 == 0; }
+int sgc_linear_rows_blockdiag_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift_or_null,
+                                     float *y, const int32_t *rows_dev_or_null, int rows_cap, int G, int K, int Nh,
+                                     sgc_stream_t stream) {
+  if (!x || !w_hi || !w_lo || !y) return fail(SGC_EINVAL, "null pointer");
+  int rows = rows_cap;
+  if (rows_dev_or_null && *rows_dev_or_null < rows) rows = *rows_dev_or_null;
+  if (rows <= 0) return SGC_OK;
+  float *xg = (float *)malloc(sizeof(float) * (size_t)rows * K), *yg = (float *)malloc(sizeof(float) * (size_t)rows * Nh);
+  int rc = SGC_OK;
+  for (int g = 0; g < G && !rc; ++g) {
+    for (int r = 0; r < rows; ++r) memcpy(xg + (size_t)r * K, x + (size_t)r * G * K + (size_t)g * K, sizeof(float) * K);
+    rc = sgc_linear_rows_bf16x3(xg, w_hi + (size_t)g * Nh * K, w_lo + (size_t)g * Nh * K, shift_or_null ? shift_or_null + g * Nh : NULL,
+                                yg, NULL, rows, K, Nh, stream);
+    for (int r = 0; r < rows && !rc; ++r) memcpy(y + (size_t)r * G * Nh + (size_t)g * Nh, yg + (size_t)r * Nh, sizeof(float) * Nh);
+  }
+  free(xg); free(yg);
+  return rc;
+}
+
 /* the same with one all-zero row behind the result (y holds rows_cap + 1 rows) */
 int sgc_linear_rows_zrow_bf16x3(const float *x, const uint16_t *w_hi, const uint16_t *w_lo, const float *shift,
                                 float *y, const int32_t *rows_dev_or_null, int rows_cap, int Cin, int Cout,

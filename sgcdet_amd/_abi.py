@@ -50,6 +50,7 @@ SIGNATURES = {
     "sgc_valid_pyramid": [_p, _p, _i, _i, _i, _i, _p],
     "sgc_linear_rows_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
     "sgc_linear_rows_zrow_bf16x3": [_p] * 6 + [_i] * 3 + [_p],
+    "sgc_linear_rows_blockdiag_bf16x3": [_p] * 6 + [_i] * 4 + [_p],
     "sgc_level_tail": [_p] * 7 + [_f] + [_p] * 8 + [_f] + [_p] + [_i] * 3 + [_p],
     "sgc_topk_select": [_p, _i, _i, _p, _p, _p, _p],
     "sgc_topk_select_ws": [_p, _i, _i, _p, _p, _p, _p, C.c_int64, _p],
@@ -90,6 +91,7 @@ INTROSPECTION = {
     "sgc_bin_pairs_workspace_bytes": (C.c_int64, [_i] * 7),
     "sgc_dfa3d_backward_binned_lds_bytes": (C.c_int64, [_i] * 8),
     "sgc_pairs_geometry_linear_supported": (C.c_int, [_i] * 4),
+    "sgc_linear_rows_blockdiag_supported": (C.c_int, [_i] * 3),
     "sgc_pairs_geometry_linear_workspace_bytes": (C.c_int64, [_i]),
 }
 

@@ -264,6 +264,24 @@ def rows_to_ncdhw(rows, grid, channels):
     return rows.view(X, Y, Z, rows.shape[1])[..., :channels].permute(3, 0, 1, 2).unsqueeze(0)
 
 
+class BlockDiagSpec:
+    """A block-diagonal Linear [G * K -> G * Nh] kept as its G blocks (``sgc_linear_rows_blockdiag_bf16x3``): group g's K inputs times
+    its own [Nh, K] weight.  ``weight`` [G, Nh, K], ``bias`` [G * Nh]."""
+
+    def __init__(self, weight, bias):
+        w = weight.detach().float().contiguous()
+        self.G, self.Nh, self.K = w.shape
+        self.w_hi, self.w_lo = ext.ops().split_operand(w)
+        self.shift = bias.detach().float().contiguous() if bias is not None else None
+
+    @staticmethod
+    def supported(G, K, Nh):
+        return CONV_MODE == "bf16x3" and ext.ops().linear_rows_blockdiag_supported(G, K, Nh)
+
+    def __call__(self, x, count=None):
+        return ext.ops().linear_rows_blockdiag(x, self.w_hi, self.w_lo, self.shift, count=count)
+
+
 class LinearSpec:
     """nn.Linear (or a row-block of stacked weights) prepared for ``sgc_conv3d_cl_bf16x3`` as a 1x1x1
     convolution over M rows: y[M, out] = x[M, in] @ W^T + b on the bf16 matrix cores with the 3-way split."""

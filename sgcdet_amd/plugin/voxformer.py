@@ -45,7 +45,7 @@ from ..mmcv_lite import (ATTENTION, TRANSFORMER, TRANSFORMER_LAYER, TRANSFORMER_
                          build_transformer_layer_sequence, constant_init, xavier_init)
 from ..functions import MultiScale3DDeformableAttnFunction_fp32
 from .. import ext
-from .conv_plan import LinearSpec, module_fingerprint
+from .conv_plan import BlockDiagSpec, LinearSpec, module_fingerprint
 
 
 def _ops():
@@ -327,21 +327,25 @@ class DeformCrossAttention_DFA3D(BaseModule):
     # Projected-query form of the inter-view attention (sgc_view_attend_pq, round 5): K and V leave the pair list.
     #   "auto": wherever the kernel supports the shape (8 heads, C in {128, 256}, <= 128 views) and a voxel is seen by enough
     #           cameras for the per-voxel GEMMs (C -> heads * C and heads * C -> C) to cost less than the per-pair K | V GEMM
-    #           (C -> 2C on every visible pair): with the block-diagonal V run as a dense GEMM the break-even was MEASURED at ~45 ring views;
+    #           (C -> 2C on every visible pair): break-even MEASURED at ~30 ring views with V head by head (~45 with the dense 8C -> C GEMM);
     #   True / False force it on (where supported) / off.  Same function of the inputs either way (~1e-6: association of sums).
     projected_query = {"0": False, "1": True}.get(__import__("os").environ.get("SGC_PROJECTED_QUERY", ""), "auto")   # env: A/B runs
-    projected_query_min_views = 48      # measured (profiles/r05_pq_ab.txt): 40 views -1 %, 50 views +1 %, 60 views +2.6 %, 100 views +9.8 %
+    # measured with V head by head (round 6, profiles/r06_pq_views.txt, r06_pq_ab.txt; config-2 shapes, four scenes in flight): 8 / 12 / 16 / 20
+    # views -2 % / -1.3 % / -1.1 % / -0.6 %, 30 views even, 40 views +1.7 %, 100 views +1.5 % over the dense-V form that was already +9.8 %
+    # over the per-pair K | V GEMM there.  (Round 5, dense 8C -> C V projection: break-even at ~45 views, profiles/r05_pq_ab.txt.)
+    projected_query_min_views = 32
     # The form's two transients (projected queries and attention-weighted features) are [voxel capacity, heads * C] fp32 EACH: 0.6 GB per
     # level and scene in flight at config 5's 73.7 k voxels.  Past this many bytes for the pair the level keeps the per-pair K | V GEMM
     # (whose transient grows with the pairs instead).  A static rule on shapes: nothing is queried while a graph is being captured.
     projected_query_max_bytes = 2 << 30
+    projected_query_blockdiag = __import__("os").environ.get("SGC_PQ_BLOCKDIAG", "1") != "0"     # V head by head (round 6); 0 = the dense 8C -> C GEMM
 
     def _projected_query_plan(self, mha, plan):
         """qp = scale * W_k,h^T q_h as ONE Linear on the pooled feature (composed with the q / output projections of `qo`), and
         V as a block-diagonal Linear heads * C -> C; composed in float64, stored fp32 (the GEMMs then run like every other)."""
         C, Hn = self.embed_dims, mha.num_heads
         if not _ops().view_attend_pq_supported(1, C, Hn):
-            return dict(qp=None, vbd=None)
+            return dict(qp=None, vbd=None, vbd_g=None)
         hd = C // Hn
         w = mha.in_proj_weight.detach().double()
         b = mha.in_proj_bias.detach().double()
@@ -354,7 +358,12 @@ class DeformCrossAttention_DFA3D(BaseModule):
         wbd = torch.zeros((C, Hn * C), dtype=torch.float64, device=w.device)
         for h in range(Hn):
             wbd[h * hd:(h + 1) * hd, h * C:(h + 1) * C] = wv[h * hd:(h + 1) * hd]
-        return dict(qp=LinearSpec(wqp.float(), bqp.float()), vbd=LinearSpec(wbd.float(), bv.float(), useful=1.0 / Hn))
+        # the same V projection kept as its Hn blocks (round 6, sgc_linear_rows_blockdiag_bf16x3: x read once, no zero blocks); the dense
+        # form above stays as the A/B twin (SGC_PQ_BLOCKDIAG=0) and for shapes the block kernel does not take
+        vg = None
+        if self.projected_query_blockdiag and BlockDiagSpec.supported(Hn, C, hd):
+            vg = BlockDiagSpec(wv.view(Hn, hd, C).float(), bv.float())
+        return dict(qp=LinearSpec(wqp.float(), bqp.float()), vbd=LinearSpec(wbd.float(), bv.float(), useful=1.0 / Hn), vbd_g=vg)
 
     def _use_projected_query(self, gemm, n_views, n_rows_cap=0):
         if gemm is None or gemm.get("qp") is None or self.projected_query is False:
@@ -475,7 +484,7 @@ class DeformCrossAttention_DFA3D(BaseModule):
                 qp = gemm["qp"](mean, count=valid_cnt)                                   # [n_valid, heads * C]
                 sw = ops.view_attend_pq(qp, per_pair, slot, valid_index, mha.num_heads, count=valid_cnt)
                 del qp
-                ctx = gemm["vbd"](sw, count=valid_cnt)                                   # [n_valid, C]
+                ctx = (gemm["vbd_g"] if gemm.get("vbd_g") is not None else gemm["vbd"])(sw, count=valid_cnt)     # [n_valid, C]
                 del sw
             else:
                 if use_mfma:

@@ -762,6 +762,28 @@ class TensorOps:
             self._call("sgc_linear_rows_bf16x3", x, w_hi, w_lo, shift, y, count, rows, Cin, Cout, _meta=meta)
         return y
 
+    def linear_rows_blockdiag_supported(self, G, K, Nh):
+        return bool(self.lib._dll.sgc_linear_rows_blockdiag_supported(int(G), int(K), int(Nh)))
+
+    def linear_rows_blockdiag(self, x, w_hi, w_lo, shift=None, count=None):
+        """y[r, g * Nh + j] = x[r, g * K : (g + 1) * K] @ w[g, j] + shift[g * Nh + j] for the first ``count`` rows: x [rows_cap, G * K],
+        w_hi / w_lo [G, Nh, K] (the operand split of the current arithmetic mode) -> [rows_cap, G * Nh]
+        (``sgc_linear_rows_blockdiag_bf16x3``: the V projection of the projected-query attention, head by head)."""
+        self._check(x=x, w_hi=w_hi, w_lo=w_lo, shift=shift, count=count)
+        self._f32(x=x, shift=shift)
+        self._i32(count=count)
+        if w_hi.dtype != torch.bfloat16 or w_lo.dtype != torch.bfloat16 or w_hi.shape != w_lo.shape or w_hi.dim() != 3:
+            raise RuntimeError("linear_rows_blockdiag: w_hi / w_lo must be bfloat16 tensors [G, Nh, K] of one shape")
+        G, Nh, K = w_hi.shape
+        rows = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != G * K:
+            raise RuntimeError("linear_rows_blockdiag: x must be [rows, G * K]")
+        y = torch.empty((rows, G * Nh), dtype=torch.float32, device=x.device)
+        if rows:
+            self._call("sgc_linear_rows_blockdiag_bf16x3", x, w_hi, w_lo, shift, y, count, rows, G, K, Nh,
+                       _meta=dict(V=rows, Cin=G * K, Cout=G * Nh, taps=1, OV=rows, useful=1.0 / G))
+        return y
+
     def conv2d_nhwc_bf16x3(self, x, w_hi, w_lo, nhw, ksize, scale=None, shift=None, residual=None, relu=False, out=None):
         """2-D convolution (k in {1,3}, padding k//2, stride 1) over channels-last image rows: x [N*H*W, Cin] ->
         [N*H*W, Cout]; weights [k*k, Cout, Cin] split as ``split_bf16`` (``sgc_conv2d_nhwc_bf16x3``)."""

@@ -1166,6 +1166,38 @@ def test_projected_query_attention_against_oracle(N, Nq, C, oracle_ops, gpu_ops)
         gpu_ops.view_attend_pq(cu(qp[:, :4 * C].contiguous()), cu(x), cu(slot), cu(valid_index), 4)
 
 
+@pytest.mark.parametrize("rows,K", [(6400, 256), (77, 256), (5000, 128), (33, 128), (40001, 128)])
+def test_block_diagonal_linear_against_oracle_and_its_dense_form(rows, K, oracle_ops, gpu_ops):
+    """sgc_linear_rows_blockdiag_bf16x3 (the V projection of the projected-query attention, head by head): against the oracle's
+    per-group Linear, BIT-IDENTICAL to sgc_linear_rows_bf16x3 on the dense block-diagonal matrix it replaces (same products, same
+    K order; the zero blocks add exact zeros), ragged row counts, the device-side count (rows past it untouched), repeatable."""
+    G, Nh = 8, K // 8
+    g = torch.Generator().manual_seed(rows + K)
+    n_small = min(rows, 600)                                # the scalar oracle on a slice, the dense GPU form on everything
+    x = torch.randn(rows, G * K, generator=g)
+    w = torch.randn(G, Nh, K, generator=g) * (1.0 / K ** 0.5)
+    b = torch.randn(G * Nh, generator=g) * 0.1
+    hi, lo = gpu_ops.split_bf16(w)
+    assert gpu_ops.linear_rows_blockdiag_supported(G, K, Nh) and not gpu_ops.linear_rows_blockdiag_supported(4, K, Nh)
+    y = gpu_ops.linear_rows_blockdiag(x.cuda(), hi.cuda(), lo.cuda(), b.cuda())
+    want = oracle_ops.linear_rows_blockdiag(x[:n_small].contiguous(), hi, lo, b)
+    assert float((y[:n_small].cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    dense = torch.zeros(G * Nh, G * K)
+    for h in range(G):
+        dense[h * Nh:(h + 1) * Nh, h * K:(h + 1) * K] = w[h]
+    dhi, dlo = gpu_ops.split_bf16(dense.view(1, G * Nh, G * K))
+    y_dense = gpu_ops.linear_rows_bf16x3(x.cuda(), dhi.cuda(), dlo.cuda(), b.cuda())
+    assert torch.equal(y, y_dense)
+    assert torch.equal(y, gpu_ops.linear_rows_blockdiag(x.cuda(), hi.cuda(), lo.cuda(), b.cuda()))
+    # device-side count: rows past it are neither read nor written
+    cnt = torch.tensor([max(1, rows - 7)], dtype=torch.int32, device="cuda")
+    part = gpu_ops.linear_rows_blockdiag(x.cuda(), hi.cuda(), lo.cuda(), b.cuda(), count=cnt)
+    n = int(cnt.item())
+    assert torch.equal(part[:n], y[:n])
+    with pytest.raises(RuntimeError):
+        gpu_ops.linear_rows_blockdiag(x[:, :G * K - 32].contiguous().cuda(), hi.cuda(), lo.cuda(), b.cuda())
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(3000, 256, 256), (777, 64, 36), (12800, 128, 128)])
 def test_linear_rows_with_the_zero_row_behind_the_result(rows, cin, cout, oracle_ops, gpu_ops):
     """sgc_linear_rows_zrow_bf16x3: the Linear's rows are bit-identical to sgc_linear_rows_bf16x3 (persistent row GEMM and tile

@@ -101,3 +101,29 @@ def test_oracle_batch_norm_rows_is_torch_batch_norm(oracle_ops):
         y_ref.backward(dy.double())
         assert torch.allclose(dx.double(), xd.grad, atol=2e-5)
         assert torch.allclose(dw.double(), wd.grad, atol=2e-4) and torch.allclose(db.double(), bd.grad, atol=2e-4)
+
+
+def test_oracle_block_diagonal_linear_is_the_per_head_matmul(oracle_ops):
+    """Oracle twin of sgc_linear_rows_blockdiag_bf16x3: group g's K inputs times its own [Nh, K] weight -- the V rows of
+    nn.MultiheadAttention.in_proj_weight applied head by head (TU/deformable_cross_attention.py:826-833) -- against float64 torch,
+    and against nn.MultiheadAttention's own in-projection of V on a feature that is the same for every head."""
+    G, K, Nh, rows = 8, 128, 16, 50
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, G * K, generator=g)
+    w = torch.randn(G, Nh, K, generator=g) * 0.1
+    b = torch.randn(G * Nh, generator=g) * 0.1
+    hi, lo = oracle_ops.split_bf16(w)
+    y = oracle_ops.linear_rows_blockdiag(x, hi, lo, b)
+    want = torch.cat([x[:, h * K:(h + 1) * K].double() @ w[h].double().t() for h in range(G)], 1) + b.double()
+    assert float((y.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    mha = torch.nn.MultiheadAttention(K, G)
+    wv, bv = mha.in_proj_weight.detach()[2 * K:], mha.in_proj_bias.detach()[2 * K:]
+    feat = torch.randn(rows, K, generator=g)
+    hi, lo = oracle_ops.split_bf16(wv.view(G, Nh, K).contiguous())
+    y = oracle_ops.linear_rows_blockdiag(feat.repeat(1, G).contiguous(), hi, lo, bv)
+    want = torch.nn.functional.linear(feat.double(), wv.double(), bv.double())
+    assert float((y.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    # the device-side count leaves the rows past it untouched
+    cnt = torch.tensor([20], dtype=torch.int32)
+    part = oracle_ops.linear_rows_blockdiag(feat.repeat(1, G).contiguous(), hi, lo, bv, count=cnt)
+    assert torch.equal(part[:20], y[:20])
