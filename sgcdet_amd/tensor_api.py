@@ -781,7 +781,7 @@ class TensorOps:
         y = torch.empty((rows, G * Nh), dtype=torch.float32, device=x.device)
         if rows:
             self._call("sgc_linear_rows_blockdiag_bf16x3", x, w_hi, w_lo, shift, y, count, rows, G, K, Nh,
-                       _meta=dict(V=rows, Cin=G * K, Cout=G * Nh, taps=1, OV=rows, useful=1.0 / G))
+                       _meta=dict(V=rows, Cin=K, Cout=G * Nh, taps=1, OV=rows))     # 2 K Nh multiply-adds per row and group: the algorithmic count
         return y
 
     def conv2d_nhwc_bf16x3(self, x, w_hi, w_lo, nhw, ksize, scale=None, shift=None, residual=None, relu=False, out=None):
