@@ -1198,6 +1198,31 @@ def test_block_diagonal_linear_against_oracle_and_its_dense_form(rows, K, oracle
         gpu_ops.linear_rows_blockdiag(x[:, :G * K - 32].contiguous().cuda(), hi.cuda(), lo.cuda(), b.cuda())
 
 
+def test_block_diagonal_linear_in_the_one_product_modes(gpu_ops):
+    """The opt-in arithmetic modes (plain bf16 / plain fp16 products, sgc_set_conv_products 1 / 2) of the block-diagonal Linear: the
+    dense form in the same mode, bit for bit (the plugin keeps the dense GEMM in those modes; the entry point follows the mode)."""
+    G, K, Nh, rows = 8, 256, 32, 1000
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(rows, G * K, generator=g).cuda()
+    w = (torch.randn(G, Nh, K, generator=g) * (1.0 / K ** 0.5)).cuda()
+    b = (torch.randn(G * Nh, generator=g) * 0.1).cuda()
+    dense = torch.zeros(1, G * Nh, G * K, device="cuda")
+    for h in range(G):
+        dense[0, h * Nh:(h + 1) * Nh, h * K:(h + 1) * K] = w[h]
+    try:
+        for mode in (1, 2):
+            gpu_ops.lib.call("sgc_set_conv_products", mode)
+            hi, lo = gpu_ops.split_operand(w)
+            dhi, dlo = gpu_ops.split_operand(dense)
+            y = gpu_ops.linear_rows_blockdiag(x, hi, lo, b)
+            assert torch.equal(y, gpu_ops.linear_rows_bf16x3(x, dhi, dlo, b)), mode
+            ref = torch.cat([x[:, h * K:(h + 1) * K].double() @ w[h].double().t() for h in range(G)], 1) + b.double()
+            err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+            assert 1e-6 < err < (2.0 ** -6 if mode == 1 else 2.0 ** -9), (mode, err)
+    finally:
+        gpu_ops.lib.call("sgc_set_conv_products", 3)
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(3000, 256, 256), (777, 64, 36), (12800, 128, 128)])
 def test_linear_rows_with_the_zero_row_behind_the_result(rows, cin, cout, oracle_ops, gpu_ops):
     """sgc_linear_rows_zrow_bf16x3: the Linear's rows are bit-identical to sgc_linear_rows_bf16x3 (persistent row GEMM and tile
