@@ -1200,7 +1200,7 @@ def test_block_diagonal_linear_against_oracle_and_its_dense_form(rows, K, oracle
 
 def test_block_diagonal_linear_in_the_one_product_modes(gpu_ops):
     """The opt-in arithmetic modes (plain bf16 / plain fp16 products, sgc_set_conv_products 1 / 2) of the block-diagonal Linear: the
-    dense form in the same mode, bit for bit (the plugin keeps the dense GEMM in those modes; the entry point follows the mode)."""
+    dense form in the same mode, bit for bit (the entry point follows the process-wide mode like every MFMA kernel of the library)."""
     G, K, Nh, rows = 8, 256, 32, 1000
     g = torch.Generator().manual_seed(99)
     x = torch.randn(rows, G * K, generator=g).cuda()
