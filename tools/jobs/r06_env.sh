@@ -15,5 +15,5 @@ for rnd in 1 2; do
   run "HIP_FORCE_DEV_KERNARG=1" HIP_FORCE_DEV_KERNARG=1
   run "HIP_FORCE_DEV_KERNARG=0" HIP_FORCE_DEV_KERNARG=0
   run "GPU_MAX_HW_QUEUES=4" GPU_MAX_HW_QUEUES=4
-  run "DEBUG_HIP_GRAPH_DOT_PRINT=0 HIP_GRAPH_... none" A=2
+  run "default (again)                            " A=2
 done
