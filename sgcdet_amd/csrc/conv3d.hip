@@ -908,6 +908,9 @@ __global__ __launch_bounds__(512) void conv3d_halo_bf16x3_kernel(const ConvParam
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(f.bh[j]), "v"(f.bl[j]));
       return;
     }
+    // (s_setprio 2 around this cluster -- the wave that feeds the matrix pipe first at the issue arbiter -- or around everything else:
+    //  181.9 / 181.7 against 182.7 us on the 90-GF Winograd layer, 149.7 / 150.1 against 151.3 on 512 -> 512, bit-identical: noise;
+    //  profiles/r06_wz_prio.txt.  Not kept.)
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
